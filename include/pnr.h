@@ -1,0 +1,139 @@
+/*
+ * pnr.h -- C-ABI of libpnr.so, the MI355X (gfx950) implementation of PanopticNeRF's
+ * render_rays hot path (BASELINE.json north_star).
+ *
+ * Which reference interface each entry point replaces.  The mounted reference
+ * (/root/reference) contains only README.md -- README.md:7 / README.md:13 name the code
+ * branches (`panopticnerf360`, `panopticnerf`) that hold lib/networks/renderer and are NOT
+ * in the mount -- so no file:line can be cited for the functions themselves.  Each entry
+ * below names the reference function (as BASELINE.json's north_star names it) and the
+ * SURVEY.md section-8a row that specifies its arithmetic:
+ *
+ *   pnr_stratified      render_rays' stratified z sampler                 (8a row a3)
+ *   pnr_points          pts = o + d*z                                     (8a row a3)
+ *   pnr_embed           Embedder / get_embedder                           (8a row a4)
+ *   pnr_mlp_*           Network (NeRF 8x256 MLP + semantic/instance heads) (8a row a5)
+ *   pnr_composite       raw2outputs (+ panoptic logit / fixed-field maps) (8a row a6)
+ *   pnr_sample_pdf      sample_pdf + sorted merge with the coarse z       (8a row a7)
+ *   pnr_bbox_hits       ray / 3D-bbox intersection (bbox prior)           (8a row a8)
+ *   pnr_sample_labels   per-sample fixed semantic / instance labels        (8a row a8)
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer; the library never allocates, frees or synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - int return: 0 = PNR_OK, negative = error; pnr_last_error() gives the text
+ *     (thread-local);  no C++ exception crosses the ABI;
+ *   - re-entrant; graph-capture safe (no hipMalloc / sync inside).
+ * Arrays are dense row-major fp32 / int32 unless a stride is given.
+ */
+#ifndef PNR_H
+#define PNR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_OK 0
+#define PNR_EINVAL (-1)  /* bad argument (size, alignment, unsupported configuration) */
+#define PNR_EHIP (-2)    /* a HIP runtime call failed; see pnr_last_error() */
+#define PNR_ENODEV (-3)  /* no gfx950 device */
+
+#define PNR_PREC_BF16 0  /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+#define PNR_PREC_FP32 1  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), parity mode */
+
+int pnr_version(void);
+const char* pnr_last_error(void);
+/* Name of device `dev` copied to buf (host). Returns PNR_ENODEV if it is not gfx950. */
+int pnr_device_check(int dev, char* buf_host, int buflen);
+
+/* ---- a3: stratified sampler.  rays (R,8) = o(3) d(3) near far.  t_rand (R,N) or NULL
+ * (perturb == 0).  z_out (R,N).  Bit-exact with oracle/pnr_oracle.c:pnro_stratified. */
+int pnr_stratified(const float* rays, int64_t n_rays, int n_samples, int lindisp,
+                   const float* t_rand, float* z_out, void* stream);
+
+/* pts_out (R,N,3) = o + d*z.  Bit-exact with pnro_points. */
+int pnr_points(const float* rays, const float* z, int64_t n_rays, int n_samples, float* pts_out,
+               void* stream);
+
+/* ---- a4: Embedder.  x (n,3) -> out (n, 3+6L), [x, sin(2^k x), cos(2^k x)]_k. */
+int pnr_embed(const float* x, int64_t n, int L, float* out, void* stream);
+
+/* ---- a5: fused NeRF MLP + heads.
+ * Geometry of one network.  Trunk: D layers of width W (W = 128 or 256), skip-concat of
+ * gamma(x) after layer `skip` (-1 = none).  sigma, feature(W), views(W+dir -> W/2), rgb.
+ * Optional heads W -> head_W -> n_sem / n_inst (0 = absent). */
+typedef struct pnr_mlp_desc {
+    int32_t D, W, skip;
+    int32_t xyz_L, dir_L;
+    int32_t n_sem, n_inst, head_W;
+    int32_t precision; /* PNR_PREC_* */
+    int32_t reserved[7];
+} pnr_mlp_desc;
+
+/* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
+ * pts_w[i]/pts_b[i] for i < D.  Head pointers may be NULL when the head is absent. */
+typedef struct pnr_mlp_params_host {
+    const float* const* pts_w; const float* const* pts_b;
+    const float* alpha_w; const float* alpha_b;
+    const float* feature_w; const float* feature_b;
+    const float* views_w; const float* views_b;
+    const float* rgb_w; const float* rgb_b;
+    const float* sem0_w; const float* sem0_b; const float* sem1_w; const float* sem1_b;
+    const float* inst0_w; const float* inst0_b; const float* inst1_w; const float* inst1_b;
+} pnr_mlp_params_host;
+
+/* Bytes of the packed (MFMA-fragment-ordered) parameter image for `desc`; <0 on error. */
+int64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc);
+/* Pack host parameters into packed_host (pnr_mlp_packed_bytes bytes, host). Pure CPU. */
+int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, void* packed_host);
+
+/* Evaluate the network on every sample of every ray:
+ *   pts = o + d*z, viewdir = d/||d||, raw = MLP(gamma(pts), gamma(viewdir)).
+ * packed: device copy of the pnr_mlp_pack image.  rays (R,8), z (R,N).
+ * raw element (sample s = r*N+i, channel c) is written at raw[s*raw_stride_s + c*raw_stride_c],
+ * channels = [r g b sigma | n_sem | n_inst].  Channel-major (stride_s=1, stride_c=R*N) is the
+ * fast layout; sample-major (stride_s=4+n_sem+n_inst, stride_c=1) is the reference's. */
+int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                    int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                    int64_t raw_stride_c, void* stream);
+
+/* ---- a6: raw2outputs.  raw strides as above.  noise (R,N) or NULL; label_* (R,N) int32 or
+ * NULL (fixed bbox-prior field, -1 = none).  sem_mode 0: composite logits; 1: softmax first.
+ * Any output pointer may be NULL.  weights (R,N); rgb (R,3); depth (R); acc (R);
+ * sem/fix_sem (R,n_sem); inst/fix_inst (R,n_inst).  n_samples % 4 == 0, n_samples <= 256. */
+int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw_stride_c, const float* z,
+                  const float* rays, const float* noise, const int32_t* label_sem,
+                  const int32_t* label_inst, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                  int sem_mode, int white_bkgd, float* rgb, float* depth, float* acc, float* weights,
+                  float* sem, float* inst, float* fix_sem, float* fix_inst, void* stream);
+
+/* ---- a7: sample_pdf + merge.  z (R,Nc), weights (R,Nc) coarse; u (R,Nf) or NULL (det).
+ * z_samples (R,Nf) and inds (R,Nf) int32 may be NULL; z_fine (R,Nc+Nf) sorted union or NULL.
+ * Indices / z_samples bit-exact with pnro_sample_pdf.  Nc <= 256, Nc+Nf <= 512. */
+int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse,
+                   int n_fine, float* z_samples, int32_t* inds, float* z_fine, void* stream);
+
+/* ---- a8: bbox prior.  box (M,15) = centre(3) rotation rows(9) half extents(3).
+ * hit_t (R,max_hits,2), hit_box (R,max_hits) int32 (-1 pad), hit_count (R) int32.
+ * Bit-exact with pnro_bbox_hits. */
+int pnr_bbox_hits(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits,
+                  float* hit_t, int32_t* hit_box, int32_t* hit_count, void* stream);
+
+/* box_ids (M,2) int32 = (semantic id, instance id).  label_* (R,N) int32. */
+int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float* hit_t,
+                      const int32_t* hit_box, const int32_t* hit_count, int max_hits,
+                      const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream);
+
+/* ---- measurement helper: run `iters` launches of pnr_mlp_forward / pnr_composite on `stream`
+ * bracketed by hipEvents recorded on that same stream; returns mean milliseconds per launch in
+ * *ms_out (host).  Synchronises the stream (bench use only; not graph-capture safe). */
+int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                         int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                         int64_t raw_stride_c, int iters, float* ms_out_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNR_H */

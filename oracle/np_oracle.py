@@ -1,0 +1,135 @@
+"""Plain-loop numpy float64 restatement of the per-ray stages, written from the equations
+of SURVEY.md section 8a (not from torch_oracle.py / pnr_oracle.c) so that the three
+restatements check one another (SURVEY.md 8c "how to keep a self-written oracle honest").
+
+TEST INFRASTRUCTURE ONLY; small cases only (pure Python loops).  PARITY UNPINNED: the
+reference mount holds no source, see oracle/pnr_oracle.c's header.
+"""
+import numpy as np
+
+
+def embed(x, L):
+    x = np.asarray(x, np.float64)
+    out = np.zeros((x.shape[0], 3 + 6 * L))
+    for s in range(x.shape[0]):
+        out[s, 0:3] = x[s]
+        for k in range(L):
+            for a in range(3):
+                out[s, 3 + 6 * k + a] = np.sin(x[s, a] * 2.0 ** k)
+                out[s, 3 + 6 * k + 3 + a] = np.cos(x[s, a] * 2.0 ** k)
+    return out
+
+
+def stratified(rays, N, lindisp=False, t_rand=None):
+    rays = np.asarray(rays, np.float64)
+    R = rays.shape[0]
+    z = np.zeros((R, N))
+    for r in range(R):
+        near, far = rays[r, 6], rays[r, 7]
+        for i in range(N):
+            t = i / (N - 1) if N > 1 else 0.0
+            z[r, i] = 1.0 / ((1 - t) / near + t / far) if lindisp else near * (1 - t) + far * t
+        if t_rand is not None:
+            zz = z[r].copy()
+            for i in range(N):
+                lo = zz[0] if i == 0 else 0.5 * (zz[i] + zz[i - 1])
+                up = zz[N - 1] if i == N - 1 else 0.5 * (zz[i] + zz[i + 1])
+                z[r, i] = lo + (up - lo) * float(t_rand[r, i])
+    return z
+
+
+def composite(raw, z, rays, C, K, noise=None, label_sem=None, label_inst=None, sem_mode=0,
+              white_bkgd=False):
+    """raw (R,N,4+C+K) sample-major."""
+    raw = np.asarray(raw, np.float64)
+    z = np.asarray(z, np.float64)
+    rays = np.asarray(rays, np.float64)
+    R, N = z.shape
+    out = dict(rgb=np.zeros((R, 3)), depth=np.zeros(R), acc=np.zeros(R), weights=np.zeros((R, N)),
+               semantic=np.zeros((R, C)), instance=np.zeros((R, K)),
+               fix_semantic=np.zeros((R, C)), fix_instance=np.zeros((R, K)))
+
+    def field(v):
+        if sem_mode == 0:
+            return v
+        e = np.exp(v - v.max())
+        return e / e.sum()
+
+    for r in range(R):
+        dn = np.sqrt((rays[r, 3:6] ** 2).sum())
+        T = 1.0
+        for i in range(N):
+            dist = (z[r, i + 1] - z[r, i]) if i + 1 < N else 1e10
+            sg = raw[r, i, 3] + (0.0 if noise is None else float(noise[r, i]))
+            alpha = 1.0 - np.exp(-max(sg, 0.0) * dist * dn)
+            w = alpha * T
+            T *= (1.0 - alpha + 1e-10)
+            out["weights"][r, i] = w
+            out["rgb"][r] += w / (1.0 + np.exp(-raw[r, i, 0:3]))
+            out["depth"][r] += w * z[r, i]
+            out["acc"][r] += w
+            if C:
+                out["semantic"][r] += w * field(raw[r, i, 4:4 + C])
+                if label_sem is not None and 0 <= label_sem[r, i] < C:
+                    out["fix_semantic"][r, label_sem[r, i]] += w
+            if K:
+                out["instance"][r] += w * field(raw[r, i, 4 + C:4 + C + K])
+                if label_inst is not None and 0 <= label_inst[r, i] < K:
+                    out["fix_instance"][r, label_inst[r, i]] += w
+        if white_bkgd:
+            out["rgb"][r] += 1.0 - out["acc"][r]
+    return out
+
+
+def sample_pdf(z, weights, Nf, u=None):
+    """Coarse z (R,Nc), coarse weights (R,Nc) -> z_samples (R,Nf), inds (R,Nf)."""
+    z = np.asarray(z, np.float64)
+    weights = np.asarray(weights, np.float64)
+    R, Nc = z.shape
+    zs = np.zeros((R, Nf))
+    inds = np.zeros((R, Nf), np.int64)
+    for r in range(R):
+        bins = [0.5 * (z[r, k + 1] + z[r, k]) for k in range(Nc - 1)]
+        w = [weights[r, j + 1] + 1e-5 for j in range(Nc - 2)]
+        tot = sum(w)
+        cdf = [0.0]
+        for j in range(Nc - 2):
+            cdf.append(cdf[-1] + w[j] / tot)
+        for i in range(Nf):
+            uu = float(u[r, i]) if u is not None else (i / (Nf - 1) if Nf > 1 else 0.0)
+            ind = sum(1 for c in cdf if c <= uu)
+            below, above = max(ind - 1, 0), min(ind, Nc - 2)
+            den = cdf[above] - cdf[below]
+            if den < 1e-5:
+                den = 1.0
+            t = (uu - cdf[below]) / den
+            zs[r, i] = bins[below] + t * (bins[above] - bins[below])
+            inds[r, i] = ind
+    return zs, inds
+
+
+def bbox_hits(rays, box, max_hits):
+    rays = np.asarray(rays, np.float64)
+    box = np.asarray(box, np.float64)
+    R, M = rays.shape[0], box.shape[0]
+    hit_t = np.zeros((R, max_hits, 2))
+    hit_box = -np.ones((R, max_hits), np.int64)
+    cnt = np.zeros(R, np.int64)
+    for r in range(R):
+        o, d, near, far = rays[r, 0:3], rays[r, 3:6], rays[r, 6], rays[r, 7]
+        for m in range(M):
+            if cnt[r] >= max_hits:
+                break
+            c, Rm, e = box[m, 0:3], box[m, 3:12].reshape(3, 3), box[m, 12:15]
+            ol, dl = Rm @ (o - c), Rm @ d
+            tmin, tmax = near, far
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for a in range(3):
+                    t1, t2 = (-e[a] - ol[a]) / dl[a], (e[a] - ol[a]) / dl[a]
+                    tmin = np.fmax(tmin, np.fmin(t1, t2))
+                    tmax = np.fmin(tmax, np.fmax(t1, t2))
+            if tmin <= tmax:
+                hit_t[r, cnt[r]] = (tmin, tmax)
+                hit_box[r, cnt[r]] = m
+                cnt[r] += 1
+    return hit_t, hit_box, cnt

@@ -1,0 +1,280 @@
+"""Vectorised PyTorch (CPU, fp32) restatement of the PanopticNeRF render_rays path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under panopticnerf_amd/ may import this module; it is
+used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, as the checker
+and as the timed "reference PyTorch CPU path" BASELINE.json asks to report.
+
+PARITY UNPINNED.  /root/reference holds only README.md (README.md:7, README.md:13 point at
+the un-mounted code branches `panopticnerf360` / `panopticnerf`), so nothing here can cite
+a reference file:line.  Every function follows SURVEY.md section 8a (rows a3..a8): the
+canonical NeRF formulation denoted by the names in BASELINE.json's north_star
+(render_rays, sample_pdf, raw2outputs, Embedder, coarse/fine NeRF MLP with semantic and
+instance heads).  Constants marked (!) are the parity-critical ones SURVEY.md section 9
+lists for re-verification once the code branch is mounted.
+
+Weights are passed as a plain dict name -> tensor with the canonical NeRF names:
+  pts_linears.{i}.weight/bias (i < D), alpha_linear, feature_linear, views_linears.0,
+  rgb_linear, semantic_linears.{0,1}, instance_linears.{0,1}
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+
+def mlp_config(D=8, W=256, skips=(4,), xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=128):
+    return SimpleNamespace(D=D, W=W, skips=tuple(skips), xyz_L=xyz_L, dir_L=dir_L,
+                           n_sem=n_sem, n_inst=n_inst, head_W=head_W)
+
+
+def init_params(cfg, seed=0, sigma_bias=None):
+    """nn.Linear default init (kaiming_uniform a=sqrt(5)) for every layer, seeded."""
+    g = torch.Generator().manual_seed(seed)
+    ex, ed = 3 + 6 * cfg.xyz_L, 3 + 6 * cfg.dir_L
+    p = {}
+
+    def lin(name, fin, fout):
+        bound = 1.0 / math.sqrt(fin)
+        p[name + ".weight"] = (torch.rand(fout, fin, generator=g) * 2 - 1) * bound
+        p[name + ".bias"] = (torch.rand(fout, generator=g) * 2 - 1) * bound
+
+    for i in range(cfg.D):
+        fin = ex if i == 0 else (cfg.W + ex if (i - 1) in cfg.skips else cfg.W)
+        lin(f"pts_linears.{i}", fin, cfg.W)
+    lin("alpha_linear", cfg.W, 1)
+    lin("feature_linear", cfg.W, cfg.W)
+    lin("views_linears.0", cfg.W + ed, cfg.W // 2)
+    lin("rgb_linear", cfg.W // 2, 3)
+    if cfg.n_sem:
+        lin("semantic_linears.0", cfg.W, cfg.head_W)
+        lin("semantic_linears.1", cfg.head_W, cfg.n_sem)
+    if cfg.n_inst:
+        lin("instance_linears.0", cfg.W, cfg.head_W)
+        lin("instance_linears.1", cfg.head_W, cfg.n_inst)
+    if sigma_bias is not None:
+        p["alpha_linear.bias"] = torch.full((1,), float(sigma_bias))
+    return p
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+# ------------------------------------------------------------------ a3 stratified sampler
+def stratified(rays, n_samples, lindisp=False, t_rand=None):
+    near, far = rays[..., 6:7], rays[..., 7:8]
+    t = torch.linspace(0.0, 1.0, steps=n_samples)
+    if not lindisp:
+        z = near * (1.0 - t) + far * t
+    else:
+        z = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
+    if t_rand is not None:
+        mids = 0.5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    return z
+
+
+def points(rays, z):
+    return rays[..., None, 0:3] + rays[..., None, 3:6] * z[..., :, None]
+
+
+# ------------------------------------------------------------------ a4 Embedder
+def embed(x, L):
+    out = [x]
+    for k in range(L):
+        f = 2.0 ** k
+        out.append(torch.sin(x * f))
+        out.append(torch.cos(x * f))
+    return torch.cat(out, -1)
+
+
+# ------------------------------------------------------------------ a5 NeRF MLP + heads
+def mlp_forward(p, cfg, pts, viewdirs, emulate_bf16=False):
+    """pts (S,3), viewdirs (S,3) already normalised (!) -> raw (S, 4+n_sem+n_inst) =
+    [rgb(3) sigma(1) semantic logits instance logits].
+    emulate_bf16 rounds every Linear's input activations and weights to bf16 (RNE) and
+    keeps fp32 accumulation + fp32 bias: the arithmetic of the MFMA bf16 kernel up to
+    accumulation order."""
+    q = bf16_round if emulate_bf16 else (lambda t: t)
+
+    def lin(name, x):
+        return F.linear(q(x), q(p[name + ".weight"]), p[name + ".bias"])
+
+    ex = embed(pts, cfg.xyz_L)
+    ed = embed(viewdirs, cfg.dir_L)
+    h = ex
+    for i in range(cfg.D):
+        h = F.relu(lin(f"pts_linears.{i}", h))
+        if i in cfg.skips:
+            h = torch.cat([ex, h], -1)           # (!) order: [gamma(x), h]
+    sigma = lin("alpha_linear", h)
+    feat = lin("feature_linear", h)
+    g = F.relu(lin("views_linears.0", torch.cat([feat, ed], -1)))   # (!) order: [feature, gamma(d)]
+    rgb = lin("rgb_linear", g)
+    outs = [rgb, sigma]
+    if cfg.n_sem:
+        outs.append(lin("semantic_linears.1", F.relu(lin("semantic_linears.0", h))))
+    if cfg.n_inst:
+        outs.append(lin("instance_linears.1", F.relu(lin("instance_linears.0", h))))
+    return torch.cat(outs, -1)
+
+
+def run_network(p, cfg, rays, z, emulate_bf16=False, chunk=1 << 16):
+    """rays (R,8), z (R,N) -> raw (R,N,ch)."""
+    R, N = z.shape
+    pts = points(rays, z).reshape(-1, 3)
+    d = rays[:, 3:6]
+    vd = (d / torch.norm(d, dim=-1, keepdim=True))[:, None, :].expand(R, N, 3).reshape(-1, 3)
+    outs = []
+    for s in range(0, pts.shape[0], chunk):
+        outs.append(mlp_forward(p, cfg, pts[s:s + chunk], vd[s:s + chunk], emulate_bf16))
+    return torch.cat(outs, 0).reshape(R, N, -1)
+
+
+# ------------------------------------------------------------------ a6 raw2outputs
+def raw2outputs(raw, z, rays_d, n_sem=0, n_inst=0, noise=None, label_sem=None, label_inst=None,
+                sem_mode=0, white_bkgd=False):
+    dists = z[..., 1:] - z[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)    # (!) 1e10
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)                # (!) * ||d||
+    rgb = torch.sigmoid(raw[..., :3])
+    sigma = raw[..., 3]
+    if noise is not None:
+        sigma = sigma + noise
+    alpha = 1.0 - torch.exp(-F.relu(sigma) * dists)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha + 1e-10], -1), -1)[..., :-1]
+    w = alpha * T
+    out = {"weights": w,
+           "rgb": torch.sum(w[..., None] * rgb, -2),
+           "depth": torch.sum(w * z, -1),
+           "acc": torch.sum(w, -1)}
+    if white_bkgd:
+        out["rgb"] = out["rgb"] + (1.0 - out["acc"][..., None])
+    if n_sem:
+        s = raw[..., 4:4 + n_sem]
+        if sem_mode == 1:
+            s = torch.softmax(s, -1)
+        out["semantic"] = torch.sum(w[..., None] * s, -2)
+        if label_sem is not None:
+            oh = F.one_hot(label_sem.clamp(min=0).long(), n_sem).float() * (label_sem >= 0)[..., None]
+            out["fix_semantic"] = torch.sum(w[..., None] * oh, -2)
+    if n_inst:
+        s = raw[..., 4 + n_sem:4 + n_sem + n_inst]
+        if sem_mode == 1:
+            s = torch.softmax(s, -1)
+        out["instance"] = torch.sum(w[..., None] * s, -2)
+        if label_inst is not None:
+            oh = F.one_hot(label_inst.clamp(min=0).long(), n_inst).float() * (label_inst >= 0)[..., None]
+            out["fix_instance"] = torch.sum(w[..., None] * oh, -2)
+    return out
+
+
+# ------------------------------------------------------------------ a7 sample_pdf
+def sample_pdf(bins, weights, n_importance, det=True, u=None):
+    weights = weights + 1e-5                                                 # (!) 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if u is None:
+        assert det
+        u = torch.linspace(0.0, 1.0, steps=n_importance).expand(list(cdf.shape[:-1]) + [n_importance])
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_b, cdf_a = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    bins_b, bins_a = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)         # (!) 1e-5
+    t = (u - cdf_b) / denom
+    return bins_b + t * (bins_a - bins_b), inds
+
+
+def importance_z(z, weights, n_importance, u=None):
+    """coarse z (R,Nc), coarse weights (R,Nc) -> sorted union z_fine (R,Nc+Nf), z_samples, inds."""
+    mid = 0.5 * (z[..., 1:] + z[..., :-1])
+    zs, inds = sample_pdf(mid, weights[..., 1:-1], n_importance, det=(u is None), u=u)
+    zs = zs.detach()
+    z_fine, _ = torch.sort(torch.cat([z, zs], -1), -1)
+    return z_fine, zs, inds
+
+
+# ------------------------------------------------------------------ a8 bbox prior
+def bbox_hits(rays, box, max_hits):
+    """rays (R,8), box (M,15) = c(3) Rrows(9) e(3).  Dense slab test -> first max_hits hits
+    per ray in ascending box index.  Returns hit_t (R,mh,2), hit_box (R,mh) int32, count."""
+    o, d, near, far = rays[:, None, 0:3], rays[:, None, 3:6], rays[:, None, 6], rays[:, None, 7]
+    c, Rm, e = box[None, :, 0:3], box[None, :, 3:12].reshape(1, -1, 3, 3), box[None, :, 12:15]
+    p = o - c
+    ol = (Rm[..., 0] * p[..., None, 0] + Rm[..., 1] * p[..., None, 1]) + Rm[..., 2] * p[..., None, 2]
+    dl = (Rm[..., 0] * d[..., None, 0] + Rm[..., 1] * d[..., None, 1]) + Rm[..., 2] * d[..., None, 2]
+    inv = 1.0 / dl
+    t1, t2 = (-e - ol) * inv, (e - ol) * inv
+    tn, tf = torch.fmin(t1, t2), torch.fmax(t1, t2)
+    tmin, tmax = near.expand(-1, box.shape[0]).clone(), far.expand(-1, box.shape[0]).clone()
+    for a in range(3):
+        tmin = torch.fmax(tmin, tn[..., a])
+        tmax = torch.fmin(tmax, tf[..., a])
+    hit = tmin <= tmax
+    R, M = hit.shape
+    rank = torch.cumsum(hit.int(), 1) - 1
+    keep = hit & (rank < max_hits)
+    hit_t = torch.zeros(R, max_hits, 2)
+    hit_box = torch.full((R, max_hits), -1, dtype=torch.int32)
+    rr, mm = torch.nonzero(keep, as_tuple=True)
+    k = rank[rr, mm].long()
+    hit_t[rr, k, 0], hit_t[rr, k, 1] = tmin[rr, mm], tmax[rr, mm]
+    hit_box[rr, k] = mm.int()
+    return hit_t, hit_box, keep.sum(1).int()
+
+
+def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
+    R, N = z.shape
+    mh = hit_box.shape[1]
+    valid = (torch.arange(mh)[None, :] < hit_count[:, None])[:, None, :]
+    ti, to = hit_t[:, None, :, 0], hit_t[:, None, :, 1]
+    inside = valid & (ti <= z[..., None]) & (z[..., None] <= to)
+    key = torch.where(inside, ti.expand(R, N, mh), torch.full((R, N, mh), float("inf")))
+    best = torch.argmin(key, -1)          # first minimum on ties
+    any_in = inside.any(-1)
+    bidx = torch.gather(hit_box.long(), 1, best).clamp(min=0)
+    ids = box_ids.long()
+    ls = torch.where(any_in, ids[bidx, 0], torch.full_like(bidx, -1))
+    li = torch.where(any_in, ids[bidx, 1], torch.full_like(bidx, -1))
+    return ls.int(), li.int()
+
+
+# ------------------------------------------------------------------ a2 render_rays
+def render_rays(params, cfg, rays, n_samples, n_importance=0, lindisp=False, t_rand=None, u=None,
+                noise0=None, noise1=None, box=None, box_ids=None, max_hits=8, sem_mode=0,
+                white_bkgd=False, emulate_bf16=False, keep_raw=False):
+    """params: {"coarse": dict, "fine": dict} (fine used when n_importance>0).
+    Returns dict with *_0 (coarse) and *_1 (fine) maps."""
+    ret = {}
+    hits = None
+    if box is not None:
+        hits = bbox_hits(rays, box, max_hits)
+    z = stratified(rays, n_samples, lindisp, t_rand)
+
+    def level(tag, prm, zz, noise):
+        raw = run_network(prm, cfg, rays, zz, emulate_bf16)
+        ls = li = None
+        if hits is not None:
+            ls, li = sample_labels(zz, hits[0], hits[1], hits[2], box_ids)
+        o = raw2outputs(raw, zz, rays[:, 3:6], cfg.n_sem, cfg.n_inst, noise, ls, li, sem_mode, white_bkgd)
+        for k, v in o.items():
+            ret[f"{k}_{tag}"] = v
+        ret[f"z_vals_{tag}"] = zz
+        if keep_raw:
+            ret[f"raw_{tag}"] = raw
+        return o["weights"]
+
+    w0 = level(0, params["coarse"], z, noise0)
+    if n_importance > 0:
+        z_fine, zs, inds = importance_z(z, w0, n_importance, u)
+        ret["z_samples"], ret["inds"] = zs, inds
+        level(1, params["fine"], z_fine, noise1)
+    return ret

@@ -1,0 +1,83 @@
+"""ctypes binding of libpnr.so (include/pnr.h).  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError is raised -- the product path never routes through
+the oracle or any CPU implementation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnr.so")
+
+c_f = ctypes.c_void_p       # device pointers travel as integers
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+
+PREC_BF16, PREC_FP32 = 0, 1
+
+
+class MlpDesc(ctypes.Structure):
+    """pnr_mlp_desc (include/pnr.h)."""
+    _fields_ = [("D", ctypes.c_int32), ("W", ctypes.c_int32), ("skip", ctypes.c_int32),
+                ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
+                ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
+                ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_fpp = ctypes.POINTER(_fp)
+
+
+class MlpParamsHost(ctypes.Structure):
+    """pnr_mlp_params_host (include/pnr.h)."""
+    _fields_ = [("pts_w", _fpp), ("pts_b", _fpp),
+                ("alpha_w", _fp), ("alpha_b", _fp), ("feature_w", _fp), ("feature_b", _fp),
+                ("views_w", _fp), ("views_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp),
+                ("sem0_w", _fp), ("sem0_b", _fp), ("sem1_w", _fp), ("sem1_b", _fp),
+                ("inst0_w", _fp), ("inst0_b", _fp), ("inst1_w", _fp), ("inst1_b", _fp)]
+
+
+# name -> (restype, argtypes); every symbol include/pnr.h declares
+SIGNATURES = {
+    "pnr_version": (c_int, []),
+    "pnr_last_error": (ctypes.c_char_p, []),
+    "pnr_device_check": (c_int, [c_int, ctypes.c_char_p, c_int]),
+    "pnr_stratified": (c_int, [c_f, c_i64, c_int, c_int, c_f, c_f, c_f]),
+    "pnr_points": (c_int, [c_f, c_f, c_i64, c_int, c_f, c_f]),
+    "pnr_embed": (c_int, [c_f, c_i64, c_int, c_f, c_f]),
+    "pnr_mlp_packed_bytes": (c_i64, [ctypes.POINTER(MlpDesc)]),
+    "pnr_mlp_pack": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), ctypes.c_void_p]),
+    "pnr_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_f]),
+    "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
+                              c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_time_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64,
+                                     c_int, ctypes.POINTER(ctypes.c_float), c_f]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpnr.so (built by __graft_entry__.build() / panopticnerf_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C panopticnerf_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pnr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

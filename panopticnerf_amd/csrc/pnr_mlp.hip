@@ -1,0 +1,407 @@
+// K3 (+K2 fused): the NeRF MLP with semantic / instance heads as ONE fused gfx950 kernel.
+// Reference: Network / NeRF forward + Embedder (branch not in the
+// mount, see include/pnr.h).  Design: pnr_mlp_layout.h.
+//
+//  * Every layer is evaluated transposed (H^T = W * H_in^T) so the 32x32 MFMA accumulator of
+//    one layer is, after bias/ReLU/convert, directly the B operand of the next: activations
+//    stay in VGPRs/AGPRs from gamma(x) to the raw outputs, never touching LDS or HBM.
+//  * Weights are the A operand.  They are pre-permuted on the host into 1 KiB fragments in
+//    consumption order and streamed L2 -> LDS with global_load_lds (16 B/lane, lane-linear,
+//    conflict-free ds_read_b128), one (layer, 32-row block) chunk ahead of the MFMAs, double
+//    buffered; the 4 (or 8) waves of a workgroup share every fragment.
+//  * gamma(x), gamma(d) are computed in registers by the lanes that need them (the two
+//    half-waves split the frequency bands), so the 63/27-wide encodings never exist in memory.
+//  * bf16 path: v_mfma_f32_32x32x16_bf16, fp32 accumulate, RNE conversion of activations.
+//    fp32 path (parity mode): v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain.
+//
+// HBM traffic per sample: 4 B of z (+32 B/ray) in, 4*(4+C+K) B of raw out; the kernel is
+// MFMA-bound (1.19 MFLOP/sample trunk + heads).
+#include "pnr_common.h"
+#include "pnr_mlp_layout.h"
+#include "pnr_mlp_plan.h"
+
+int pnr_mlp_validate(const pnr_mlp_desc* d);
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct MlpArgs {
+    const uint8_t* data;            // fragment stream (device)
+    const pnr_chunk_entry* table;   // chunk table (device)
+    int n_chunks, slot_bytes;
+    const float* rays; const float* z;
+    int S, N, n_groups;
+    float* raw; int64_t ss, sc;
+    int D, skip, n_sem, n_inst;
+};
+
+enum { MODE_RELU = 0, MODE_LINEAR = 1 };
+
+template <int PREC> struct PrecT;
+template <> struct PrecT<PNR_PREC_BF16> { static constexpr int RPB = 8; };    // B regs per 32 input features
+template <> struct PrecT<PNR_PREC_FP32> { static constexpr int RPB = 16; };
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// One k-step: 16 bytes of A per lane against 4 B registers.
+template <int PREC>
+__device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x16 acc)
+{
+    if constexpr (PREC == PNR_PREC_BF16) {
+        u32x4 bv;
+        bv[0] = b[0]; bv[1] = b[1]; bv[2] = b[2]; bv[3] = b[3];
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv),
+                                                        acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]),
+                                                       __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+        return acc;
+    }
+}
+
+template <int WAVES>
+struct Ctx {
+    const MlpArgs& a;
+    char* smem;
+    int lane, wave, hi;
+    int ci, slot;
+
+    // Issue the L2 -> LDS copy of chunk `idx` into slot `sl` (asynchronous; LDS-DMA).
+    __device__ __forceinline__ void issue(int idx, int sl) const
+    {
+        const pnr_chunk_entry e = a.table[idx];
+        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
+        char* dst = smem + sl * a.slot_bytes;
+        for (int f = wave; f < (int)e.nfrag; f += WAVES)
+            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
+                                             (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
+    }
+    __device__ __forceinline__ int next_index() const { return ci + 1 == a.n_chunks ? 0 : ci + 1; }
+    __device__ __forceinline__ void prefetch() const { issue(next_index(), slot ^ 1); }
+    __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
+    // All of this wave's LDS-DMA has landed, every wave is done reading the current slot.
+    __device__ __forceinline__ void finish()
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ci = next_index();
+        slot ^= 1;
+    }
+};
+
+__device__ __forceinline__ void load_bias(const char* bias_frag, int hi, f32x16& acc)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_frag + (8 * m + 4 * hi) * 4);
+        acc[4 * m + 0] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+    }
+}
+
+// Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
+template <int PREC, int TILES, int WAVES, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
+__device__ __forceinline__ void layer_regs(Ctx<WAVES>& c, const uint32_t (&inA)[TILES][NA],
+                                           const uint32_t (&inB)[TILES][NB > 0 ? NB : 1],
+                                           uint32_t (&out)[TILES][NOUT])
+{
+    constexpr int RPB = PrecT<PREC>::RPB;
+    constexpr int KSA = NA / 4, KSB = NB / 4;
+    static_assert(NOUT >= NFB_OUT * RPB, "output register array too small");
+#pragma unroll
+    for (int fb = 0; fb < NFB_OUT; ++fb) {
+        c.prefetch();
+        const char* base = c.base();
+        const char* frag = base + c.lane * 16;
+        f32x16 acc[TILES];
+        load_bias(base + (KSA + KSB) * PNR_FRAG_BYTES, c.hi, acc[0]);
+#pragma unroll
+        for (int t = 1; t < TILES; ++t) acc[t] = acc[0];
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(frag + ks * PNR_FRAG_BYTES);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inA[t][4 * ks], acc[t]);
+        }
+        if constexpr (NB > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(frag + (KSA + ks) * PNR_FRAG_BYTES);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inB[t][4 * ks], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            if constexpr (PREC == PNR_PREC_BF16) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    float lo = acc[t][2 * p], hi = acc[t][2 * p + 1];
+                    if (MODE == MODE_RELU) { lo = fmaxf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }
+                    out[t][fb * RPB + p] = pack_bf16(lo, hi);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r];
+                    if (MODE == MODE_RELU) v = fmaxf(v, 0.0f);
+                    out[t][fb * RPB + r] = __builtin_bit_cast(uint32_t, v);
+                }
+            }
+        }
+        c.finish();
+    }
+}
+
+// Output layer: rows [0, n_out) are stored to raw channels ch_base + row.
+template <int PREC, int TILES, int WAVES, int NA, int NB>
+__device__ __forceinline__ void layer_out(Ctx<WAVES>& c, const uint32_t (&inA)[TILES][NA],
+                                          const uint32_t (&inB)[TILES][NB > 0 ? NB : 1], int n_out, int ch_base,
+                                          const int (&samp)[TILES])
+{
+    constexpr int KSA = NA / 4, KSB = NB / 4;
+    const int nfb = (n_out + 31) >> 5;
+#pragma unroll 1
+    for (int fb = 0; fb < nfb; ++fb) {
+        c.prefetch();
+        const char* base = c.base();
+        const char* frag = base + c.lane * 16;
+        f32x16 acc[TILES];
+        load_bias(base + (KSA + KSB) * PNR_FRAG_BYTES, c.hi, acc[0]);
+#pragma unroll
+        for (int t = 1; t < TILES; ++t) acc[t] = acc[0];
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(frag + ks * PNR_FRAG_BYTES);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inA[t][4 * ks], acc[t]);
+        }
+        if constexpr (NB > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(frag + (KSA + ks) * PNR_FRAG_BYTES);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inB[t][4 * ks], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            if (samp[t] >= 0) {
+                float* dst = c.a.raw + (int64_t)samp[t] * c.a.ss;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = fb * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.hi;
+                    if (row < n_out) dst[(int64_t)(ch_base + row) * c.a.sc] = acc[t][r];
+                }
+            }
+        }
+        c.finish();
+    }
+}
+
+// gamma() of one 3-vector into this lane's share of the lane vector (pnr_mlp_layout.h).
+// NF = frequency bands per half-wave (5 for xyz, 2 for view directions); NV = values per lane.
+template <int PREC, int NF, int NV, int NREG>
+__device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi, uint32_t (&out)[NREG])
+{
+    float v[NV];
+    v[0] = hi ? p2 : p0;
+    v[1] = hi ? 0.0f : p1;
+#pragma unroll
+    for (int fp = 0; fp < NF; ++fp) {
+        const float sc = hi ? (float)(1 << (NF + fp)) : (float)(1 << fp);
+        float s, co;
+        sincosf(p0 * sc, &s, &co); v[2 + 6 * fp + 0] = s; v[2 + 6 * fp + 3] = co;
+        sincosf(p1 * sc, &s, &co); v[2 + 6 * fp + 1] = s; v[2 + 6 * fp + 4] = co;
+        sincosf(p2 * sc, &s, &co); v[2 + 6 * fp + 2] = s; v[2 + 6 * fp + 5] = co;
+    }
+#pragma unroll
+    for (int i = 2 + 6 * NF; i < NV; ++i) v[i] = 0.0f;
+    if constexpr (PREC == PNR_PREC_BF16) {
+#pragma unroll
+        for (int p = 0; p < NV / 2; ++p) out[p] = pack_bf16(v[2 * p], v[2 * p + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) out[i] = __builtin_bit_cast(uint32_t, v[i]);
+    }
+}
+
+template <int PREC, int W, int TILES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_mlp_fused(const MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPB = PrecT<PREC>::RPB;
+    constexpr int NFB = W / 32, HFB = W / 64;
+    constexpr int HR = NFB * RPB, GR = HFB * RPB;
+    constexpr int GXR = PREC == PNR_PREC_BF16 ? 16 : 32;
+    constexpr int GDR = PREC == PNR_PREC_BF16 ? 8 : 16;
+
+    Ctx<WAVES> c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
+                 (int)((threadIdx.x & 63) >> 5), 0, 0};
+    const int n = c.lane & 31;
+
+    c.issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    uint32_t dummy[TILES][1];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) dummy[t][0] = 0;
+
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        int samp[TILES];
+        float vd[TILES][3];
+        uint32_t ex[TILES][GXR];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int s = ((grp * WAVES + c.wave) * TILES + t) * 32 + n;
+            samp[t] = s < a.S ? s : -1;
+            const int sl = s < a.S ? s : a.S - 1;
+            const int ray = sl / a.N;
+            const float4 o4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8);
+            const float4 d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
+            const float zz = a.z[sl];
+            const float dx = o4.w, dy = d4.x, dz = d4.y;
+            // pts = o + d*z: separate multiply and add, as the sampler's pnr_points does
+            const float px = __fadd_rn(o4.x, __fmul_rn(dx, zz));
+            const float py = __fadd_rn(o4.y, __fmul_rn(dy, zz));
+            const float pz = __fadd_rn(o4.z, __fmul_rn(dz, zz));
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            vd[t][0] = dx / nrm; vd[t][1] = dy / nrm; vd[t][2] = dz / nrm;
+            embed_lane<PREC, 5, 32, GXR>(px, py, pz, c.hi, ex[t]);
+        }
+
+        uint32_t cur[TILES][HR], nxt[TILES][HR];
+        layer_regs<PREC, TILES, WAVES, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur);
+#pragma unroll 1
+        for (int l = 1; l < a.D; ++l) {
+            if (l - 1 == a.skip)
+                layer_regs<PREC, TILES, WAVES, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt);
+            else
+                layer_regs<PREC, TILES, WAVES, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int i = 0; i < HR; ++i) cur[t][i] = nxt[t][i];
+        }
+        if (a.n_sem) {
+            uint32_t sh[TILES][GR];
+            layer_regs<PREC, TILES, WAVES, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_out<PREC, TILES, WAVES, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
+        }
+        if (a.n_inst) {
+            uint32_t sh[TILES][GR];
+            layer_regs<PREC, TILES, WAVES, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_out<PREC, TILES, WAVES, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+        }
+        layer_regs<PREC, TILES, WAVES, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt);
+        uint32_t ed[TILES][GDR];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) embed_lane<PREC, 2, 16, GDR>(vd[t][0], vd[t][1], vd[t][2], c.hi, ed[t]);
+        uint32_t g[TILES][GR];
+        layer_regs<PREC, TILES, WAVES, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g);
+        layer_out<PREC, TILES, WAVES, GR, HR>(c, g, cur, 4, 0, samp);
+    }
+}
+
+// ------------------------------------------------------------------------------- launcher
+template <int PREC, int W, int TILES, int WAVES>
+static int launch_mlp(const MlpArgs& a0, int lds_bytes, hipStream_t stream)
+{
+    MlpArgs a = a0;
+    const int per_group = 32 * TILES * WAVES;
+    a.n_groups = (a.S + per_group - 1) / per_group;
+    auto kern = k_mlp_fused<PREC, W, TILES, WAVES>;
+    static thread_local int configured = 0;
+    if (configured < lds_bytes) {
+        PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        configured = lds_bytes;
+    }
+    // persistent-style grid: at most 2 workgroups per CU, grid-stride over sample groups
+    const int grid = a.n_groups < 512 ? a.n_groups : 512;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
+    PNR_CHECK_LAUNCH("pnr_mlp_forward");
+    return PNR_OK;
+}
+
+// Tunable at run time for A/B measurements (bench / tests): PNR_MLP_TILES in {1,2}.
+static int mlp_tiles_default()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PNR_MLP_TILES");
+        v = (e && e[0] == '2') ? 2 : 1;
+    }
+    return v;
+}
+
+PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                               int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                               int64_t raw_stride_c, void* stream)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(packed && rays && z && raw, "pnr_mlp_forward: null pointer");
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_mlp_forward: bad size");
+    PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_forward: R*N=%lld exceeds 2^31",
+                (long long)(n_rays * n_samples));
+    PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)packed) & 15) == 0,
+                "pnr_mlp_forward: rays / packed must be 16-byte aligned");
+    if (n_rays == 0) return PNR_OK;
+    PnrPlan plan;
+    pnr_build_plan(*desc, plan);
+    MlpArgs a;
+    a.data = (const uint8_t*)packed + plan.data_off;
+    a.table = (const pnr_chunk_entry*)((const uint8_t*)packed + plan.table_off);
+    a.n_chunks = (int)plan.chunks.size();
+    a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
+    a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples; a.n_groups = 0;
+    a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
+    a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    const int lds = 2 * a.slot_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->precision == PNR_PREC_BF16) {
+        const int tiles = mlp_tiles_default();
+        if (desc->W == 256) return tiles == 2 ? launch_mlp<PNR_PREC_BF16, 256, 2, 4>(a, lds, st)
+                                              : launch_mlp<PNR_PREC_BF16, 256, 1, 4>(a, lds, st);
+        return tiles == 2 ? launch_mlp<PNR_PREC_BF16, 128, 2, 4>(a, lds, st)
+                          : launch_mlp<PNR_PREC_BF16, 128, 1, 4>(a, lds, st);
+    }
+    if (desc->W == 256) return launch_mlp<PNR_PREC_FP32, 256, 1, 4>(a, lds, st);
+    return launch_mlp<PNR_PREC_FP32, 128, 1, 4>(a, lds, st);
+}
+
+PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                    int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                                    int64_t raw_stride_c, int iters, float* ms_out_host, void* stream)
+{
+    PNR_REQUIRE(iters >= 1 && ms_out_host, "pnr_time_mlp_forward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    PNR_HIP(hipEventCreate(&e0));
+    PNR_HIP(hipEventCreate(&e1));
+    PNR_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) {
+        int rc = pnr_mlp_forward(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, stream);
+        if (rc != PNR_OK) return rc;
+    }
+    PNR_HIP(hipEventRecord(e1, st));
+    PNR_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out_host = ms / (float)iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return PNR_OK;
+}

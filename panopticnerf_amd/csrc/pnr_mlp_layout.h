@@ -1,0 +1,63 @@
+// Layout of the packed NeRF-MLP parameter image shared by the host packer (pnr_mlp_pack.cpp)
+// and the fused kernel (pnr_mlp.hip).  SURVEY.md 8a row a5 gives the network; this header
+// fixes how it is laid out for v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32.
+//
+// The kernel evaluates every layer TRANSPOSED:  H_out^T (features x samples) = W * H_in^T,
+// with W as the MFMA A operand and the activations as the B operand.  One wave owns 32
+// samples per tile (B/C/D column n = lane & 31); the two half-waves hi = lane >> 5 split
+// the k (input-feature) dimension.  The 32x32 accumulator holds, for lane (n, hi),
+// rows row(r,hi) = (r&3) + 8*(r>>2) + 4*hi, r = 0..15 (cdna_hip_programming.md section 3) --
+// exactly the shape a B operand needs, so a layer's output registers ARE the next layer's
+// B operand and activations never leave the register file.  The price is that input feature
+// order inside the k dimension is the accumulator's row order; the packer pays it once by
+// permuting W's columns ("slot maps" below).
+//
+// Lane vector.  For a layer input of 2*VL k-slots each lane (n,hi) holds VL values V[v].
+//   hidden features : V[v] = feature (v>>4)*32 + row(v&15, hi)           (VL = width/2)
+//   gamma(x), 64 slots (VL=32): v=0: hi?z:x  v=1: hi?pad:y  v=2+6f'+j: freq f=5*hi+f',
+//                               j = sin x,y,z, cos x,y,z  -> canonical column 3+6f+j
+//   gamma(d), 32 slots (VL=16): v=0: hi?dz:dx v=1: hi?pad:dy v=2+6f'+j: f=2*hi+f' (f'<2); v=14,15 pad
+// A "k-step" consumes KPL consecutive V values per lane = 4 B registers = one 16-byte A read:
+//   bf16: KPL=8 (one 32x32x16 MFMA);  fp32: KPL=4 (four 32x32x2 MFMAs, one value each).
+//
+// Fragment = 1 KiB: lane l = (i = l&31, hi = l>>5) owns bytes [16 l, 16 l + 16): the KPL
+// values W[fb*32 + i][col(hi, ks*KPL + j)], j < KPL, 0 where col is a pad or the row is
+// beyond the layer's outputs.  A chunk = one (layer, 32-row output block): its k-step
+// fragments in order, then ONE bias fragment (32 fp32 biases of the block's rows, rest 0).
+// The image is the chunks in execution order, preceded by a header and a chunk table.
+#pragma once
+#include <stdint.h>
+
+#define PNR_PACK_MAGIC 0x504e5231u /* "PNR1" */
+#define PNR_FRAG_BYTES 1024
+
+struct pnr_pack_header {
+    uint32_t magic, version;
+    uint32_t n_chunks, max_chunk_frags;
+    uint32_t table_off, data_off;   // bytes from image start
+    uint64_t total_bytes;
+    int32_t desc[16];               // copy of pnr_mlp_desc
+    uint32_t pad[8];
+};                                   // 128 bytes
+struct pnr_chunk_entry { uint32_t off_frag, nfrag; };   // offset from data_off in fragments
+
+static inline int pnr_row_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+static inline int pnr_kpl(int precision) { return precision == 0 ? 8 : 4; }
+
+enum { PNR_SEG_GX = 0, PNR_SEG_GD = 1, PNR_SEG_FEAT = 2 };
+
+// canonical column (within the segment's own canonical vector) of lane-vector slot (hi, v); -1 = pad
+static inline int pnr_seg_col(int kind, int L, int hi, int v)
+{
+    if (kind == PNR_SEG_FEAT) return (v >> 4) * 32 + pnr_row_of(v & 15, hi);
+    const int nfh = (kind == PNR_SEG_GX) ? 5 : 2;   // frequencies per half-wave
+    if (v == 0) return hi ? 2 : 0;
+    if (v == 1) return hi ? -1 : 1;
+    const int fp = (v - 2) / 6, j = (v - 2) % 6;
+    if (fp >= nfh) return -1;
+    const int f = hi * nfh + fp;
+    if (f >= L) return -1;
+    return 3 + 6 * f + j;
+}
+// values per lane of a segment
+static inline int pnr_seg_vl(int kind, int nfeat) { return kind == PNR_SEG_GX ? 32 : kind == PNR_SEG_GD ? 16 : nfeat / 2; }

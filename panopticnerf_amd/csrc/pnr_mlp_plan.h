@@ -1,0 +1,75 @@
+// Execution plan of the fused MLP: the ordered list of layers and (layer, 32-row block)
+// chunks.  Host-only; used by the packer and by the launcher (chunk count, LDS slot size).
+// Order = the order the kernel consumes the weight stream:
+//   trunk 0..D-1 | [sem0, sem1] | [inst0, inst1] | feature | views | rgb+sigma
+#pragma once
+#include <stddef.h>
+
+#include <vector>
+
+#include "pnr.h"
+#include "pnr_mlp_layout.h"
+
+enum { PNR_L_TRUNK = 0, PNR_L_SEM0, PNR_L_SEM1, PNR_L_INST0, PNR_L_INST1, PNR_L_FEATURE, PNR_L_VIEWS, PNR_L_RGBSIGMA };
+
+struct PnrLayer {
+    int kind, index;       // index: trunk layer number
+    int out_dim, n_fb;     // output rows, 32-row blocks
+    int nseg;
+    int seg_kind[2], seg_nfeat[2];
+    int nks;               // k-steps (weight fragments) per chunk
+};
+struct PnrChunk { int layer, fb, off_frag, nfrag; };
+struct PnrPlan {
+    std::vector<PnrLayer> layers;
+    std::vector<PnrChunk> chunks;
+    int max_chunk_frags;
+    size_t table_off, data_off, total_bytes;
+};
+
+static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
+{
+    const int kpl = pnr_kpl(d.precision);
+    auto add = [&](int kind, int index, int out_dim, int k0, int n0, int k1 = -1, int n1 = 0) {
+        PnrLayer L;
+        L.kind = kind; L.index = index; L.out_dim = out_dim; L.n_fb = (out_dim + 31) / 32;
+        L.nseg = k1 >= 0 ? 2 : 1;
+        L.seg_kind[0] = k0; L.seg_nfeat[0] = n0; L.seg_kind[1] = k1; L.seg_nfeat[1] = n1;
+        L.nks = pnr_seg_vl(k0, n0) / kpl + (k1 >= 0 ? pnr_seg_vl(k1, n1) / kpl : 0);
+        plan.layers.push_back(L);
+    };
+    plan.layers.clear();
+    plan.chunks.clear();
+    for (int i = 0; i < d.D; ++i) {
+        if (i == 0) add(PNR_L_TRUNK, i, d.W, PNR_SEG_GX, 0);
+        else if (i - 1 == d.skip) add(PNR_L_TRUNK, i, d.W, PNR_SEG_GX, 0, PNR_SEG_FEAT, d.W);
+        else add(PNR_L_TRUNK, i, d.W, PNR_SEG_FEAT, d.W);
+    }
+    if (d.n_sem) {
+        add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.head_W);
+    }
+    if (d.n_inst) {
+        add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.head_W);
+    }
+    add(PNR_L_FEATURE, 0, d.W, PNR_SEG_FEAT, d.W);
+    add(PNR_L_VIEWS, 0, d.W / 2, PNR_SEG_FEAT, d.W, PNR_SEG_GD, 0);
+    add(PNR_L_RGBSIGMA, 0, 4, PNR_SEG_FEAT, d.W / 2, PNR_SEG_FEAT, d.W);
+    int off = 0, mx = 0;
+    for (size_t li = 0; li < plan.layers.size(); ++li) {
+        const PnrLayer& L = plan.layers[li];
+        for (int fb = 0; fb < L.n_fb; ++fb) {
+            PnrChunk c;
+            c.layer = (int)li; c.fb = fb; c.off_frag = off; c.nfrag = L.nks + 1;   // + bias fragment
+            off += c.nfrag;
+            if (c.nfrag > mx) mx = c.nfrag;
+            plan.chunks.push_back(c);
+        }
+    }
+    plan.max_chunk_frags = mx;
+    plan.table_off = sizeof(pnr_pack_header);
+    size_t t = plan.table_off + plan.chunks.size() * sizeof(pnr_chunk_entry);
+    plan.data_off = (t + 1023) & ~(size_t)1023;
+    plan.total_bytes = plan.data_off + (size_t)off * PNR_FRAG_BYTES;
+}

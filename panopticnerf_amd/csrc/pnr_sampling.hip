@@ -1,0 +1,337 @@
+// K1 / K1b / K2 / K5: per-ray sample generation, Embedder, sample_pdf + merge, bbox prior.
+// gfx950 only.  The sampler, sample_pdf and bbox kernels are BIT-EXACT restatements of
+// oracle/pnr_oracle.c (pnro_stratified / pnro_points / pnro_sample_pdf / pnro_bbox_hits /
+// pnro_sample_labels): same fp32 operations in the same order, one rounding each; the file
+// is compiled with -ffp-contract=off and the pragma below so no mul+add pair is fused.
+// Reference functions these replace (the reference source
+// is not in the mount, include/pnr.h explains the citation form).
+#include "pnr_common.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------- a3
+__device__ __forceinline__ float strat_z(float nr, float fr, int i, int N, int lindisp)
+{
+    const float t = (N > 1) ? ((float)i / (float)(N - 1)) : 0.0f;
+    const float omt = 1.0f - t;
+    if (!lindisp) {
+        const float a = nr * omt, b = fr * t;
+        return a + b;
+    }
+    const float a = (1.0f / nr) * omt, b = (1.0f / fr) * t;
+    return 1.0f / (a + b);
+}
+
+// One thread per sample; HBM-bound: reads 8 B/ray amortised (+4 B t_rand), writes 4 B.
+__global__ __launch_bounds__(256) void k_stratified(const float* __restrict__ rays, int64_t R, int N,
+                                                     int lindisp, const float* __restrict__ t_rand,
+                                                     float* __restrict__ z_out)
+{
+    const int64_t total = R * N;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = s / N;
+        const int i = (int)(s - r * N);
+        const float nr = rays[r * 8 + 6], fr = rays[r * 8 + 7];
+        const float zi = strat_z(nr, fr, i, N, lindisp);
+        float z = zi;
+        if (t_rand) {
+            const float z0 = strat_z(nr, fr, 0, N, lindisp), zl = strat_z(nr, fr, N - 1, N, lindisp);
+            const float lo = (i == 0) ? z0 : 0.5f * (zi + strat_z(nr, fr, i - 1, N, lindisp));
+            const float up = (i == N - 1) ? zl : 0.5f * (strat_z(nr, fr, i + 1, N, lindisp) + zi);
+            const float w = up - lo;
+            const float m = w * t_rand[s];
+            z = lo + m;
+        }
+        z_out[s] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_points(const float* __restrict__ rays, const float* __restrict__ z,
+                                                 int64_t R, int N, float* __restrict__ pts)
+{
+    const int64_t total = R * N * 3;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = e / 3;
+        const int a = (int)(e - s * 3);
+        const int64_t r = s / N;
+        const float m = rays[r * 8 + 3 + a] * z[s];
+        pts[e] = rays[r * 8 + a] + m;
+    }
+}
+
+// ------------------------------------------------------------------------------- a4
+// One thread per OUTPUT element so that the (n, 3+6L) sample-major image is written fully
+// coalesced.  Trig-bound (cdna_hip_programming.md App. B): accurate sinf/cosf (ocml) because
+// arguments reach 2^(L-1)*|x|.  The fused MLP kernel computes gamma() in registers instead.
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, int64_t n, int L,
+                                                float* __restrict__ out)
+{
+    const int E = 3 + 6 * L;
+    const int64_t total = n * E;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = e / E;
+        const int c = (int)(e - s * E);
+        float v;
+        if (c < 3) {
+            v = x[s * 3 + c];
+        } else {
+            const int k = (c - 3) / 6, j = (c - 3) - 6 * k;
+            const int a = j % 3;
+            const float arg = x[s * 3 + a] * ldexpf(1.0f, k);
+            v = (j < 3) ? sinf(arg) : cosf(arg);
+        }
+        out[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------- a7
+// One 64-lane workgroup (= one wavefront) per ray.  The CDF is accumulated by lane 0 in the
+// oracle's sequential fp32 order (the bit-exact index requirement, SURVEY.md section 7 "hard
+// parts"); everything else is lane-parallel: bins, pdf, one upper_bound per u, and a bitonic
+// sort of the Nc+Nf union in LDS.  LDS per workgroup: 5 KiB.
+#define PDF_MAXC 256
+#define PDF_MAXT 512
+__global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, const float* __restrict__ weights,
+                                                    const float* __restrict__ u, int64_t R, int Nc, int Nf,
+                                                    float* __restrict__ zs_out, int32_t* __restrict__ inds_out,
+                                                    float* __restrict__ zfine_out)
+{
+    __shared__ float s_z[PDF_MAXC], s_w[PDF_MAXC], s_pdf[PDF_MAXC], s_cdf[PDF_MAXC], s_bins[PDF_MAXC];
+    __shared__ float s_sort[PDF_MAXT];
+    __shared__ float s_total;
+    const int lane = threadIdx.x;
+    const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
+    int P = 1;
+    while (P < Nt) P <<= 1;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        for (int i = lane; i < Nc; i += 64) {
+            s_z[i] = z[r * Nc + i];
+            s_w[i] = weights[r * Nc + i];
+        }
+        __syncthreads();
+        for (int k = lane; k < nb; k += 64) s_bins[k] = 0.5f * (s_z[k + 1] + s_z[k]);
+        if (lane == 0) {
+            float total = 0.0f;
+            for (int j = 0; j < nw; ++j) total = total + (s_w[j + 1] + 1e-5f);
+            s_total = total;
+        }
+        __syncthreads();
+        const float total = s_total;
+        for (int j = lane; j < nw; j += 64) s_pdf[j] = (s_w[j + 1] + 1e-5f) / total;
+        __syncthreads();
+        if (lane == 0) {
+            float c = 0.0f;
+            s_cdf[0] = 0.0f;
+            for (int j = 0; j < nw; ++j) {
+                c = c + s_pdf[j];
+                s_cdf[j + 1] = c;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < Nf; i += 64) {
+            const float uu = u ? u[r * Nf + i] : ((Nf > 1) ? ((float)i / (float)(Nf - 1)) : 0.0f);
+            int lo = 0, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+            }
+            const int inds = lo;
+            const int below = inds - 1 > 0 ? inds - 1 : 0;
+            const int above = inds < nb - 1 ? inds : nb - 1;
+            float denom = s_cdf[above] - s_cdf[below];
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uu - s_cdf[below]) / denom;
+            const float span = s_bins[above] - s_bins[below];
+            const float m = t * span;
+            const float zs = s_bins[below] + m;
+            if (zs_out) zs_out[r * Nf + i] = zs;
+            if (inds_out) inds_out[r * Nf + i] = inds;
+            s_sort[Nc + i] = zs;
+        }
+        if (zfine_out) {
+            for (int i = lane; i < Nc; i += 64) s_sort[i] = s_z[i];
+            for (int i = Nt + lane; i < P; i += 64) s_sort[i] = INFINITY;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = lane; t < (P >> 1); t += 64) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int p = i | j;
+                        const float a = s_sort[i], b = s_sort[p];
+                        const bool asc = (i & k) == 0;
+                        if ((a > b) == asc) {
+                            s_sort[i] = b;
+                            s_sort[p] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = lane; i < Nt; i += 64) zfine_out[r * Nt + i] = s_sort[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- a8
+// One thread per ray; the box table is wave-uniform (scalar loads, L2/K$ resident: M*60 B).
+__global__ __launch_bounds__(256) void k_bbox_hits(const float* __restrict__ rays, int64_t R,
+                                                    const float* __restrict__ box, int M, int max_hits,
+                                                    float* __restrict__ hit_t, int32_t* __restrict__ hit_box,
+                                                    int32_t* __restrict__ hit_count)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const float o0 = rays[r * 8 + 0], o1 = rays[r * 8 + 1], o2 = rays[r * 8 + 2];
+        const float d0 = rays[r * 8 + 3], d1 = rays[r * 8 + 4], d2 = rays[r * 8 + 5];
+        const float nr = rays[r * 8 + 6], fr = rays[r * 8 + 7];
+        for (int h = 0; h < max_hits; ++h) {
+            hit_box[r * max_hits + h] = -1;
+            hit_t[(r * max_hits + h) * 2 + 0] = 0.0f;
+            hit_t[(r * max_hits + h) * 2 + 1] = 0.0f;
+        }
+        int cnt = 0;
+        for (int m = 0; m < M; ++m) {
+            const float* b = box + m * 15;
+            const float p0 = o0 - b[0], p1 = o1 - b[1], p2 = o2 - b[2];
+            float tmin = nr, tmax = fr;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float r0 = b[3 + 3 * a], r1 = b[4 + 3 * a], r2 = b[5 + 3 * a];
+                const float ol = (r0 * p0 + r1 * p1) + r2 * p2;
+                const float dl = (r0 * d0 + r1 * d1) + r2 * d2;
+                const float inv = 1.0f / dl;
+                const float e = b[12 + a];
+                const float t1 = (-e - ol) * inv, t2 = (e - ol) * inv;
+                tmin = fmaxf(tmin, fminf(t1, t2));
+                tmax = fminf(tmax, fmaxf(t1, t2));
+            }
+            if (tmin <= tmax && cnt < max_hits) {
+                hit_t[(r * max_hits + cnt) * 2 + 0] = tmin;
+                hit_t[(r * max_hits + cnt) * 2 + 1] = tmax;
+                hit_box[r * max_hits + cnt] = m;
+                ++cnt;
+            }
+        }
+        hit_count[r] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_labels(const float* __restrict__ z, int64_t R, int N,
+                                                        const float* __restrict__ hit_t,
+                                                        const int32_t* __restrict__ hit_box,
+                                                        const int32_t* __restrict__ hit_count, int max_hits,
+                                                        const int32_t* __restrict__ box_ids,
+                                                        int32_t* __restrict__ label_sem,
+                                                        int32_t* __restrict__ label_inst)
+{
+    const int64_t total = R * N;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = s / N;
+        const float zz = z[s];
+        const int cnt = hit_count[r];
+        int best = -1;
+        float bt = 0.0f;
+        for (int h = 0; h < cnt; ++h) {
+            const float ti = hit_t[(r * max_hits + h) * 2], to = hit_t[(r * max_hits + h) * 2 + 1];
+            if (ti <= zz && zz <= to && (best < 0 || ti < bt)) {
+                best = h;
+                bt = ti;
+            }
+        }
+        int ls = -1, li = -1;
+        if (best >= 0) {
+            const int m = hit_box[r * max_hits + best];
+            ls = box_ids[m * 2];
+            li = box_ids[m * 2 + 1];
+        }
+        label_sem[s] = ls;
+        label_inst[s] = li;
+    }
+}
+
+// ------------------------------------------------------------------------------- C-ABI
+PNR_EXPORT int pnr_stratified(const float* rays, int64_t n_rays, int n_samples, int lindisp,
+                              const float* t_rand, float* z_out, void* stream)
+{
+    PNR_REQUIRE(rays && z_out, "pnr_stratified: null pointer");
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_stratified: bad size R=%lld N=%d", (long long)n_rays, n_samples);
+    if (n_rays == 0) return PNR_OK;
+    const int64_t total = n_rays * n_samples;
+    hipLaunchKernelGGL(k_stratified, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, n_rays, n_samples, lindisp, t_rand, z_out);
+    PNR_CHECK_LAUNCH("pnr_stratified");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_points(const float* rays, const float* z, int64_t n_rays, int n_samples, float* pts_out,
+                          void* stream)
+{
+    PNR_REQUIRE(rays && z && pts_out, "pnr_points: null pointer");
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_points: bad size");
+    if (n_rays == 0) return PNR_OK;
+    const int64_t total = n_rays * n_samples * 3;
+    hipLaunchKernelGGL(k_points, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, z, n_rays, n_samples, pts_out);
+    PNR_CHECK_LAUNCH("pnr_points");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_embed(const float* x, int64_t n, int L, float* out, void* stream)
+{
+    PNR_REQUIRE(x && out, "pnr_embed: null pointer");
+    PNR_REQUIRE(n >= 0 && L >= 0 && L <= 16, "pnr_embed: bad size n=%lld L=%d", (long long)n, L);
+    if (n == 0) return PNR_OK;
+    const int64_t total = n * (3 + 6 * L);
+    hipLaunchKernelGGL(k_embed, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, n, L, out);
+    PNR_CHECK_LAUNCH("pnr_embed");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse,
+                              int n_fine, float* z_samples, int32_t* inds, float* z_fine, void* stream)
+{
+    PNR_REQUIRE(z && weights, "pnr_sample_pdf: null pointer");
+    PNR_REQUIRE(n_coarse >= 3 && n_coarse <= PDF_MAXC, "pnr_sample_pdf: n_coarse=%d outside [3,%d]", n_coarse, PDF_MAXC);
+    PNR_REQUIRE(n_fine >= 1 && n_coarse + n_fine <= PDF_MAXT, "pnr_sample_pdf: n_coarse+n_fine=%d > %d",
+                n_coarse + n_fine, PDF_MAXT);
+    if (n_rays <= 0) return PNR_OK;
+    hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, (hipStream_t)stream,
+                       z, weights, u, n_rays, n_coarse, n_fine, z_samples, inds, z_fine);
+    PNR_CHECK_LAUNCH("pnr_sample_pdf");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_bbox_hits(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits,
+                             float* hit_t, int32_t* hit_box, int32_t* hit_count, void* stream)
+{
+    PNR_REQUIRE(rays && hit_t && hit_box && hit_count, "pnr_bbox_hits: null pointer");
+    PNR_REQUIRE(n_box >= 0 && (n_box == 0 || box), "pnr_bbox_hits: bad box table");
+    PNR_REQUIRE(max_hits >= 1 && max_hits <= 64, "pnr_bbox_hits: max_hits=%d outside [1,64]", max_hits);
+    if (n_rays <= 0) return PNR_OK;
+    hipLaunchKernelGGL(k_bbox_hits, dim3(pnr_grid_cap((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, n_rays, box, n_box, max_hits, hit_t, hit_box, hit_count);
+    PNR_CHECK_LAUNCH("pnr_bbox_hits");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float* hit_t,
+                                 const int32_t* hit_box, const int32_t* hit_count, int max_hits,
+                                 const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream)
+{
+    PNR_REQUIRE(z && hit_t && hit_box && hit_count && box_ids && label_sem && label_inst,
+                "pnr_sample_labels: null pointer");
+    PNR_REQUIRE(n_samples >= 1 && max_hits >= 1, "pnr_sample_labels: bad size");
+    if (n_rays <= 0) return PNR_OK;
+    const int64_t total = n_rays * n_samples;
+    hipLaunchKernelGGL(k_sample_labels, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, z, n_rays, n_samples, hit_t, hit_box, hit_count, max_hits, box_ids,
+                       label_sem, label_inst);
+    PNR_CHECK_LAUNCH("pnr_sample_labels");
+    return PNR_OK;
+}

@@ -1,0 +1,92 @@
+"""Network / make_network -- the host-side mirror of the reference's network plugin
+(lib/networks/<name>/network.py + make_network; the reference
+source is not in the mount, so names follow BASELINE.json's north_star and canonical NeRF).
+
+The module OWNS the parameters (an ordinary nn.Module with the canonical NeRF state_dict
+names, so reference checkpoints map key for key -- SURVEY.md 8f-3) but does not evaluate
+them with torch: Renderer hands the packed bf16/fp32 MFMA-fragment image of each NeRF to the
+fused HIP kernel.  `packed(level, device)` (re)builds that image when parameters change.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _get(cfg, name, default):
+    return getattr(cfg, name, default) if cfg is not None else default
+
+
+class NeRF(nn.Module):
+    """Parameter container of one NeRF MLP (coarse or fine).
+
+    pts_linears[i] (i<D): gamma(x)->W, W->W, with [gamma(x), h] concatenated after layer `skip`;
+    alpha_linear W->1; feature_linear W->W; views_linears[0] (W+gamma(d))->W/2; rgb_linear W/2->3;
+    semantic_linears / instance_linears: W -> W/2 -> n_sem / n_inst."""
+
+    def __init__(self, D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0):
+        super().__init__()
+        self.D, self.W, self.skip, self.xyz_L, self.dir_L = D, W, skip, xyz_L, dir_L
+        self.n_sem, self.n_inst, self.head_W = n_sem, n_inst, W // 2
+        ex, ed = 3 + 6 * xyz_L, 3 + 6 * dir_L
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(ex, W)] + [nn.Linear(W + ex if (i - 1) == skip else W, W) for i in range(1, D)])
+        self.alpha_linear = nn.Linear(W, 1)
+        self.feature_linear = nn.Linear(W, W)
+        self.views_linears = nn.ModuleList([nn.Linear(W + ed, W // 2)])
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        if n_sem:
+            self.semantic_linears = nn.ModuleList([nn.Linear(W, W // 2), nn.Linear(W // 2, n_sem)])
+        if n_inst:
+            self.instance_linears = nn.ModuleList([nn.Linear(W, W // 2), nn.Linear(W // 2, n_inst)])
+
+    def desc(self, precision):
+        return ops.make_desc(self.D, self.W, self.skip, self.xyz_L, self.dir_L, self.n_sem, self.n_inst,
+                             self.head_W, precision)
+
+
+class Network(nn.Module):
+    """Coarse (`nerf_0`) and fine (`nerf_1`) NeRFs, as the reference's Network holds them."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        D, W = _get(cfg, "D", 8), _get(cfg, "W", 256)
+        skips = _get(cfg, "skips", [4])
+        skip = skips[0] if len(skips) else -1
+        if skip >= D - 1:
+            skip = -1
+        kw = dict(D=D, W=W, skip=skip, xyz_L=_get(cfg, "xyz_res", 10), dir_L=_get(cfg, "view_res", 4),
+                  n_sem=_get(cfg, "num_classes", 0), n_inst=_get(cfg, "num_instances", 0))
+        self.precision = _get(cfg, "precision", "bf16")
+        self.nerf_0 = NeRF(**kw)
+        self.nerf_1 = NeRF(**kw) if _get(cfg, "N_importance", 0) > 0 else None
+        self._packed = {}
+
+    def nerf(self, level):
+        return self.nerf_0 if level == 0 or self.nerf_1 is None else self.nerf_1
+
+    def _version(self, level):
+        return tuple(p._version for p in self.nerf(level).parameters())
+
+    def packed(self, level, device, precision=None):
+        """(desc, packed device image) of level's NeRF; rebuilt when any parameter changed."""
+        precision = precision or self.precision
+        key = (level if self.nerf_1 is not None else 0, str(device), precision)
+        ver = self._version(level)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            net = self.nerf(level)
+            desc = net.desc(precision)
+            sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+            img = ops.pack_mlp(desc, sd).to(device)
+            self._packed[key] = hit = (ver, desc, img)
+        return hit[1], hit[2]
+
+    def forward(self, *a, **k):
+        raise RuntimeError("Network is evaluated by Renderer.render() through the fused HIP kernel; "
+                           "there is no torch forward (and no CPU fallback).")
+
+
+def make_network(cfg):
+    """Reference plugin surface: make_network(cfg) -> nn.Module."""
+    return Network(cfg)

@@ -1,0 +1,223 @@
+"""torch-tensor front ends of the C-ABI kernels (include/pnr.h).
+
+PyTorch is used only for device memory and the current HIP stream: every op takes CUDA
+(ROCm) float32 / int32 tensors, checks them, and passes raw pointers + sizes through ctypes.
+All ops fail loudly off-GPU; nothing here computes on the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MlpDesc, MlpParamsHost
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stratified(rays, n_samples, lindisp=False, t_rand=None):
+    """rays (R,8) -> z (R,N).  SURVEY 8a row a3."""
+    rays = _chk(rays, "rays")
+    t_rand = _chk(t_rand, "t_rand")
+    R = rays.shape[0]
+    assert rays.shape[-1] == 8
+    if t_rand is not None:
+        assert tuple(t_rand.shape) == (R, n_samples)
+    z = torch.empty((R, n_samples), device=rays.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.pnr_stratified(_p(rays), R, n_samples, int(bool(lindisp)), _p(t_rand), _p(z), _stream()),
+               "pnr_stratified")
+    return z
+
+
+def points(rays, z):
+    rays, z = _chk(rays, "rays"), _chk(z, "z")
+    R, N = z.shape
+    pts = torch.empty((R, N, 3), device=z.device, dtype=torch.float32)
+    _lib.check(_lib.load().pnr_points(_p(rays), _p(z), R, N, _p(pts), _stream()), "pnr_points")
+    return pts
+
+
+def embed(x, L):
+    """x (n,3) -> (n, 3+6L).  SURVEY 8a row a4."""
+    x = _chk(x, "x")
+    n = x.shape[0]
+    out = torch.empty((n, 3 + 6 * L), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().pnr_embed(_p(x), n, L, _p(out), _stream()), "pnr_embed")
+    return out
+
+
+def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=None, precision="bf16"):
+    d = MlpDesc()
+    d.D, d.W, d.skip, d.xyz_L, d.dir_L = D, W, skip, xyz_L, dir_L
+    d.n_sem, d.n_inst = n_sem, n_inst
+    d.head_W = W // 2 if head_W is None else head_W
+    d.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_FP32}[precision]
+    return d
+
+
+def pack_mlp(desc, params):
+    """params: dict name -> CPU float32 tensor (canonical NeRF names, see network.py).
+    Returns the packed image as a CPU uint8 tensor (pure host work, no GPU needed)."""
+    lib = _lib.load()
+    nbytes = lib.pnr_mlp_packed_bytes(ctypes.byref(desc))
+    if nbytes < 0:
+        _lib.check(int(nbytes), "pnr_mlp_packed_bytes")
+    keep = []
+
+    def fp(name):
+        if name not in params:
+            return None
+        t = params[name].detach().to("cpu", torch.float32).contiguous()
+        keep.append(t)
+        return ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+
+    P = MlpParamsHost()
+    D = desc.D
+    pw = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.weight") for i in range(D)])
+    pb = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.bias") for i in range(D)])
+    P.pts_w, P.pts_b = pw, pb
+    P.alpha_w, P.alpha_b = fp("alpha_linear.weight"), fp("alpha_linear.bias")
+    P.feature_w, P.feature_b = fp("feature_linear.weight"), fp("feature_linear.bias")
+    P.views_w, P.views_b = fp("views_linears.0.weight"), fp("views_linears.0.bias")
+    P.rgb_w, P.rgb_b = fp("rgb_linear.weight"), fp("rgb_linear.bias")
+    if desc.n_sem:
+        P.sem0_w, P.sem0_b = fp("semantic_linears.0.weight"), fp("semantic_linears.0.bias")
+        P.sem1_w, P.sem1_b = fp("semantic_linears.1.weight"), fp("semantic_linears.1.bias")
+    if desc.n_inst:
+        P.inst0_w, P.inst0_b = fp("instance_linears.0.weight"), fp("instance_linears.0.bias")
+        P.inst1_w, P.inst1_b = fp("instance_linears.1.weight"), fp("instance_linears.1.bias")
+    img = torch.empty(int(nbytes), dtype=torch.uint8)
+    _lib.check(lib.pnr_mlp_pack(ctypes.byref(desc), ctypes.byref(P), ctypes.c_void_p(img.data_ptr())),
+               "pnr_mlp_pack")
+    return img
+
+
+def n_channels(desc):
+    return 4 + desc.n_sem + desc.n_inst
+
+
+def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
+    """Fused gamma() + NeRF MLP + heads on every sample.  SURVEY 8a rows a4+a5.
+    Returns raw as (ch, R*N) when channel_major (fast layout) else (R, N, ch)."""
+    rays, z = _chk(rays, "rays"), _chk(z, "z")
+    packed = _chk(packed, "packed", torch.uint8)
+    R, N = z.shape
+    ch = n_channels(desc)
+    S = R * N
+    if channel_major:
+        raw = out if out is not None else torch.empty((ch, S), device=z.device, dtype=torch.float32)
+        assert tuple(raw.shape) == (ch, S)
+        ss, sc = 1, S
+    else:
+        raw = out if out is not None else torch.empty((R, N, ch), device=z.device, dtype=torch.float32)
+        ss, sc = ch, 1
+    _chk(raw, "raw")
+    _lib.check(_lib.load().pnr_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), ss, sc,
+                                           _stream()), "pnr_mlp_forward")
+    return raw
+
+
+def time_mlp_forward(desc, packed, rays, z, raw, iters):
+    """Mean ms per launch measured with hipEvents on the launch stream (bench only)."""
+    R, N = z.shape
+    ms = ctypes.c_float(0.0)
+    _lib.check(_lib.load().pnr_time_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1,
+                                                R * N, int(iters), ctypes.byref(ms), _stream()),
+               "pnr_time_mlp_forward")
+    return float(ms.value)
+
+
+def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
+              sem_mode=0, white_bkgd=False, want_weights=True):
+    """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
+    raw, z, rays = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays")
+    noise = _chk(noise, "noise")
+    label_sem = _chk(label_sem, "label_sem", torch.int32)
+    label_inst = _chk(label_inst, "label_inst", torch.int32)
+    R, N = z.shape
+    ch = 4 + n_sem + n_inst
+    if channel_major:
+        assert tuple(raw.shape) == (ch, R * N), f"raw shape {tuple(raw.shape)} != {(ch, R * N)}"
+        ss, sc = 1, R * N
+    else:
+        assert tuple(raw.shape) == (R, N, ch)
+        ss, sc = ch, 1
+    dev = z.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"rgb": torch.empty((R, 3), **f32), "depth": torch.empty((R,), **f32), "acc": torch.empty((R,), **f32)}
+    if want_weights:
+        out["weights"] = torch.empty((R, N), **f32)
+    if n_sem:
+        out["semantic"] = torch.empty((R, n_sem), **f32)
+        if label_sem is not None:
+            out["fix_semantic"] = torch.empty((R, n_sem), **f32)
+    if n_inst:
+        out["instance"] = torch.empty((R, n_inst), **f32)
+        if label_inst is not None:
+            out["fix_instance"] = torch.empty((R, n_inst), **f32)
+    g = out.get
+    _lib.check(_lib.load().pnr_composite(_p(raw), ss, sc, _p(z), _p(rays), _p(noise), _p(label_sem), _p(label_inst),
+                                         R, N, n_sem, n_inst, int(sem_mode), int(bool(white_bkgd)),
+                                         _p(out["rgb"]), _p(out["depth"]), _p(out["acc"]), _p(g("weights")),
+                                         _p(g("semantic")), _p(g("instance")), _p(g("fix_semantic")),
+                                         _p(g("fix_instance")), _stream()), "pnr_composite")
+    return out
+
+
+def sample_pdf(z, weights, n_importance, u=None, want_samples=True):
+    """Coarse z, weights (R,Nc) -> z_fine (R,Nc+Nf) sorted [, z_samples (R,Nf), inds (R,Nf)].
+    SURVEY 8a row a7."""
+    z, weights, u = _chk(z, "z"), _chk(weights, "weights"), _chk(u, "u")
+    R, Nc = z.shape
+    dev = z.device
+    z_fine = torch.empty((R, Nc + n_importance), device=dev, dtype=torch.float32)
+    zs = inds = None
+    if want_samples:
+        zs = torch.empty((R, n_importance), device=dev, dtype=torch.float32)
+        inds = torch.empty((R, n_importance), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().pnr_sample_pdf(_p(z), _p(weights), _p(u), R, Nc, n_importance, _p(zs), _p(inds),
+                                          _p(z_fine), _stream()), "pnr_sample_pdf")
+    return z_fine, zs, inds
+
+
+def bbox_hits(rays, box, max_hits=8):
+    """rays (R,8), box (M,15) -> hit_t (R,mh,2), hit_box (R,mh) int32, hit_count (R) int32.  Row a8."""
+    rays, box = _chk(rays, "rays"), _chk(box, "box")
+    R, M = rays.shape[0], box.shape[0]
+    dev = rays.device
+    hit_t = torch.empty((R, max_hits, 2), device=dev, dtype=torch.float32)
+    hit_box = torch.empty((R, max_hits), device=dev, dtype=torch.int32)
+    hit_count = torch.empty((R,), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().pnr_bbox_hits(_p(rays), R, _p(box), M, max_hits, _p(hit_t), _p(hit_box), _p(hit_count),
+                                         _stream()), "pnr_bbox_hits")
+    return hit_t, hit_box, hit_count
+
+
+def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
+    z, hit_t = _chk(z, "z"), _chk(hit_t, "hit_t")
+    hit_box, hit_count = _chk(hit_box, "hit_box", torch.int32), _chk(hit_count, "hit_count", torch.int32)
+    box_ids = _chk(box_ids, "box_ids", torch.int32)
+    R, N = z.shape
+    ls = torch.empty((R, N), device=z.device, dtype=torch.int32)
+    li = torch.empty((R, N), device=z.device, dtype=torch.int32)
+    _lib.check(_lib.load().pnr_sample_labels(_p(z), R, N, _p(hit_t), _p(hit_box), _p(hit_count), hit_box.shape[1],
+                                             _p(box_ids), _p(ls), _p(li), _stream()), "pnr_sample_labels")
+    return ls, li

@@ -1,0 +1,119 @@
+"""Renderer / make_renderer -- host-side mirror of lib/networks/renderer (render,
+render_rays; the reference source is not in the mount, so
+key names follow SURVEY.md 8b and are documented in DESIGN.md).
+
+`Renderer.render(batch)` orchestrates the HIP kernels per ray chunk:
+    pnr_stratified -> [pnr_bbox_hits, pnr_sample_labels] -> pnr_mlp_forward(coarse)
+    -> pnr_composite -> pnr_sample_pdf -> [labels] -> pnr_mlp_forward(fine) -> pnr_composite
+with every intermediate (z, raw, weights) resident in HBM, raw in the channel-major layout
+the compositing kernel streams.  No torch math is on the path.
+
+batch keys:  "rays" (B,N_rays,8) = o,d,near,far  (required)
+             "bbox" (M,15), "bbox_ids" (M,2) int32  (optional: 3D bbox prior)
+             "t_rand" (B,N_rays,N_samples), "u" (B,N_rays,N_importance)  (optional explicit uniforms;
+             otherwise drawn with torch.rand on the device when cfg.perturb > 0)
+output keys, level l in {0 (coarse), 1 (fine)}:
+             rgb_l (B,N_rays,3) depth_l acc_l (B,N_rays) weights_l z_vals_l (B,N_rays,N_l)
+             semantic_l / fix_semantic_l (B,N_rays,C), instance_l / fix_instance_l (B,N_rays,K)
+"""
+import torch
+
+from . import ops
+
+
+def _get(cfg, name, default):
+    return getattr(cfg, name, default) if cfg is not None else default
+
+
+class Renderer:
+    def __init__(self, net, cfg=None):
+        self.net = net
+        self.cfg = cfg
+        self.N_samples = _get(cfg, "N_samples", 64)
+        self.N_importance = _get(cfg, "N_importance", _get(cfg, "cascade_samples", 0))
+        self.chunk_size = _get(cfg, "chunk_size", 65536)
+        self.perturb = _get(cfg, "perturb", 0.0)
+        self.raw_noise_std = _get(cfg, "raw_noise_std", 0.0)
+        self.white_bkgd = _get(cfg, "white_bkgd", False)
+        self.lindisp = _get(cfg, "lindisp", False)
+        self.max_hits = _get(cfg, "max_hits", 8)
+        self.sem_mode = {"none": 0, "logits": 0, "softmax": 1}[_get(cfg, "semantic_activation", "none")]
+        self.keep_weights = _get(cfg, "keep_weights", True)
+
+    # --- one chunk of rays: the reference's render_rays (row a2)
+    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False):
+        net, Nc, Nf = self.net, self.N_samples, self.N_importance
+        n0 = net.nerf(0)
+        C, K = n0.n_sem, n0.n_inst
+        dev = rays.device
+        ret = {}
+        hits = None
+        if box is not None:
+            hits = ops.bbox_hits(rays, box, self.max_hits)
+        if t_rand is None and self.perturb > 0 and train:
+            t_rand = torch.rand((rays.shape[0], Nc), device=dev)
+        z = ops.stratified(rays, Nc, self.lindisp, t_rand)
+
+        def level(lv, zz):
+            desc, img = net.packed(lv, dev)
+            ls = li = None
+            if hits is not None:
+                ls, li = ops.sample_labels(zz, hits[0], hits[1], hits[2], box_ids)
+            raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
+            noise = None
+            if self.raw_noise_std > 0 and train:
+                noise = torch.randn(zz.shape, device=dev) * self.raw_noise_std
+            need_w = self.keep_weights or (lv == 0 and Nf > 0)
+            out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
+            for k, v in out.items():
+                ret[f"{k}_{lv}"] = v
+            ret[f"z_vals_{lv}"] = zz
+            return out
+
+        o0 = level(0, z)
+        if Nf > 0:
+            if u is None and self.perturb > 0 and train:
+                u = torch.rand((rays.shape[0], Nf), device=dev)
+            z_fine, _, _ = ops.sample_pdf(z, o0["weights"], Nf, u, want_samples=False)
+            level(1, z_fine)
+        return ret
+
+    # --- the plugin entry point (row a1)
+    def render(self, batch):
+        rays = batch["rays"]
+        if not rays.is_cuda:
+            raise RuntimeError("Renderer.render: batch['rays'] must be on the GPU (no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()) and self.net.training:
+            raise NotImplementedError(
+                "Renderer.render: the backward pass (SURVEY.md 8a row a9) is not built yet; call under "
+                "torch.no_grad() / net.eval().  See DESIGN.md 'what comes next'.")
+        lead = rays.shape[:-1]
+        rays = rays.reshape(-1, 8).float().contiguous()
+        R = rays.shape[0]
+        box = batch.get("bbox")
+        box_ids = batch.get("bbox_ids")
+        if box is not None:
+            box = box.reshape(-1, 15).float().contiguous()
+            box_ids = box_ids.reshape(-1, 2).int().contiguous()
+        t_rand, u = batch.get("t_rand"), batch.get("u")
+        if t_rand is not None:
+            t_rand = t_rand.reshape(R, -1).float().contiguous()
+        if u is not None:
+            u = u.reshape(R, -1).float().contiguous()
+        train = self.net.training
+        outs = []
+        for s in range(0, R, self.chunk_size):
+            e = min(R, s + self.chunk_size)
+            outs.append(self.render_rays(rays[s:e], box, box_ids,
+                                         None if t_rand is None else t_rand[s:e],
+                                         None if u is None else u[s:e], train))
+        ret = {}
+        for k in outs[0]:
+            v = outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)
+            ret[k] = v.reshape(*lead, *v.shape[1:])
+        return ret
+
+
+def make_renderer(cfg, network):
+    """Reference plugin surface: make_renderer(cfg, network) -> obj with .render(batch)."""
+    return Renderer(network, cfg)
