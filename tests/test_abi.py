@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: libpnr.so loads without a GPU, exports every symbol
+include/pnr.h declares, and rejects bad arguments with PNR_EINVAL + a message BEFORE touching
+the device (no compute is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from panopticnerf_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pnr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    names = _declared()
+    assert len(names) >= 14
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_loads_and_exports_every_symbol():
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(raw, name), f"libpnr.so does not export {name}"
+    assert lib.pnr_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(_lib.MlpDesc) == 64          # 9 ints + reserved[7]
+    assert ctypes.sizeof(_lib.MlpParamsHost) == 18 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_invalid_arguments_are_rejected_before_any_launch():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)     # non-null, never dereferenced: validation fails first
+    assert lib.pnr_stratified(null, 4, 8, 0, null, null, null) == -1
+    assert b"null" in lib.pnr_last_error()
+    assert lib.pnr_composite(one, 1, 4, one, one, null, null, null, 4, 6, 0, 0, 0, 0,
+                             null, null, null, null, null, null, null, null, null) == -1
+    assert b"multiple of 4" in lib.pnr_last_error()
+    assert lib.pnr_sample_pdf(one, one, null, 4, 2, 8, null, null, null, null) == -1
+    assert lib.pnr_sample_pdf(one, one, null, 4, 64, 1000, null, null, null, null) == -1
+    assert lib.pnr_bbox_hits(one, 4, one, 3, 0, one, one, one, null) == -1
+    d = ops.make_desc(W=200)
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1
+    assert b"W=200" in lib.pnr_last_error()
+    d = ops.make_desc(skip=7)
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1
+    d = ops.make_desc(n_sem=3, head_W=100)
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1
+    d = ops.make_desc()
+    assert lib.pnr_mlp_forward(ctypes.byref(d), null, null, null, 4, 4, null, 1, 16, null) == -1
+    # zero rays is a no-op, not an error (empty input edge case)
+    assert lib.pnr_stratified(one, 0, 8, 0, null, one, null) == 0
+    assert lib.pnr_embed(one, 0, 10, one, null) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.stratified(torch.zeros(4, 8), 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.composite(torch.zeros(4, 32), torch.zeros(4, 8), torch.zeros(4, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libpnr.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,113 @@
+"""GPU end-to-end tests of Renderer.render against the oracle's
+render_rays, the golden vectors, and -- at BASELINE's full-frame size -- size-independent
+properties (chunk independence, sortedness, weight mass, PSNR parity)."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as to
+from panopticnerf_amd import make_network, make_renderer, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, C, K, prec, seeds=(4, 5), **kw):
+    cfg = NS(N_samples=64, N_importance=128, num_classes=C, num_instances=K, precision=prec, **kw)
+    net = make_network(cfg).eval()
+    oc = to.mlp_config(n_sem=C, n_inst=K)
+    params = {"coarse": to.init_params(oc, seeds[0], sigma_bias=0.05), "fine": to.init_params(oc, seeds[1], sigma_bias=0.05)}
+    net.nerf_0.load_state_dict(params["coarse"])
+    net.nerf_1.load_state_dict(params["fine"])
+    return cfg, net.to(dev), oc, params
+
+
+def psnr(a, b):
+    return -10.0 * torch.log10(torch.mean((a - b) ** 2)).item()
+
+
+def test_render_fp32_matches_golden_and_oracle(dev, golden):
+    g = golden
+    R, Nc, Nf, C, K, M, MH = (int(v) for v in g["dims"])
+    cfg, net, oc, params = _setup(dev, C, K, "fp32", max_hits=MH)
+    rend = make_renderer(cfg, net)
+    rays = torch.tensor(g["rays"][:32])
+    with torch.no_grad():
+        out = rend.render({"rays": rays[None].to(dev), "bbox": torch.tensor(g["box"]).to(dev),
+                           "bbox_ids": torch.tensor(g["box_ids"]).to(dev)})
+    tol = {"depth_0": 6e-3, "depth_1": 6e-3, "z_vals_1": 2e-3}
+    for k in ("rgb_0", "depth_0", "acc_0", "rgb_1", "depth_1", "acc_1", "semantic_1", "instance_1",
+              "fix_semantic_1", "fix_instance_1", "z_vals_1"):
+        assert out[k].shape[:2] == (1, 32)
+        np.testing.assert_allclose(out[k][0].cpu().numpy(), g["e2e_" + k], atol=tol.get(k, 1e-4), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_render_fp32_vs_oracle_with_explicit_uniforms(dev, perturb):
+    C, K = 5, 3
+    cfg, net, oc, params = _setup(dev, C, K, "fp32", seeds=(7, 8), chunk_size=100, white_bkgd=True,
+                                  semantic_activation="softmax")
+    rays = synthetic.camera_rays()[:: (1408 * 376) // 257][:257].contiguous()      # 3 ragged chunks
+    box, ids = synthetic.random_boxes(40, C, K, seed=2)
+    gen = torch.Generator().manual_seed(3)
+    t_rand = torch.rand(257, 64, generator=gen) if perturb else None
+    u = torch.rand(257, 128, generator=gen) if perturb else None
+    ref = to.render_rays(params, oc, rays, 64, 128, t_rand=t_rand, u=u, box=box, box_ids=ids, sem_mode=1, white_bkgd=True)
+    batch = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    if perturb:
+        batch["t_rand"], batch["u"] = t_rand[None].to(dev), u[None].to(dev)
+    with torch.no_grad():
+        out = make_renderer(cfg, net).render(batch)
+    for k in ("rgb_0", "acc_0", "rgb_1", "acc_1", "semantic_1", "instance_1", "fix_semantic_1", "fix_instance_1"):
+        err = (out[k][0].cpu() - ref[k]).abs().max().item()
+        assert err < 1e-4, (k, err)
+    assert (out["depth_1"][0].cpu() - ref["depth_1"]).abs().max() < 1e-2      # metres, far = 100
+
+
+def test_render_bf16_psnr_parity(dev):
+    # north_star: PSNR within 0.05 dB of the reference.  No ground-truth images exist here, so the
+    # "ground truth" is the fp32 oracle render of a DIFFERENT fine network; the criterion is then
+    # |PSNR(hip bf16, gt) - PSNR(oracle fp32, gt)| < 0.05 dB, plus a direct bound on the bf16 error.
+    C, K = 6, 4
+    cfg, net, oc, params = _setup(dev, C, K, "bf16")
+    rays = synthetic.camera_rays()[:: (1408 * 376) // 2048][:2048].contiguous()
+    ref = to.render_rays(params, oc, rays, 64, 128)
+    gt = to.render_rays({"coarse": params["coarse"], "fine": to.init_params(oc, 99, sigma_bias=0.05)}, oc, rays, 64, 128)
+    with torch.no_grad():
+        out = make_renderer(cfg, net).render({"rays": rays[None].to(dev)})
+    rgb = out["rgb_1"][0].cpu()
+    assert abs(psnr(rgb, gt["rgb_1"]) - psnr(ref["rgb_1"], gt["rgb_1"])) < 0.05
+    assert psnr(rgb, ref["rgb_1"]) > 45.0
+    assert (out["semantic_1"][0].cpu() - ref["semantic_1"]).abs().max() < 3e-2
+
+
+def test_render_full_frame_properties(dev):
+    # BASELINE size: one 1408x376 frame, 64+128 samples, semantic + instance heads, bf16.
+    C, K = 19, 8
+    cfg, net, oc, params = _setup(dev, C, K, "bf16", chunk_size=65536)
+    rays = synthetic.camera_rays()
+    box, ids = synthetic.random_boxes(64, C, K)
+    rend = make_renderer(cfg, net)
+    batch = {"rays": rays.reshape(376, 1408, 8).to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        out = rend.render(batch)
+    assert out["rgb_1"].shape == (376, 1408, 3) and out["semantic_1"].shape == (376, 1408, C)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    z1 = out["z_vals_1"]
+    assert (z1[..., 1:] >= z1[..., :-1]).all() and z1.min() >= 0.5 and z1.max() <= 100.0
+    for lv in (0, 1):
+        w = out[f"weights_{lv}"]
+        assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-4).all()
+        assert torch.allclose(out[f"acc_{lv}"], w.sum(-1), atol=1e-4)
+        assert (out[f"fix_semantic_{lv}"].sum(-1) <= out[f"acc_{lv}"] + 1e-4).all()
+    # chunk independence / idempotence: any subset of rays rendered alone gives the same maps
+    idx = torch.arange(0, 376 * 1408, 1409)
+    sub = rend.render({"rays": rays[idx][None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)})
+    for k in ("rgb_1", "depth_1", "semantic_1", "instance_1", "fix_semantic_1", "z_vals_1"):
+        a = out[k].reshape(-1, *out[k].shape[2:])[idx.to(dev)]
+        assert torch.equal(a, sub[k][0]), k
+    # and the subset agrees with the oracle (bf16 emulation) where it can afford to run
+    ref = to.render_rays(params, oc, rays[idx], 64, 128, box=box, box_ids=ids, emulate_bf16=True)
+    assert (sub["rgb_1"][0].cpu() - ref["rgb_1"]).abs().max() < 2e-2

@@ -1,0 +1,290 @@
+"""GPU parity tests, one per stage of the path, all through the C-ABI:
+HIP kernel vs the oracle on identical seeded inputs, vs the committed golden vectors, and at
+BASELINE sizes through size-independent properties.
+
+Bars (BASELINE.json north_star): bit-exact z / sample indices / ray-bbox hits / labels;
+fp32 colour, depth, logits within 1e-4 abs on identical stage inputs; bf16 MLP against the
+bf16-emulating oracle within 1e-2 abs (one bf16 ulp of a hidden activation is 4e-3 relative;
+the only legitimate differences are rounding flips caused by fp32 accumulation order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import torch_oracle as to
+from panopticnerf_amd import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev).contiguous()
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def _rays(rng, R, near=0.5, far=60.0):
+    o = rng.normal(0, 1, (R, 3)) + np.array([0, 1.5, 0])
+    d = rng.normal(0, 0.3, (R, 3)) + np.array([0, 0, 1.0])
+    return np.concatenate([o, d, np.full((R, 1), near), np.full((R, 1), far)], 1).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- a3
+@pytest.mark.parametrize("N", [1, 32, 64, 192])
+@pytest.mark.parametrize("lindisp", [False, True])
+def test_stratified_bitexact(dev, N, lindisp):
+    rng = np.random.default_rng(N)
+    rays = _rays(rng, 777)
+    tr = rng.random((777, N)).astype(np.float32)
+    for t in (None, tr):
+        z = ops.stratified(T(rays, dev), N, lindisp, None if t is None else T(t, dev))
+        assert np.array_equal(N_(z), co.stratified(rays, N, lindisp, t))
+    pts = ops.points(T(rays, dev), z)
+    assert np.array_equal(N_(pts), co.points(rays, N_(z)))
+
+
+def test_stratified_golden_and_empty(dev, golden):
+    g = golden
+    Nc = int(g["dims"][1])
+    r = T(g["rays"], dev)
+    assert np.array_equal(N_(ops.stratified(r, Nc)), g["z_det"])
+    assert np.array_equal(N_(ops.stratified(r, Nc, True)), g["z_lindisp"])
+    zp = ops.stratified(r, Nc, False, T(g["t_rand"], dev))
+    assert np.array_equal(N_(zp), g["z_perturb"])
+    assert np.array_equal(N_(ops.points(r, zp)), g["pts"])
+    assert ops.stratified(r[:0], Nc).shape == (0, Nc)           # empty input
+
+
+# ----------------------------------------------------------------------------- a4
+@pytest.mark.parametrize("L", [0, 4, 10])
+def test_embed(dev, L, golden):
+    rng = np.random.default_rng(L)
+    x = (rng.normal(0, 30, (1001, 3))).astype(np.float32)      # arguments up to 2^9 * 100
+    e = N_(ops.embed(T(x, dev), L))
+    np.testing.assert_allclose(e, co.embed(x, L), atol=2e-6)
+    if L:
+        np.testing.assert_allclose(N_(ops.embed(T(golden["embed_x"], dev), L)), golden[f"embed_L{L}"], atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- a8
+def test_bbox_hits_and_labels_bitexact(dev, golden):
+    g = golden
+    R, Nc, Nf, C, K, M, MH = (int(v) for v in g["dims"])
+    ht, hb, hc = ops.bbox_hits(T(g["rays"], dev), T(g["box"], dev), MH)
+    assert np.array_equal(N_(hb), g["hit_box"]) and np.array_equal(N_(hc), g["hit_count"])
+    assert np.array_equal(N_(ht), g["hit_t"])
+    ls, li = ops.sample_labels(T(g["z_perturb"], dev), ht, hb, hc, T(g["box_ids"], dev))
+    assert np.array_equal(N_(ls), g["label_sem"]) and np.array_equal(N_(li), g["label_inst"])
+    # larger seeded case incl. max_hits clipping and an empty table
+    rng = np.random.default_rng(9)
+    rays = synthetic.camera_rays()[::211].numpy()
+    box, ids = synthetic.random_boxes(64, 45, 32, seed=9)
+    for mh in (2, 8):
+        a = ops.bbox_hits(T(rays, dev), box.to(dev), mh)
+        b = co.bbox_hits(rays, box.numpy(), mh)
+        assert np.array_equal(N_(a[1]), b[1]) and np.array_equal(N_(a[2]), b[2]) and np.array_equal(N_(a[0]), b[0])
+    assert b[2].max() == 8 or b[2].max() > 2
+    z = co.stratified(rays, 64, t_rand=rng.random((rays.shape[0], 64)).astype(np.float32))
+    l1 = ops.sample_labels(T(z, dev), *a, ids.to(dev))
+    l2 = co.sample_labels(z, *b, ids.numpy())
+    assert np.array_equal(N_(l1[0]), l2[0]) and np.array_equal(N_(l1[1]), l2[1])
+    assert (l2[0] >= 0).any()
+    e = ops.bbox_hits(T(rays, dev), torch.zeros((0, 15), device=dev), 4)
+    assert int(e[2].sum()) == 0 and int((e[1] != -1).sum()) == 0
+
+
+def test_bbox_axis_parallel_edge_cases(dev):
+    b = np.zeros((1, 15), np.float32)
+    b[0, 0:3] = (0, 0, 10)
+    b[0, 3:12] = np.eye(3).reshape(-1)
+    b[0, 12:15] = (1, 1, 1)
+    rays = np.array([[0.5, 0.5, 0, 0, 0, 1, 0.1, 50], [1.5, 0.5, 0, 0, 0, 1, 0.1, 50],
+                     [1.0, 0.0, 0, 0, 0, 1, 0.1, 50], [0, 0, 0, 0, 0, -1, 0.1, 50]], np.float32)
+    a = ops.bbox_hits(T(rays, dev), T(b, dev), 2)
+    c = co.bbox_hits(rays, b, 2)
+    assert np.array_equal(N_(a[2]), c[2]) and np.array_equal(N_(a[1]), c[1]) and np.array_equal(N_(a[0]), c[0])
+    assert list(c[2][:2]) == [1, 0]
+
+
+# ----------------------------------------------------------------------------- a7
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (32, 32), (64, 64), (8, 5)])
+def test_sample_pdf_bitexact(dev, Nc, Nf):
+    rng = np.random.default_rng(Nc * 1000 + Nf)
+    R = 513
+    rays = _rays(rng, R)
+    z = co.stratified(rays, Nc, t_rand=rng.random((R, Nc)).astype(np.float32))
+    # realistic weights: a few peaks over a floor, plus rows of exact zeros (flat CDF, denom<1e-5 branch)
+    w = (np.exp(-0.5 * ((np.arange(Nc)[None] - rng.uniform(0, Nc, (R, 1))) / rng.uniform(0.5, 6, (R, 1))) ** 2)
+         * rng.uniform(0, 1, (R, 1))).astype(np.float32)
+    w[::7] = 0.0
+    u = rng.random((R, Nf)).astype(np.float32)
+    for uu in (None, u):
+        zf, zs, inds = ops.sample_pdf(T(z, dev), T(w, dev), Nf, None if uu is None else T(uu, dev))
+        zs_c, inds_c = co.sample_pdf(z, w, Nf, uu)
+        assert np.array_equal(N_(inds), inds_c), "sample indices must be bit-exact"
+        assert np.array_equal(N_(zs), zs_c)
+        assert np.array_equal(N_(zf), co.merge_sorted(z, zs_c))
+
+
+def test_sample_pdf_golden(dev, golden):
+    g = golden
+    Nf = int(g["dims"][2])
+    for tag, u in (("det", None), ("rand", g["u"])):
+        zf, zs, inds = ops.sample_pdf(T(g["z_perturb"], dev), T(g["comp0_weights"], dev), Nf,
+                                      None if u is None else T(u, dev))
+        assert np.array_equal(N_(inds), g[f"pdf_{tag}_inds"]) and np.array_equal(N_(zs), g[f"pdf_{tag}_zs"])
+        assert np.array_equal(N_(zf), g[f"pdf_{tag}_zfine"])
+
+
+# ----------------------------------------------------------------------------- a6
+@pytest.mark.parametrize("N", [4, 32, 64, 128, 192, 256])
+@pytest.mark.parametrize("layout", ["channel", "sample"])
+def test_composite_vs_oracle(dev, N, layout):
+    rng = np.random.default_rng(N)
+    R, C, K = 301, 7, 5          # ragged: not a multiple of the rays-per-wave of any N
+    rays = _rays(rng, R)
+    z = co.stratified(rays, N, t_rand=rng.random((R, N)).astype(np.float32))
+    raw = rng.normal(0, 1, (R, N, 4 + C + K)).astype(np.float32)
+    raw[..., 3] = rng.normal(0.02, 0.2, (R, N))
+    noise = rng.normal(0, 0.05, (R, N)).astype(np.float32)
+    ls, li = rng.integers(-1, C, (R, N)).astype(np.int32), rng.integers(-1, K, (R, N)).astype(np.int32)
+    for sm, wb in ((0, False), (1, True)):
+        ref = co.composite(raw, z, rays, C, K, noise=noise, label_sem=ls, label_inst=li, sem_mode=sm, white_bkgd=wb)
+        if layout == "channel":
+            rg = T(np.ascontiguousarray(raw.reshape(R * N, -1).T), dev)
+        else:
+            rg = T(raw, dev)
+        out = ops.composite(rg, T(z, dev), T(rays, dev), C, K, layout == "channel", T(noise, dev), T(ls, dev),
+                            T(li, dev), sm, wb)
+        for k, v in ref.items():
+            tol = 1e-4 if k != "depth" else 1e-4 * 60     # depth is in metres (far = 60): 1e-4 relative to range
+            np.testing.assert_allclose(N_(out[k]), v, atol=tol, rtol=0, err_msg=f"{k} N={N} sem_mode={sm}")
+
+
+def test_composite_golden_and_minimal_outputs(dev, golden):
+    g = golden
+    R, Nc, Nf, C, K, M, MH = (int(v) for v in g["dims"])
+    rg = T(np.ascontiguousarray(g["raw"].reshape(R * Nc, -1).T), dev)
+    for sm in (0, 1):
+        out = ops.composite(rg, T(g["z_perturb"], dev), T(g["rays"], dev), C, K, True, T(g["noise"], dev),
+                            T(g["label_sem"], dev), T(g["label_inst"], dev), sm, bool(sm))
+        for k in ("rgb", "depth", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance"):
+            np.testing.assert_allclose(N_(out[k]), g[f"comp{sm}_{k}"], atol=1e-4 if k != "depth" else 6e-3, rtol=0)
+    # no heads, no weights requested
+    out = ops.composite(T(np.ascontiguousarray(g["raw"][..., :4].reshape(R * Nc, 4).T), dev), T(g["z_perturb"], dev),
+                        T(g["rays"], dev), 0, 0, True, want_weights=False)
+    assert set(out) == {"rgb", "depth", "acc"}
+
+
+def test_composite_properties_at_frame_size(dev):
+    # BASELINE size: one 1408x376 frame of 192-sample rays would need 33 GB of raw at C+K=77;
+    # the properties are per ray, so a 65,536-ray slab (the renderer's chunk) covers the same code.
+    R, N, C = 65536, 192, 45
+    g = torch.Generator(device=dev).manual_seed(0)
+    rays = synthetic.camera_rays()[:R].to(dev)
+    z = ops.stratified(rays, N)
+    raw = torch.randn((4 + C, R * N), generator=g, device=dev)
+    raw[3] = raw[3] * 0.05 + 0.01
+    out = ops.composite(raw, z, rays, C, 0, True)
+    w = out["weights"]
+    assert torch.isfinite(w).all() and (w >= 0).all() and (w.sum(1) <= 1 + 1e-4).all()
+    assert torch.allclose(out["acc"], w.sum(1), atol=1e-4)
+    assert (out["depth"] <= 100.0 * out["acc"] + 1e-2).all()
+    # linearity of logit compositing: sem(a*x + b*y) = a*sem(x) + b*sem(y) with sigma fixed
+    raw2 = raw.clone()
+    raw2[4:] = torch.randn((C, R * N), generator=g, device=dev)
+    raw3 = raw.clone()
+    raw3[4:] = 0.5 * raw[4:] - 2.0 * raw2[4:]
+    s1, s2 = out["semantic"], ops.composite(raw2, z, rays, C, 0, True)["semantic"]
+    s3 = ops.composite(raw3, z, rays, C, 0, True)["semantic"]
+    assert torch.allclose(s3, 0.5 * s1 - 2.0 * s2, atol=2e-4)
+    # one-hot fixed field composites to a weighted histogram: rows sum to the labelled weight mass
+    lab = torch.randint(-1, C, (R, N), generator=g, device=dev).int()
+    fx = ops.composite(raw, z, rays, C, 0, True, label_sem=lab)["fix_semantic"]
+    assert torch.allclose(fx.sum(1), (w * (lab >= 0)).sum(1), atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- a5
+def _mlp_case(dev, D, W, skips, C, K, prec, seed, S_rays=9, N=37, channel_major=True):
+    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2)
+    p = to.init_params(ocfg, seed=seed, sigma_bias=0.05)
+    desc = ops.make_desc(D, W, skips[0] if skips else -1, 10, 4, C, K, W // 2, prec)
+    img = ops.pack_mlp(desc, p).to(dev)
+    rng = np.random.default_rng(seed)
+    rays = _rays(rng, S_rays)
+    z = co.stratified(rays, N, t_rand=rng.random((S_rays, N)).astype(np.float32))
+    raw = ops.mlp_forward(desc, img, T(rays, dev), T(z, dev), channel_major=channel_major)
+    raw = N_(raw)
+    if channel_major:
+        raw = raw.T.reshape(S_rays, N, -1)
+    ref32 = to.run_network(p, ocfg, torch.tensor(rays), torch.tensor(z)).numpy()
+    refbf = to.run_network(p, ocfg, torch.tensor(rays), torch.tensor(z), emulate_bf16=True).numpy()
+    return raw, ref32, refbf
+
+
+@pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (8, 256, [4], 0, 0), (4, 128, [], 0, 0),
+                                  (3, 128, [1], 7, 0), (8, 256, [4], 19, 0)])
+def test_mlp_fp32_matches_oracle(dev, geom):
+    raw, ref32, _ = _mlp_case(dev, *geom, "fp32", seed=11)
+    np.testing.assert_allclose(raw, ref32, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (8, 256, [4], 0, 0), (4, 128, [], 0, 0),
+                                  (3, 128, [1], 7, 0)])
+def test_mlp_bf16_matches_bf16_oracle(dev, geom):
+    raw, ref32, refbf = _mlp_case(dev, *geom, "bf16", seed=12)
+    err = np.abs(raw - refbf)
+    assert err.max() < 1e-2, f"max {err.max()}"
+    assert np.median(err) < 5e-4
+    assert np.abs(raw - ref32).max() < 6e-2          # and it is a bf16-accurate evaluation of the fp32 network
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mlp_layouts_tails_and_golden(dev, prec, golden):
+    g = golden
+    # sample-major raw (the reference layout) == channel-major raw
+    a, r32, rbf = _mlp_case(dev, 8, 256, [4], 6, 5, prec, seed=13, S_rays=5, N=33, channel_major=False)
+    b, _, _ = _mlp_case(dev, 8, 256, [4], 6, 5, prec, seed=13, S_rays=5, N=33, channel_major=True)
+    assert np.array_equal(a, b)
+    # S smaller than one 32-sample tile, and S = 1
+    for S_rays, N in ((1, 1), (1, 31), (3, 43)):
+        raw, r32, rbf = _mlp_case(dev, 8, 256, [4], 6, 5, prec, seed=14, S_rays=S_rays, N=N)
+        np.testing.assert_allclose(raw, r32 if prec == "fp32" else rbf, atol=1e-4 if prec == "fp32" else 1e-2)
+    # golden vectors: small net with stored weights, big net from its seed
+    R_, N_s = g["mlp_z"].shape
+    C, K = int(g["dims"][3]), int(g["dims"][4])
+    p_s = {k[len("mlp_s."):]: torch.tensor(v) for k, v in g.items() if k.startswith("mlp_s.")}
+    desc = ops.make_desc(4, 128, 1, 10, 4, C, K, 64, prec)
+    raw = ops.mlp_forward(desc, ops.pack_mlp(desc, p_s).to(dev), T(g["mlp_rays"], dev), T(g["mlp_z"], dev))
+    np.testing.assert_allclose(N_(raw).T.reshape(R_, N_s, -1), g[f"mlp_s_raw_{prec}"],
+                               atol=1e-4 if prec == "fp32" else 1e-2)
+    p_b = to.init_params(to.mlp_config(n_sem=C, n_inst=K), seed=int(g["mlp_b_seed"][0]), sigma_bias=0.05)
+    desc = ops.make_desc(n_sem=C, n_inst=K, precision=prec)
+    raw = ops.mlp_forward(desc, ops.pack_mlp(desc, p_b).to(dev), T(g["mlp_rays"], dev), T(g["mlp_z"], dev))
+    np.testing.assert_allclose(N_(raw).T.reshape(R_, N_s, -1), g[f"mlp_b_raw_{prec}"],
+                               atol=1e-4 if prec == "fp32" else 1e-2)
+
+
+def test_mlp_many_groups_persistent_loop(dev):
+    # more sample groups than the persistent grid (512 workgroups x 128 samples): exercises the
+    # grid-stride loop and the weight stream wrapping from the last chunk back to chunk 0
+    C, K = 3, 2
+    ocfg = to.mlp_config(n_sem=C, n_inst=K)
+    p = to.init_params(ocfg, seed=21, sigma_bias=0.05)
+    desc = ops.make_desc(n_sem=C, n_inst=K, precision="bf16")
+    img = ops.pack_mlp(desc, p).to(dev)
+    rays = synthetic.camera_rays()[::53][:4096].contiguous()
+    z = ops.stratified(rays.to(dev), 64)
+    raw = ops.mlp_forward(desc, img, rays.to(dev), z)            # 262,144 samples = 2048 groups
+    assert torch.isfinite(raw).all()
+    idx = torch.arange(0, 4096, 97)
+    sub = ops.mlp_forward(desc, img, rays[idx].to(dev).contiguous(), z[idx.to(dev)].contiguous())
+    full = raw.reshape(-1, 4096, 64)[:, idx.to(dev)].reshape(raw.shape[0], -1)
+    assert torch.equal(full, sub), "a sample's result must not depend on which workgroup/iteration computed it"
+    ref = to.run_network(p, ocfg, rays[idx], z[idx.to(dev)].cpu(), emulate_bf16=True)
+    assert (sub.T.reshape(len(idx), 64, -1).cpu() - ref).abs().max() < 1e-2

@@ -1,0 +1,128 @@
+"""CPU tests of the host logic: the plugin surface (make_network / make_renderer), the
+state_dict key layout, loud failure off-GPU, synthetic inputs, and the ray-sharding path at
+world_size 2 over gloo (the oracle stands in for the GPU renderer -- tests may use it)."""
+import os
+import socket
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import torch_oracle as to
+from panopticnerf_amd import Network, Renderer, make_network, make_renderer, shard, synthetic
+
+
+def test_plugin_surface_and_state_dict_keys():
+    cfg = NS(N_samples=64, N_importance=128, num_classes=45, num_instances=32)
+    net = make_network(cfg)
+    assert isinstance(net, Network) and isinstance(net, torch.nn.Module)
+    rend = make_renderer(cfg, net)
+    assert isinstance(rend, Renderer) and callable(rend.render)
+    keys = set(net.state_dict())
+    for lv in (0, 1):
+        for name in ("pts_linears.0", "pts_linears.7", "alpha_linear", "feature_linear", "views_linears.0",
+                     "rgb_linear", "semantic_linears.0", "semantic_linears.1", "instance_linears.1"):
+            assert f"nerf_{lv}.{name}.weight" in keys and f"nerf_{lv}.{name}.bias" in keys
+    sd = net.nerf_0.state_dict()
+    assert sd["pts_linears.0.weight"].shape == (256, 63)
+    assert sd["pts_linears.5.weight"].shape == (256, 319)        # skip: [gamma(x), h]
+    assert sd["views_linears.0.weight"].shape == (128, 283)      # [feature, gamma(d)]
+    assert sd["semantic_linears.1.weight"].shape == (45, 128)
+    # same names/shapes as the oracle's parameter dict => checkpoints map key for key
+    ref = to.init_params(to.mlp_config(n_sem=45, n_inst=32))
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in ref.items()}
+    # coarse-only config has no fine network
+    assert make_network(NS(N_importance=0)).nerf_1 is None
+
+
+def test_packed_cache_tracks_parameter_updates():
+    net = make_network(NS(D=2, W=128, skips=[]))
+    d1, img1 = net.packed(0, "cpu")
+    d2, img2 = net.packed(0, "cpu")
+    assert img1 is img2
+    with torch.no_grad():
+        net.nerf_0.rgb_linear.bias.add_(1.0)
+    _, img3 = net.packed(0, "cpu")
+    assert img3 is not img1 and not torch.equal(img3, img1)
+
+
+def test_renderer_fails_loudly_without_gpu():
+    cfg = NS(N_samples=8, N_importance=0)
+    rend = make_renderer(cfg, make_network(cfg).eval())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rend.render({"rays": torch.zeros(1, 4, 8)})
+    with pytest.raises(RuntimeError):
+        make_network(cfg)(torch.zeros(1))
+
+
+def test_synthetic_inputs_are_kitti_shaped():
+    rays = synthetic.camera_rays()
+    assert rays.shape == (1408 * 376, 8) and rays.dtype == torch.float32
+    assert torch.all(rays[:, 6] == 0.5) and torch.all(rays[:, 7] == 100.0)
+    box, ids = synthetic.random_boxes(64, 45, 32)
+    assert box.shape == (64, 15) and ids.shape == (64, 2) and ids.dtype == torch.int32
+    Rm = box[:, 3:12].reshape(-1, 3, 3)
+    assert torch.allclose(Rm @ Rm.transpose(1, 2), torch.eye(3).expand(64, 3, 3), atol=1e-6)
+    hits = to.bbox_hits(rays[::997], box, 8)
+    assert hits[2].sum() > 0          # the prior is exercised by the synthetic scene
+
+
+def test_shard_roundtrip_single_process():
+    rays = torch.arange(11 * 8, dtype=torch.float32).reshape(11, 8)
+    parts = [shard.shard_rays(rays, r, 3) for r in range(3)]
+    assert sum(p.shape[0] for p in parts) == 11
+    assert torch.equal(parts[1][0], rays[1]) and torch.equal(parts[2][1], rays[5])
+    assert shard.gather_maps({"a": rays}, 11, 0, 1)["a"] is rays
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rays, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    cfg = to.mlp_config(D=2, W=32, skips=(), n_sem=3, n_inst=2, head_W=16)
+    params = {"coarse": to.init_params(cfg, 1, sigma_bias=0.1), "fine": to.init_params(cfg, 2, sigma_bias=0.1)}
+    rays = synthetic.camera_rays()[:: (1408 * 376) // n_rays][:n_rays].contiguous()
+
+    def render(r):
+        o = to.render_rays(params, cfg, r, 16, 16)
+        return {k: o[k] for k in ("rgb_1", "depth_1", "semantic_1", "z_vals_1")}
+
+    full = shard.render_sharded(render, rays, rank, world, gather=True)
+    local = shard.render_sharded(render, rays, rank, world, gather=False)
+    assert local["rgb_1"].shape[0] == len(range(rank, n_rays, world))
+    ref = render(rays)
+    ok = all(torch.allclose(full[k], ref[k], atol=1e-6) for k in ref)
+    # every rank holds the same complete frame
+    chk = full["rgb_1"].double().sum().reshape(1)
+    both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both, chk)
+    ok = ok and all(torch.equal(b, both[0]) for b in both)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("n_rays", [10, 7])      # even and ragged split over 2 ranks
+def test_sharded_render_world2_gloo(n_rays):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)

@@ -1,0 +1,57 @@
+"""CPU tests of the host packer (pnr_mlp_pack): the packed MFMA-fragment image, pushed
+through a numpy emulation of the kernel's dataflow (tests/_emulate.py), must reproduce the
+dense oracle MLP.  Covers BASELINE configs' geometries: 8x256 skip@4 with heads (configs 2-5)
+and 4x128 without skip (config 1)."""
+import ctypes
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from _emulate import PackedImage, emulate
+from oracle import torch_oracle as to
+from panopticnerf_amd import _lib, make_network, ops
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (8, 256, [4], 0, 0), (4, 128, [], 0, 0),
+                                  (3, 128, [1], 7, 0), (2, 128, [0], 0, 33)])
+def test_packed_image_reproduces_dense_mlp(prec, geom):
+    D, W, skips, C, K = geom
+    torch.manual_seed(D * 1000 + W + C)
+    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K))
+    sd = net.nerf_0.state_dict()
+    desc = net.nerf_0.desc(prec)
+    img = ops.pack_mlp(desc, sd)
+    n = 37
+    pts = torch.rand(n, 3) * 40 - 20
+    vd = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2)
+    ref = to.mlp_forward({k: v.detach() for k, v in sd.items()}, ocfg, pts, vd, emulate_bf16=(prec == "bf16")).numpy()
+    em = emulate(img, pts.numpy(), vd.numpy())
+    # bf16: an activation that lands on a rounding tie may flip (accumulation order) -> 1 bf16 ulp downstream
+    np.testing.assert_allclose(em, ref, atol=2e-3 if prec == "bf16" else 2e-6)
+
+
+def test_image_header_and_sizes():
+    desc = ops.make_desc(n_sem=45, n_inst=32)
+    net = make_network(NS(num_classes=45, num_instances=32))
+    img = ops.pack_mlp(desc, net.nerf_0.state_dict())
+    im = PackedImage(img)
+    assert img.numel() == _lib.load().pnr_mlp_packed_bytes(ctypes.byref(desc))
+    # trunk 8x8 + sem 4+2 + inst 4+1 + feature 8 + views 4 + rgb/sigma 1
+    assert im.n_chunks == 64 + 6 + 5 + 8 + 4 + 1
+    assert im.max_frags == 25      # rgb/sigma chunk: 8 (g) + 16 (h) k-steps + bias
+    assert int(im.table[:, 1].sum()) * 1024 + im.data_off == img.numel()
+    # fp32 image: twice the k-steps
+    d32 = ops.make_desc(n_sem=45, n_inst=32, precision="fp32")
+    im32 = PackedImage(ops.pack_mlp(d32, net.nerf_0.state_dict()))
+    assert im32.n_chunks == im.n_chunks and im32.max_frags == 49
+
+
+def test_pack_rejects_missing_parameters():
+    desc = ops.make_desc(n_sem=5)
+    net = make_network(NS(num_classes=0))
+    with pytest.raises(RuntimeError, match="semantic"):
+        ops.pack_mlp(desc, net.nerf_0.state_dict())
