@@ -216,12 +216,14 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
                              int sem_mode, int white_bkgd, float* rgb, float* depth, float* acc, float* weights,
                              float* sem, float* inst, float* fix_sem, float* fix_inst, void* stream)
 {
-    PNR_REQUIRE(raw && z && rays, "pnr_composite: null pointer");
+    PNR_REQUIRE(n_rays <= 0 || (raw && z && rays), "pnr_composite: null pointer");
     PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0,
                 "pnr_composite: n_samples=%d must be a multiple of 4 in [4,256]", n_samples);
     PNR_REQUIRE(n_sem >= 0 && n_inst >= 0 && (sem_mode == 0 || sem_mode == 1), "pnr_composite: bad field sizes");
     PNR_REQUIRE((((uintptr_t)z) & 15) == 0, "pnr_composite: z must be 16-byte aligned");
     PNR_REQUIRE(!weights || (((uintptr_t)weights) & 15) == 0, "pnr_composite: weights must be 16-byte aligned");
+    PNR_REQUIRE((((uintptr_t)noise) & 15) == 0 && (((uintptr_t)label_sem) & 15) == 0 && (((uintptr_t)label_inst) & 15) == 0,
+                "pnr_composite: noise / label arrays must be 16-byte aligned");
     if (n_rays <= 0) return PNR_OK;
     CompositeArgs a;
     a.raw = raw; a.stride_s = raw_stride_s; a.stride_c = raw_stride_c; a.z = z; a.rays = rays; a.noise = noise;

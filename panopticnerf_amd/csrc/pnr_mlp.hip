@@ -22,6 +22,10 @@
 
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
+#ifndef PNR_MLP_DEFAULT_VARIANT
+#define PNR_MLP_DEFAULT_VARIANT 0
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -71,33 +75,71 @@ __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x1
     }
 }
 
-template <int WAVES>
+// The chunk table is read through the constant address space so that hipcc emits scalar
+// (s_load) instead of vector loads: a vector load here costs an L2 round trip AND a vmcnt(0)
+// that drains the in-flight LDS-DMA, once per chunk.
+typedef const __attribute__((address_space(4))) pnr_chunk_entry* table_ptr;
+
+// DB = true : two LDS slots, chunk c+1 streams in while chunk c feeds the MFMAs.
+// DB = false: one slot (fp32 parity mode, whose 49 KiB chunks would put a second slot past the
+//             64 KiB that the LDS-DMA destination offset (M0[15:0]) can address).
+template <int WAVES, bool DB, int GDB_>
 struct Ctx {
+    static constexpr int GDB = GDB_;   // A-fragment read-ahead (k-steps) on the double-buffered path
     const MlpArgs& a;
     char* smem;
     int lane, wave, hi;
     int ci, slot;
+    pnr_chunk_entry e1, e2;   // table entries of chunks ci+1 and ci+2 (fetched a chunk early)
 
-    // Issue the L2 -> LDS copy of chunk `idx` into slot `sl` (asynchronous; LDS-DMA).
-    __device__ __forceinline__ void issue(int idx, int sl) const
+    __device__ __forceinline__ int wrap(int i) const { return i >= a.n_chunks ? i - a.n_chunks : i; }
+    __device__ __forceinline__ pnr_chunk_entry entry(int idx) const
     {
-        const pnr_chunk_entry e = a.table[idx];
+        table_ptr t = (table_ptr)(uintptr_t)a.table;
+        pnr_chunk_entry e;
+        e.off_frag = t[idx].off_frag;
+        e.nfrag = t[idx].nfrag;
+        return e;
+    }
+    // Issue the L2 -> LDS copy of a chunk into slot `sl` (asynchronous; LDS-DMA).
+    __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int sl) const
+    {
         const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
         char* dst = smem + sl * a.slot_bytes;
         for (int f = wave; f < (int)e.nfrag; f += WAVES)
             __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
                                              (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
     }
-    __device__ __forceinline__ int next_index() const { return ci + 1 == a.n_chunks ? 0 : ci + 1; }
-    __device__ __forceinline__ void prefetch() const { issue(next_index(), slot ^ 1); }
+    __device__ __forceinline__ void start()
+    {
+        ci = 0; slot = 0;
+        issue(entry(0), 0);
+        e1 = entry(wrap(1));
+        e2 = entry(wrap(2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void prefetch() const
+    {
+        if constexpr (DB) issue(e1, slot ^ 1);
+    }
     __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
     // All of this wave's LDS-DMA has landed, every wave is done reading the current slot.
     __device__ __forceinline__ void finish()
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        ci = next_index();
-        slot ^= 1;
+        if constexpr (DB) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            slot ^= 1;
+        } else {
+            __syncthreads();                 // every wave has read the slot
+            issue(e1, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        ci = wrap(ci + 1);
+        e1 = e2;
+        e2 = entry(wrap(ci + 2));
     }
 };
 
@@ -110,9 +152,57 @@ __device__ __forceinline__ void load_bias(const char* bias_frag, int hi, f32x16&
     }
 }
 
+
+// All MFMAs of one chunk.  A fragments are read from LDS in groups of G k-steps, one group
+// ahead of the MFMAs that use them; the memory-clobber fence keeps hipcc from hoisting every
+// ds_read_b128 of the chunk to its top (which costs 64-96 VGPRs and forces spills at 2
+// waves/SIMD) while leaving MFMA/VALU scheduling free.
+template <int PREC, int TILES, int G, int NA, int NB>
+__device__ __forceinline__ void mma_chunk(const char* frag, const uint32_t (&inA)[TILES][NA],
+                                          const uint32_t (&inB)[TILES][NB > 0 ? NB : 1], f32x16 (&acc)[TILES])
+{
+    constexpr int KSA = NA / 4, KSB = NB / 4, KS = KSA + KSB, NG = (KS + G - 1) / G;
+    constexpr int MPK = PREC == PNR_PREC_BF16 ? 1 : 4;   // MFMAs per k-step per tile
+    u32x4 A[2][G];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        if (j < KS) A[0][j] = *reinterpret_cast<const u32x4*>(frag + j * PNR_FRAG_BYTES);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int ks = (g + 1) * G + j;
+                if (ks < KS) A[(g + 1) & 1][j] = *reinterpret_cast<const u32x4*>(frag + ks * PNR_FRAG_BYTES);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int ks = g * G + j;
+            if (ks < KS) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    if (ks < KSA) acc[t] = kstep<PREC>(A[g & 1][j], &inA[t][4 * (ks < KSA ? ks : 0)], acc[t]);
+                    else if constexpr (NB > 0) acc[t] = kstep<PREC>(A[g & 1][j], &inB[t][4 * (ks >= KSA ? ks - KSA : 0)], acc[t]);
+                }
+            }
+        }
+        // pin the interleave: the next group's G ds_reads go out two per k-step during the FIRST half
+        // of this group's MFMAs, so the youngest read is >= G/2 k-steps old at the group boundary
+#pragma unroll
+        for (int j = 0; j < G / 2; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TILES * MPK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, (G - G / 2) * TILES * MPK, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
-template <int PREC, int TILES, int WAVES, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
-__device__ __forceinline__ void layer_regs(Ctx<WAVES>& c, const uint32_t (&inA)[TILES][NA],
+template <int PREC, int TILES, int WAVES, bool DB, int GDB, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
+__device__ __forceinline__ void layer_regs(Ctx<WAVES, DB, GDB>& c, const uint32_t (&inA)[TILES][NA],
                                            const uint32_t (&inB)[TILES][NB > 0 ? NB : 1],
                                            uint32_t (&out)[TILES][NOUT])
 {
@@ -128,20 +218,7 @@ __device__ __forceinline__ void layer_regs(Ctx<WAVES>& c, const uint32_t (&inA)[
         load_bias(base + (KSA + KSB) * PNR_FRAG_BYTES, c.hi, acc[0]);
 #pragma unroll
         for (int t = 1; t < TILES; ++t) acc[t] = acc[0];
-#pragma unroll
-        for (int ks = 0; ks < KSA; ++ks) {
-            const u32x4 av = *reinterpret_cast<const u32x4*>(frag + ks * PNR_FRAG_BYTES);
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inA[t][4 * ks], acc[t]);
-        }
-        if constexpr (NB > 0) {
-#pragma unroll
-            for (int ks = 0; ks < KSB; ++ks) {
-                const u32x4 av = *reinterpret_cast<const u32x4*>(frag + (KSA + ks) * PNR_FRAG_BYTES);
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inB[t][4 * ks], acc[t]);
-            }
-        }
+        mma_chunk<PREC, TILES, (DB ? GDB : 4), NA, NB>(frag, inA, inB, acc);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             if constexpr (PREC == PNR_PREC_BF16) {
@@ -165,8 +242,8 @@ __device__ __forceinline__ void layer_regs(Ctx<WAVES>& c, const uint32_t (&inA)[
 }
 
 // Output layer: rows [0, n_out) are stored to raw channels ch_base + row.
-template <int PREC, int TILES, int WAVES, int NA, int NB>
-__device__ __forceinline__ void layer_out(Ctx<WAVES>& c, const uint32_t (&inA)[TILES][NA],
+template <int PREC, int TILES, int WAVES, bool DB, int GDB, int NA, int NB>
+__device__ __forceinline__ void layer_out(Ctx<WAVES, DB, GDB>& c, const uint32_t (&inA)[TILES][NA],
                                           const uint32_t (&inB)[TILES][NB > 0 ? NB : 1], int n_out, int ch_base,
                                           const int (&samp)[TILES])
 {
@@ -181,20 +258,7 @@ __device__ __forceinline__ void layer_out(Ctx<WAVES>& c, const uint32_t (&inA)[T
         load_bias(base + (KSA + KSB) * PNR_FRAG_BYTES, c.hi, acc[0]);
 #pragma unroll
         for (int t = 1; t < TILES; ++t) acc[t] = acc[0];
-#pragma unroll
-        for (int ks = 0; ks < KSA; ++ks) {
-            const u32x4 av = *reinterpret_cast<const u32x4*>(frag + ks * PNR_FRAG_BYTES);
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inA[t][4 * ks], acc[t]);
-        }
-        if constexpr (NB > 0) {
-#pragma unroll
-            for (int ks = 0; ks < KSB; ++ks) {
-                const u32x4 av = *reinterpret_cast<const u32x4*>(frag + (KSA + ks) * PNR_FRAG_BYTES);
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) acc[t] = kstep<PREC>(av, &inB[t][4 * ks], acc[t]);
-            }
-        }
+        mma_chunk<PREC, TILES, (DB ? GDB : 4), NA, NB>(frag, inA, inB, acc);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             if (samp[t] >= 0) {
@@ -237,9 +301,11 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
     }
 }
 
-template <int PREC, int W, int TILES, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_mlp_fused(const MlpArgs a)
+template <int PREC, int W, int TILES, int WAVES, int MINW>
+__global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 {
+    constexpr bool DB = PREC == PNR_PREC_BF16;
+    constexpr int GDB = MINW >= 2 ? 4 : 8;   // deeper read-ahead when a wave is alone on its SIMD
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPB = PrecT<PREC>::RPB;
     constexpr int NFB = W / 32, HFB = W / 64;
@@ -247,13 +313,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_fused(const MlpArgs a)
     constexpr int GXR = PREC == PNR_PREC_BF16 ? 16 : 32;
     constexpr int GDR = PREC == PNR_PREC_BF16 ? 8 : 16;
 
-    Ctx<WAVES> c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
-                 (int)((threadIdx.x & 63) >> 5), 0, 0};
+    Ctx<WAVES, DB, GDB> c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
+                 (int)((threadIdx.x & 63) >> 5), 0, 0, {0, 0}, {0, 0}};
     const int n = c.lane & 31;
-
-    c.issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    c.start();
 
     uint32_t dummy[TILES][1];
 #pragma unroll
@@ -283,13 +346,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_fused(const MlpArgs a)
         }
 
         uint32_t cur[TILES][HR], nxt[TILES][HR];
-        layer_regs<PREC, TILES, WAVES, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur);
+        layer_regs<PREC, TILES, WAVES, DB, GDB, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur);
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             if (l - 1 == a.skip)
-                layer_regs<PREC, TILES, WAVES, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt);
+                layer_regs<PREC, TILES, WAVES, DB, GDB, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt);
             else
-                layer_regs<PREC, TILES, WAVES, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt);
+                layer_regs<PREC, TILES, WAVES, DB, GDB, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt);
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -297,53 +360,74 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_fused(const MlpArgs a)
         }
         if (a.n_sem) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, WAVES, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
-            layer_out<PREC, TILES, WAVES, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
+            layer_regs<PREC, TILES, WAVES, DB, GDB, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_out<PREC, TILES, WAVES, DB, GDB, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, WAVES, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
-            layer_out<PREC, TILES, WAVES, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+            layer_regs<PREC, TILES, WAVES, DB, GDB, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_out<PREC, TILES, WAVES, DB, GDB, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
-        layer_regs<PREC, TILES, WAVES, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt);
+        layer_regs<PREC, TILES, WAVES, DB, GDB, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt);
         uint32_t ed[TILES][GDR];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) embed_lane<PREC, 2, 16, GDR>(vd[t][0], vd[t][1], vd[t][2], c.hi, ed[t]);
         uint32_t g[TILES][GR];
-        layer_regs<PREC, TILES, WAVES, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g);
-        layer_out<PREC, TILES, WAVES, GR, HR>(c, g, cur, 4, 0, samp);
+        layer_regs<PREC, TILES, WAVES, DB, GDB, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g);
+        layer_out<PREC, TILES, WAVES, DB, GDB, GR, HR>(c, g, cur, 4, 0, samp);
     }
 }
 
 // ------------------------------------------------------------------------------- launcher
-template <int PREC, int W, int TILES, int WAVES>
-static int launch_mlp(const MlpArgs& a0, int lds_bytes, hipStream_t stream)
+template <int PREC, int W, int TILES, int WAVES, int MINW>
+static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
+    constexpr bool DB = PREC == PNR_PREC_BF16;
+    const int lds_bytes = (DB ? 2 : 1) * a.slot_bytes;
+    PNR_REQUIRE(lds_bytes <= 65536, "pnr_mlp_forward: weight-stream LDS footprint %d > 64 KiB (LDS-DMA offset limit)",
+                lds_bytes);
     const int per_group = 32 * TILES * WAVES;
     a.n_groups = (a.S + per_group - 1) / per_group;
-    auto kern = k_mlp_fused<PREC, W, TILES, WAVES>;
-    static thread_local int configured = 0;
-    if (configured < lds_bytes) {
-        PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        configured = lds_bytes;
+    auto kern = k_mlp_fused<PREC, W, TILES, WAVES, MINW>;
+    static thread_local int wg_per_cu = 0;
+    if (wg_per_cu == 0) {
+        PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        int nb = 0;
+        PNR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 64 * WAVES, lds_bytes));
+        wg_per_cu = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
     }
-    // persistent-style grid: at most 2 workgroups per CU, grid-stride over sample groups
-    const int grid = a.n_groups < 512 ? a.n_groups : 512;
+    // persistent grid: every resident workgroup slot of the 256 CUs, grid-stride over sample groups
+    const int cap = 256 * wg_per_cu;
+    const int grid = a.n_groups < cap ? a.n_groups : cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
     PNR_CHECK_LAUNCH("pnr_mlp_forward");
     return PNR_OK;
 }
 
-// Tunable at run time for A/B measurements (bench / tests): PNR_MLP_TILES in {1,2}.
-static int mlp_tiles_default()
+// Kernel variant for the bf16 path, selectable at run time for A/B measurements
+// (PNR_MLP_VARIANT): 0 = 1 tile/wave, 4 waves, 1 wave/SIMD;  1 = 1 tile/wave, 4 waves,
+// registers capped for 2 workgroups per CU;  2 = 2 tiles/wave, 4 waves;  3 = 1 tile/wave, 8 waves.
+static int mlp_variant()
 {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("PNR_MLP_TILES");
-        v = (e && e[0] == '2') ? 2 : 1;
+        const char* e = getenv("PNR_MLP_VARIANT");
+        v = e ? atoi(e) : PNR_MLP_DEFAULT_VARIANT;
+        if (v < 0 || v > 3) v = PNR_MLP_DEFAULT_VARIANT;
     }
     return v;
+}
+
+template <int W>
+static int launch_bf16(const MlpArgs& a, hipStream_t st)
+{
+    switch (mlp_variant()) {
+    case 1: return launch_mlp<PNR_PREC_BF16, W, 1, 4, 2>(a, st);
+    case 2: return launch_mlp<PNR_PREC_BF16, W, 2, 4, 1>(a, st);
+    case 3: return launch_mlp<PNR_PREC_BF16, W, 1, 8, 2>(a, st);
+    default: return launch_mlp<PNR_PREC_BF16, W, 1, 4, 1>(a, st);
+    }
 }
 
 PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
@@ -352,13 +436,13 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(packed && rays && z && raw, "pnr_mlp_forward: null pointer");
     PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_mlp_forward: bad size");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(packed && rays && z && raw, "pnr_mlp_forward: null pointer");
     PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_forward: R*N=%lld exceeds 2^31",
                 (long long)(n_rays * n_samples));
     PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)packed) & 15) == 0,
                 "pnr_mlp_forward: rays / packed must be 16-byte aligned");
-    if (n_rays == 0) return PNR_OK;
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     MlpArgs a;
@@ -369,17 +453,10 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
     a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples; a.n_groups = 0;
     a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
-    const int lds = 2 * a.slot_bytes;
     hipStream_t st = (hipStream_t)stream;
-    if (desc->precision == PNR_PREC_BF16) {
-        const int tiles = mlp_tiles_default();
-        if (desc->W == 256) return tiles == 2 ? launch_mlp<PNR_PREC_BF16, 256, 2, 4>(a, lds, st)
-                                              : launch_mlp<PNR_PREC_BF16, 256, 1, 4>(a, lds, st);
-        return tiles == 2 ? launch_mlp<PNR_PREC_BF16, 128, 2, 4>(a, lds, st)
-                          : launch_mlp<PNR_PREC_BF16, 128, 1, 4>(a, lds, st);
-    }
-    if (desc->W == 256) return launch_mlp<PNR_PREC_FP32, 256, 1, 4>(a, lds, st);
-    return launch_mlp<PNR_PREC_FP32, 128, 1, 4>(a, lds, st);
+    if (desc->precision == PNR_PREC_BF16) return desc->W == 256 ? launch_bf16<256>(a, st) : launch_bf16<128>(a, st);
+    if (desc->W == 256) return launch_mlp<PNR_PREC_FP32, 256, 1, 4, 1>(a, st);
+    return launch_mlp<PNR_PREC_FP32, 128, 1, 4, 1>(a, st);
 }
 
 PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
@@ -401,7 +478,7 @@ PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed
     float ms = 0.0f;
     PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out_host = ms / (float)iters;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return PNR_OK;
 }

@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void k_sample_labels(const float* __restrict__
 PNR_EXPORT int pnr_stratified(const float* rays, int64_t n_rays, int n_samples, int lindisp,
                               const float* t_rand, float* z_out, void* stream)
 {
-    PNR_REQUIRE(rays && z_out, "pnr_stratified: null pointer");
     PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_stratified: bad size R=%lld N=%d", (long long)n_rays, n_samples);
-    if (n_rays == 0) return PNR_OK;
+    if (n_rays == 0) return PNR_OK;     // empty input is a no-op
+    PNR_REQUIRE(rays && z_out, "pnr_stratified: null pointer");
     const int64_t total = n_rays * n_samples;
     hipLaunchKernelGGL(k_stratified, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rays, n_rays, n_samples, lindisp, t_rand, z_out);
@@ -271,9 +271,9 @@ PNR_EXPORT int pnr_stratified(const float* rays, int64_t n_rays, int n_samples, 
 PNR_EXPORT int pnr_points(const float* rays, const float* z, int64_t n_rays, int n_samples, float* pts_out,
                           void* stream)
 {
-    PNR_REQUIRE(rays && z && pts_out, "pnr_points: null pointer");
     PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_points: bad size");
     if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(rays && z && pts_out, "pnr_points: null pointer");
     const int64_t total = n_rays * n_samples * 3;
     hipLaunchKernelGGL(k_points, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rays, z, n_rays, n_samples, pts_out);
@@ -283,9 +283,9 @@ PNR_EXPORT int pnr_points(const float* rays, const float* z, int64_t n_rays, int
 
 PNR_EXPORT int pnr_embed(const float* x, int64_t n, int L, float* out, void* stream)
 {
-    PNR_REQUIRE(x && out, "pnr_embed: null pointer");
     PNR_REQUIRE(n >= 0 && L >= 0 && L <= 16, "pnr_embed: bad size n=%lld L=%d", (long long)n, L);
     if (n == 0) return PNR_OK;
+    PNR_REQUIRE(x && out, "pnr_embed: null pointer");
     const int64_t total = n * (3 + 6 * L);
     hipLaunchKernelGGL(k_embed, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, n, L, out);
@@ -296,7 +296,7 @@ PNR_EXPORT int pnr_embed(const float* x, int64_t n, int L, float* out, void* str
 PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse,
                               int n_fine, float* z_samples, int32_t* inds, float* z_fine, void* stream)
 {
-    PNR_REQUIRE(z && weights, "pnr_sample_pdf: null pointer");
+    PNR_REQUIRE(n_rays <= 0 || (z && weights), "pnr_sample_pdf: null pointer");
     PNR_REQUIRE(n_coarse >= 3 && n_coarse <= PDF_MAXC, "pnr_sample_pdf: n_coarse=%d outside [3,%d]", n_coarse, PDF_MAXC);
     PNR_REQUIRE(n_fine >= 1 && n_coarse + n_fine <= PDF_MAXT, "pnr_sample_pdf: n_coarse+n_fine=%d > %d",
                 n_coarse + n_fine, PDF_MAXT);
@@ -310,7 +310,7 @@ PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float*
 PNR_EXPORT int pnr_bbox_hits(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits,
                              float* hit_t, int32_t* hit_box, int32_t* hit_count, void* stream)
 {
-    PNR_REQUIRE(rays && hit_t && hit_box && hit_count, "pnr_bbox_hits: null pointer");
+    PNR_REQUIRE(n_rays <= 0 || (rays && hit_t && hit_box && hit_count), "pnr_bbox_hits: null pointer");
     PNR_REQUIRE(n_box >= 0 && (n_box == 0 || box), "pnr_bbox_hits: bad box table");
     PNR_REQUIRE(max_hits >= 1 && max_hits <= 64, "pnr_bbox_hits: max_hits=%d outside [1,64]", max_hits);
     if (n_rays <= 0) return PNR_OK;
@@ -324,7 +324,7 @@ PNR_EXPORT int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, 
                                  const int32_t* hit_box, const int32_t* hit_count, int max_hits,
                                  const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream)
 {
-    PNR_REQUIRE(z && hit_t && hit_box && hit_count && box_ids && label_sem && label_inst,
+    PNR_REQUIRE(n_rays <= 0 || (z && hit_t && hit_box && hit_count && box_ids && label_sem && label_inst),
                 "pnr_sample_labels: null pointer");
     PNR_REQUIRE(n_samples >= 1 && max_hits >= 1, "pnr_sample_labels: bad size");
     if (n_rays <= 0) return PNR_OK;
