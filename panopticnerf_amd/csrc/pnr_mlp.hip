@@ -23,7 +23,7 @@
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #ifndef PNR_MLP_DEFAULT_VARIANT
-#define PNR_MLP_DEFAULT_VARIANT 0
+#define PNR_MLP_DEFAULT_VARIANT 3
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -67,10 +67,13 @@ __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x1
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv),
                                                         acc, 0, 0, 0);
     } else {
+        // NB: __builtin_bit_cast(float, a[j]) on an ext-vector ELEMENT miscompiles with ROCm 7.2's
+        // clang (every j reads element 0); copy the element to a scalar first.
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]),
-                                                       __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t av = a[j], bv = b[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av), __uint_as_float(bv), acc, 0, 0, 0);
+        }
         return acc;
     }
 }
@@ -233,7 +236,7 @@ __device__ __forceinline__ void layer_regs(Ctx<WAVES, DB, GDB>& c, const uint32_
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[t][r];
                     if (MODE == MODE_RELU) v = fmaxf(v, 0.0f);
-                    out[t][fb * RPB + r] = __builtin_bit_cast(uint32_t, v);
+                    out[t][fb * RPB + r] = __float_as_uint(v);
                 }
             }
         }
@@ -297,7 +300,7 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
         for (int p = 0; p < NV / 2; ++p) out[p] = pack_bf16(v[2 * p], v[2 * p + 1]);
     } else {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) out[i] = __builtin_bit_cast(uint32_t, v[i]);
+        for (int i = 0; i < NV; ++i) out[i] = __float_as_uint(v[i]);
     }
 }
 

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import c_oracle as co
 from oracle import torch_oracle as to
 from panopticnerf_amd import make_network, make_renderer, synthetic
 
@@ -27,20 +28,50 @@ def psnr(a, b):
     return -10.0 * torch.log10(torch.mean((a - b) ** 2)).item()
 
 
+def _oracle_maps_on_hip_z(params, oc, rays, out, lv, box=None, ids=None, max_hits=8, sem_mode=0, white=False):
+    """Oracle MLP + raw2outputs evaluated on the HIP path's OWN z_vals of level lv (identical stage
+    inputs).  Why not compare two independent end-to-end runs at 1e-4: the L=10 positional encoding
+    multiplies a 1-ulp difference in z (strict i/(N-1) vs torch.linspace, sequential vs vectorised CDF)
+    by 2^9 * |d|, i.e. ~1e-3 in the highest band, so two correct fp32 pipelines differ by ~1e-3 in
+    colour unless they are fed the same z ('hard parts')."""
+    z = out[f"z_vals_{lv}"][0].cpu()
+    prm = params["coarse" if lv == 0 else "fine"]
+    raw = to.run_network(prm, oc, rays, z)
+    ls = li = None
+    if box is not None:
+        hits = co.bbox_hits(rays.numpy(), box.numpy(), max_hits)
+        ls, li = co.sample_labels(z.numpy(), *hits, ids.numpy())
+        ls, li = torch.tensor(ls), torch.tensor(li)
+    return to.raw2outputs(raw, z, rays[:, 3:6], oc.n_sem, oc.n_inst, None, ls, li, sem_mode, white)
+
+
 def test_render_fp32_matches_golden_and_oracle(dev, golden):
     g = golden
     R, Nc, Nf, C, K, M, MH = (int(v) for v in g["dims"])
     cfg, net, oc, params = _setup(dev, C, K, "fp32", max_hits=MH)
     rend = make_renderer(cfg, net)
     rays = torch.tensor(g["rays"][:32])
+    box, ids = torch.tensor(g["box"]), torch.tensor(g["box_ids"])
     with torch.no_grad():
-        out = rend.render({"rays": rays[None].to(dev), "bbox": torch.tensor(g["box"]).to(dev),
-                           "bbox_ids": torch.tensor(g["box_ids"]).to(dev)})
-    tol = {"depth_0": 6e-3, "depth_1": 6e-3, "z_vals_1": 2e-3}
+        out = rend.render({"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)})
+    # (1) golden maps: independent end-to-end run of the torch oracle -> PE-amplified tolerance (see above)
+    tol = {"depth_0": 2e-2, "depth_1": 5e-2, "z_vals_1": 5e-3}
     for k in ("rgb_0", "depth_0", "acc_0", "rgb_1", "depth_1", "acc_1", "semantic_1", "instance_1",
               "fix_semantic_1", "fix_instance_1", "z_vals_1"):
         assert out[k].shape[:2] == (1, 32)
-        np.testing.assert_allclose(out[k][0].cpu().numpy(), g["e2e_" + k], atol=tol.get(k, 1e-4), rtol=0, err_msg=k)
+        np.testing.assert_allclose(out[k][0].cpu().numpy(), g["e2e_" + k], atol=tol.get(k, 1e-2), rtol=0, err_msg=k)
+    # (2) identical stage inputs: 1e-4 on every map of both levels
+    for lv in (0, 1):
+        ref = _oracle_maps_on_hip_z(params, oc, rays, out, lv, box, ids, MH)
+        for k in ("rgb", "acc", "semantic", "instance", "fix_semantic", "fix_instance", "weights"):
+            err = (out[f"{k}_{lv}"][0].cpu() - ref[k]).abs().max().item()
+            assert err < 1e-4, (k, lv, err)
+        assert (out[f"depth_{lv}"][0].cpu() - ref["depth"]).abs().max() < 6e-3        # metres, far = 60
+    # (3) the z the HIP path sampled is the strict-order oracle's z, bit for bit, given the HIP coarse weights
+    z0 = out["z_vals_0"][0].cpu().numpy()
+    assert np.array_equal(z0, co.stratified(rays.numpy(), Nc))
+    zs, _ = co.sample_pdf(z0, out["weights_0"][0].cpu().numpy(), Nf)
+    assert np.array_equal(out["z_vals_1"][0].cpu().numpy(), co.merge_sorted(z0, zs))
 
 
 @pytest.mark.parametrize("perturb", [False, True])
@@ -53,16 +84,26 @@ def test_render_fp32_vs_oracle_with_explicit_uniforms(dev, perturb):
     gen = torch.Generator().manual_seed(3)
     t_rand = torch.rand(257, 64, generator=gen) if perturb else None
     u = torch.rand(257, 128, generator=gen) if perturb else None
-    ref = to.render_rays(params, oc, rays, 64, 128, t_rand=t_rand, u=u, box=box, box_ids=ids, sem_mode=1, white_bkgd=True)
     batch = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
     if perturb:
         batch["t_rand"], batch["u"] = t_rand[None].to(dev), u[None].to(dev)
     with torch.no_grad():
         out = make_renderer(cfg, net).render(batch)
+    # independent end-to-end oracle run: PE-amplified tolerance
+    ref = to.render_rays(params, oc, rays, 64, 128, t_rand=t_rand, u=u, box=box, box_ids=ids, sem_mode=1, white_bkgd=True)
     for k in ("rgb_0", "acc_0", "rgb_1", "acc_1", "semantic_1", "instance_1", "fix_semantic_1", "fix_instance_1"):
         err = (out[k][0].cpu() - ref[k]).abs().max().item()
-        assert err < 1e-4, (k, err)
-    assert (out["depth_1"][0].cpu() - ref["depth_1"]).abs().max() < 1e-2      # metres, far = 100
+        assert err < 2e-2, (k, err)
+    # identical stage inputs: 1e-4
+    for lv in (0, 1):
+        hyb = _oracle_maps_on_hip_z(params, oc, rays, out, lv, box, ids, 8, sem_mode=1, white=True)
+        for k in ("rgb", "acc", "semantic", "instance", "fix_semantic", "fix_instance"):
+            err = (out[f"{k}_{lv}"][0].cpu() - hyb[k]).abs().max().item()
+            assert err < 1e-4, (k, lv, err)
+    z0 = out["z_vals_0"][0].cpu().numpy()
+    assert np.array_equal(z0, co.stratified(rays.numpy(), 64, t_rand=None if t_rand is None else t_rand.numpy()))
+    zs, _ = co.sample_pdf(z0, out["weights_0"][0].cpu().numpy(), 128, None if u is None else u.numpy())
+    assert np.array_equal(out["z_vals_1"][0].cpu().numpy(), co.merge_sorted(z0, zs))
 
 
 def test_render_bf16_psnr_parity(dev):
