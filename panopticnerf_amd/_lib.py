@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnr.so")
+LIB_PATH = os.environ.get("PNR_LIB_PATH") or os.path.join(_HERE, "libpnr.so")   # override: A/B builds only
 
 c_f = ctypes.c_void_p       # device pointers travel as integers
 c_i64 = ctypes.c_int64

@@ -22,8 +22,11 @@
 //
 // Fragment = 1 KiB: lane l = (i = l&31, hi = l>>5) owns bytes [16 l, 16 l + 16): the KPL
 // values W[fb*32 + i][col(hi, ks*KPL + j)], j < KPL, 0 where col is a pad or the row is
-// beyond the layer's outputs.  A chunk = one (layer, 32-row output block): its k-step
-// fragments in order, then ONE bias fragment (32 fp32 biases of the block's rows, rest 0).
+// beyond the layer's outputs.  A chunk = FBC consecutive 32-row output blocks of one layer
+// (pnr_layer_fbc): block 0's k-step fragments in order, block 1's, ..., then ONE bias fragment
+// (FBC x 32 fp32 biases, rest 0).  The kernel runs the FBC blocks of a chunk as FBC interleaved
+// accumulator chains: an instruction issued between two MFMAs on the SAME accumulator costs
+// ~43 cycles on gfx950, between different accumulators ~6 (MI355X_MICROARCH.md cycle table).
 // The image is the chunks in execution order, preceded by a header and a chunk table.
 #pragma once
 #include <stdint.h>
@@ -45,6 +48,21 @@ static inline int pnr_row_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 
 static inline int pnr_kpl(int precision) { return precision == 0 ? 8 : 4; }
 
 enum { PNR_SEG_GX = 0, PNR_SEG_GD = 1, PNR_SEG_FEAT = 2 };
+
+// layer kinds in execution order
+enum { PNR_L_TRUNK0 = 0, PNR_L_TRUNK, PNR_L_SEM0, PNR_L_SEM1, PNR_L_INST0, PNR_L_INST1, PNR_L_FEATURE, PNR_L_VIEWS,
+       PNR_L_RGBSIGMA };
+
+// 32-row output blocks per chunk.  fp32 (parity mode) keeps 1: its fragments are twice as many.
+static constexpr int pnr_layer_fbc(int kind, int precision)
+{
+    if (precision != 0) return 1;
+    switch (kind) {
+    case PNR_L_TRUNK0: return 4;                       // 4 k-steps per block: 4 blocks make a 16-MFMA chunk
+    case PNR_L_TRUNK: case PNR_L_FEATURE: case PNR_L_SEM0: case PNR_L_INST0: case PNR_L_VIEWS: return 2;
+    default: return 1;                                 // output layers: run-time block count
+    }
+}
 
 // canonical column (within the segment's own canonical vector) of lane-vector slot (hi, v); -1 = pad
 static inline int pnr_seg_col(int kind, int L, int hi, int v)

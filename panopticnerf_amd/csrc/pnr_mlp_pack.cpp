@@ -88,6 +88,7 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
         auto weight = [&](int row, int seg, int col) -> float {
             if (row >= L.out_dim || col < 0) return 0.0f;
             switch (L.kind) {
+            case PNR_L_TRUNK0:
             case PNR_L_TRUNK: {
                 const int i = L.index;
                 const float* Wm = p->pts_w[i];
@@ -115,6 +116,7 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
         auto bias = [&](int row) -> float {
             if (row >= L.out_dim) return 0.0f;
             switch (L.kind) {
+            case PNR_L_TRUNK0:
             case PNR_L_TRUNK: return p->pts_b[L.index][row];
             case PNR_L_SEM0: return p->sem0_b[row];
             case PNR_L_SEM1: return p->sem1_b[row];
@@ -126,31 +128,35 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
             }
             return 0.0f;
         };
-        int ks_global = 0;
-        for (int seg = 0; seg < L.nseg; ++seg) {
-            const int kind = L.seg_kind[seg];
-            const int vl = pnr_seg_vl(kind, L.seg_nfeat[seg]);
-            const int Lf = kind == PNR_SEG_GX ? desc->xyz_L : desc->dir_L;
-            for (int ks = 0; ks < vl / kpl; ++ks, ++ks_global) {
-                uint8_t* frag = base + (size_t)ks_global * PNR_FRAG_BYTES;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int i = lane & 31, hi = lane >> 5;
-                    const int row = ch.fb * 32 + i;
-                    for (int j = 0; j < kpl; ++j) {
-                        const int col = pnr_seg_col(kind, Lf, hi, ks * kpl + j);
-                        const float w = weight(row, seg, col);
-                        if (bf16) {
-                            const uint16_t h = f32_to_bf16_rne(w);
-                            memcpy(frag + lane * 16 + j * 2, &h, 2);
-                        } else {
-                            memcpy(frag + lane * 16 + j * 4, &w, 4);
+        int frag_idx = 0;
+        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
+            const int fb = ch.fb + fbl;
+            for (int seg = 0; seg < L.nseg; ++seg) {
+                const int kind = L.seg_kind[seg];
+                const int vl = pnr_seg_vl(kind, L.seg_nfeat[seg]);
+                const int Lf = kind == PNR_SEG_GX ? desc->xyz_L : desc->dir_L;
+                for (int ks = 0; ks < vl / kpl; ++ks, ++frag_idx) {
+                    uint8_t* frag = base + (size_t)frag_idx * PNR_FRAG_BYTES;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, hi = lane >> 5;
+                        const int row = fb * 32 + i;
+                        for (int j = 0; j < kpl; ++j) {
+                            const int col = pnr_seg_col(kind, Lf, hi, ks * kpl + j);
+                            const float w = weight(row, seg, col);
+                            if (bf16) {
+                                const uint16_t h = f32_to_bf16_rne(w);
+                                memcpy(frag + lane * 16 + j * 2, &h, 2);
+                            } else {
+                                memcpy(frag + lane * 16 + j * 4, &w, 4);
+                            }
                         }
                     }
                 }
             }
         }
-        float* bfrag = (float*)(base + (size_t)ks_global * PNR_FRAG_BYTES);
-        for (int r = 0; r < 32; ++r) bfrag[r] = bias(ch.fb * 32 + r);
+        float* bfrag = (float*)(base + (size_t)frag_idx * PNR_FRAG_BYTES);
+        for (int fbl = 0; fbl < ch.nfb; ++fbl)
+            for (int r = 0; r < 32; ++r) bfrag[fbl * 32 + r] = bias((ch.fb + fbl) * 32 + r);
     }
     return PNR_OK;
 }

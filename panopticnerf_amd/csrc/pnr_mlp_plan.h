@@ -10,16 +10,15 @@
 #include "pnr.h"
 #include "pnr_mlp_layout.h"
 
-enum { PNR_L_TRUNK = 0, PNR_L_SEM0, PNR_L_SEM1, PNR_L_INST0, PNR_L_INST1, PNR_L_FEATURE, PNR_L_VIEWS, PNR_L_RGBSIGMA };
-
 struct PnrLayer {
     int kind, index;       // index: trunk layer number
     int out_dim, n_fb;     // output rows, 32-row blocks
     int nseg;
     int seg_kind[2], seg_nfeat[2];
-    int nks;               // k-steps (weight fragments) per chunk
+    int nks;               // k-steps (weight fragments) per 32-row block
+    int fbc;               // blocks per chunk
 };
-struct PnrChunk { int layer, fb, off_frag, nfrag; };
+struct PnrChunk { int layer, fb, nfb, off_frag, nfrag; };   // fb: first block, nfb: blocks in this chunk
 struct PnrPlan {
     std::vector<PnrLayer> layers;
     std::vector<PnrChunk> chunks;
@@ -36,12 +35,14 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         L.nseg = k1 >= 0 ? 2 : 1;
         L.seg_kind[0] = k0; L.seg_nfeat[0] = n0; L.seg_kind[1] = k1; L.seg_nfeat[1] = n1;
         L.nks = pnr_seg_vl(k0, n0) / kpl + (k1 >= 0 ? pnr_seg_vl(k1, n1) / kpl : 0);
+        L.fbc = pnr_layer_fbc(kind, d.precision);
+        if (L.n_fb % L.fbc) L.fbc = 1;
         plan.layers.push_back(L);
     };
     plan.layers.clear();
     plan.chunks.clear();
     for (int i = 0; i < d.D; ++i) {
-        if (i == 0) add(PNR_L_TRUNK, i, d.W, PNR_SEG_GX, 0);
+        if (i == 0) add(PNR_L_TRUNK0, i, d.W, PNR_SEG_GX, 0);
         else if (i - 1 == d.skip) add(PNR_L_TRUNK, i, d.W, PNR_SEG_GX, 0, PNR_SEG_FEAT, d.W);
         else add(PNR_L_TRUNK, i, d.W, PNR_SEG_FEAT, d.W);
     }
@@ -59,9 +60,9 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
     int off = 0, mx = 0;
     for (size_t li = 0; li < plan.layers.size(); ++li) {
         const PnrLayer& L = plan.layers[li];
-        for (int fb = 0; fb < L.n_fb; ++fb) {
+        for (int fb = 0; fb < L.n_fb; fb += L.fbc) {
             PnrChunk c;
-            c.layer = (int)li; c.fb = fb; c.off_frag = off; c.nfrag = L.nks + 1;   // + bias fragment
+            c.layer = (int)li; c.fb = fb; c.nfb = L.fbc; c.off_frag = off; c.nfrag = L.fbc * L.nks + 1;   // + bias fragment
             off += c.nfrag;
             if (c.nfrag > mx) mx = c.nfrag;
             plan.chunks.push_back(c);

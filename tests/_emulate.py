@@ -48,15 +48,16 @@ class PackedImage:
         self.kpl = 8 if self.bf16 else 4
 
     def chunk(self, ci):
+        """-> (A fragments (nfrag-1, 64 lanes, kpl), bias floats (256)) of chunk ci."""
         off, nfrag = int(self.table[ci, 0]), int(self.table[ci, 1])
         raw = self.b[self.data_off + off * 1024: self.data_off + (off + nfrag) * 1024]
-        nks = nfrag - 1
+        nw = nfrag - 1
         if self.bf16:
-            u = np.frombuffer(raw[:nks * 1024], np.uint16).astype(np.uint32) << 16
-            A = u.view(np.float32).reshape(nks, 64, 8)
+            u = np.frombuffer(raw[:nw * 1024], np.uint16).astype(np.uint32) << 16
+            A = u.view(np.float32).reshape(nw, 64, 8)
         else:
-            A = np.frombuffer(raw[:nks * 1024], np.float32).reshape(nks, 64, 4)
-        bias = np.frombuffer(raw[nks * 1024: nks * 1024 + 128], np.float32)
+            A = np.frombuffer(raw[:nw * 1024], np.float32).reshape(nw, 64, 4)
+        bias = np.frombuffer(raw[nw * 1024: nw * 1024 + 1024], np.float32)
         return A, bias
 
 
@@ -72,21 +73,26 @@ def emulate(img_u8, pts, viewdirs):
     def layer(segs, n_out, relu, to_regs=True):
         """segs: list of [V_hi0, V_hi1] each (n, VL).  Returns lane vectors or dense (n, n_out)."""
         nfb = (n_out + 31) // 32
+        nks = sum(V[0].shape[1] // kpl for V in segs)
         dense = np.zeros((n, nfb * 32), np.float32)
-        for fb in range(nfb):
-            A, bias = im.chunk(state["ci"])
+        fb = 0
+        while fb < nfb:
+            A, bias = im.chunk(state["ci"])       # a chunk = fbc consecutive 32-row blocks, then the bias fragment
             state["ci"] += 1
-            Dm = np.tile(bias[None, :32], (n, 1)).astype(np.float32)        # (n, 32 rows)
-            ks = 0
-            for V in segs:
-                for k in range(V[0].shape[1] // kpl):
-                    for hi in (0, 1):
-                        a = A[ks][hi * 32:(hi + 1) * 32]                     # (32 rows i, kpl)
-                        bvals = V[hi][:, k * kpl:(k + 1) * kpl]             # (n, kpl)
-                        Dm += bvals @ a.T
-                    ks += 1
-            assert ks == A.shape[0], (ks, A.shape)
-            dense[:, fb * 32:(fb + 1) * 32] = Dm
+            assert A.shape[0] % nks == 0, (A.shape, nks)
+            fbc = A.shape[0] // nks
+            for b in range(fbc):
+                Dm = np.tile(bias[None, b * 32:(b + 1) * 32], (n, 1)).astype(np.float32)        # (n, 32 rows)
+                ks = b * nks
+                for V in segs:
+                    for k in range(V[0].shape[1] // kpl):
+                        for hi in (0, 1):
+                            a = A[ks][hi * 32:(hi + 1) * 32]                     # (32 rows i, kpl)
+                            bvals = V[hi][:, k * kpl:(k + 1) * kpl]             # (n, kpl)
+                            Dm += bvals @ a.T
+                        ks += 1
+                dense[:, (fb + b) * 32:(fb + b + 1) * 32] = Dm
+            fb += fbc
         if relu:
             dense = np.maximum(dense, 0.0)
         if not to_regs:
