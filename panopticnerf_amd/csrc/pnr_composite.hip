@@ -4,13 +4,19 @@
 // include/pnr.h).  HBM-bound: every (sigma, rgb, logit) value is read exactly once.
 //
 // Mapping (wave64): a ray of N samples (N % 4 == 0, N <= 256) is owned by a group of
-// SUB = pow2ceil(N/4) consecutive lanes, each lane holding 4 consecutive samples, so with
-// the channel-major raw image written by the MLP kernel every channel row of a ray group is
-// one 16 B-per-lane coalesced load (N=64: 4 rays per wave, 1 KiB per wave-load; N=192: one
-// ray per wave, 768 B).  T(t) is a segmented (width SUB) wave-level inclusive product scan of
-// the per-lane products of (1 - alpha + 1e-10); per-channel sums are width-SUB butterflies.
-// Nothing is re-read, so the samples are staged in registers, not LDS: there is no reuse for
-// LDS to serve (cdna_hip_programming.md common mistake 7).
+// SUB = pow2ceil(N/4) consecutive lanes (compile-time), each lane holding 4 consecutive samples,
+// so with the channel-major raw image written by the MLP kernel every channel row of a ray group
+// is one 16 B-per-lane coalesced load (N=64: 4 rays per wave, 1 KiB per wave-load; N=192: one ray
+// per wave, 768 B).
+//   * T(t): segmented (width SUB) wave-level inclusive product scan of the per-lane products of
+//     (1 - alpha + 1e-10) -- the "wavefront-level prefix sum" of BASELINE.json's north_star.
+//   * channel sums: 8 channel rows per batch; the NEXT batch's 8 loads are issued before the
+//     current batch is reduced, so >= 6 KiB per wave stays in flight through the butterflies.
+//   * fixed (bbox-prior) fields: a per-ray histogram of the sample labels in LDS, accumulated
+//     in 2^-30 fixed point with integer ds_add (associative => bit-reproducible whatever the
+//     order), instead of one compare-select reduction per class.
+// Nothing is re-read, so samples are staged in registers, not LDS: there is no reuse for LDS
+// to serve (cdna_hip_programming.md common mistake 7).
 #include "pnr_common.h"
 
 struct CompositeArgs {
@@ -19,9 +25,12 @@ struct CompositeArgs {
     const int32_t* label_sem; const int32_t* label_inst;
     int64_t R; int N, C, K, sem_mode, white_bkgd;
     float *rgb, *depth, *acc, *weights, *sem, *inst, *fix_sem, *fix_inst;
+    int use_hist;       // 1: LDS histogram for the fixed fields (fits in LDS), 0: reduction fallback
 };
 
 struct f4 { float v[4]; };
+#define CMP_UB 8        // channel rows per batch
+#define CMP_FIX_SCALE 1073741824.0f   // 2^30
 
 template <bool CH_MAJOR>
 __device__ __forceinline__ f4 load4(const float* __restrict__ raw, int64_t ss, int64_t sc, int64_t s0, int c, bool active)
@@ -39,10 +48,41 @@ __device__ __forceinline__ f4 load4(const float* __restrict__ raw, int64_t ss, i
     return o;
 }
 
-__device__ __forceinline__ float group_sum(float x, int SUB)
+// x + x[lane ^ D] without touching LDS where DPP can do it: quad_perm for D = 1, 2; row_half_mirror /
+// row_mirror for D = 4, 8 (a lane is paired with a lane of the OTHER half of its 8 / 16 group, which is all
+// a sum butterfly needs); ds_swizzle for D = 16; ds_bpermute (via __shfl_xor) only for D = 32.
+template <int D>
+__device__ __forceinline__ float xor_add(float x)
 {
-    for (int d = SUB >> 1; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+    const int xi = __float_as_int(x);
+    int yi;
+    if constexpr (D == 1) yi = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true);
+    else if constexpr (D == 2) yi = __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xF, 0xF, true);
+    else if constexpr (D == 4) yi = __builtin_amdgcn_mov_dpp(xi, 0x141, 0xF, 0xF, true);
+    else if constexpr (D == 8) yi = __builtin_amdgcn_mov_dpp(xi, 0x140, 0xF, 0xF, true);
+    else if constexpr (D == 16) yi = __builtin_amdgcn_ds_swizzle(xi, 0x401F);
+    else yi = __shfl_xor(xi, 32, 64);
+    return x + __int_as_float(yi);
+}
+
+template <int SUB>
+__device__ __forceinline__ float group_sum(float x)
+{
+    if constexpr (SUB > 1) x = xor_add<1>(x);
+    if constexpr (SUB > 2) x = xor_add<2>(x);
+    if constexpr (SUB > 4) x = xor_add<4>(x);
+    if constexpr (SUB > 8) x = xor_add<8>(x);
+    if constexpr (SUB > 16) x = xor_add<16>(x);
+    if constexpr (SUB > 32) x = xor_add<32>(x);
     return x;
+}
+
+template <int SUB, int NB>
+__device__ __forceinline__ void group_sum_batch(float (&r)[NB])
+{
+#define PNR_STEP(D) if constexpr (SUB > D) { _Pragma("unroll") for (int j = 0; j < NB; ++j) r[j] = xor_add<D>(r[j]); }
+    PNR_STEP(1) PNR_STEP(2) PNR_STEP(4) PNR_STEP(8) PNR_STEP(16) PNR_STEP(32)
+#undef PNR_STEP
 }
 
 __device__ __forceinline__ float dot4(const f4& w, const f4& v)
@@ -50,26 +90,28 @@ __device__ __forceinline__ float dot4(const f4& w, const f4& v)
     return fmaf(w.v[3], v.v[3], fmaf(w.v[2], v.v[2], fmaf(w.v[1], v.v[1], w.v[0] * v.v[0])));
 }
 
-template <bool CH_MAJOR>
+template <bool CH_MAJOR, int SUB, bool SOFTMAX>
 __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int N = a.N, nq = N >> 2;
-    int SUB = 1;
-    while (SUB < nq) SUB <<= 1;
-    const int rpw = 64 / SUB;            // rays per wave
-    const int q = lane & (SUB - 1);      // lane's position in its ray group
-    const int g = lane / SUB;            // which ray of the wave
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];   // [4 waves][RPW][C+K] when use_hist
+    constexpr int RPW = 64 / SUB;          // rays per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.N, nq4 = N >> 2;
+    const int q = lane & (SUB - 1);        // lane's position in its ray group
+    const int g = lane / SUB;              // which ray of the wave
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_groups = (a.R + rpw - 1) / rpw;
-    const int CH_SEM = 4, CH_INST = 4 + a.C;
+    const int64_t n_groups = (a.R + RPW - 1) / RPW;
+    const int CK = a.C + a.K;
+    const int nq = 3 + CK;                 // composited raw channels: rgb, semantic, instance (sigma excluded)
+    uint32_t* hist = s_hist + ((size_t)wave * RPW + g) * CK;
 
     for (int64_t grp = wave_global; grp < n_groups; grp += n_waves) {
-        const int64_t ray = grp * rpw + g;
-        const bool active = (ray < a.R) && (q < nq);
+        const int64_t ray = grp * RPW + g;
+        const bool active = (ray < a.R) && (q < nq4);
         const int64_t rayc = ray < a.R ? ray : a.R - 1;
         const int64_t s0 = rayc * N + (active ? 4 * q : 0);
+        const bool writer = active && q == 0;
 
         // ---- phase 1: weights
         f4 zz, sg;
@@ -80,6 +122,10 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
             zz.v[0] = zz.v[1] = zz.v[2] = zz.v[3] = 0.0f;
         }
         sg = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, 3, active);
+        // first batch of channel rows: in flight while the weights are computed
+        f4 nxt[CMP_UB];
+#pragma unroll
+        for (int j = 0; j < CMP_UB; ++j) nxt[j] = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, j < 3 ? j : j + 1, active && j < nq);
         if (a.noise && active) {
             const float4 t = *reinterpret_cast<const float4*>(a.noise + s0);
             sg.v[0] += t.x; sg.v[1] += t.y; sg.v[2] += t.z; sg.v[3] += t.w;
@@ -87,7 +133,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
         const float dx = a.rays[rayc * 8 + 3], dy = a.rays[rayc * 8 + 4], dz = a.rays[rayc * 8 + 5];
         const float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float znext = __shfl_down(zz.v[0], 1, 64);   // first sample of the next lane
-        f4 w, tt;
+        f4 w;
         float P = 1.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -98,12 +144,12 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
             const float s = fmaxf(sg.v[k], 0.0f);
             const float alpha = 1.0f - expf(-(s * dist));
             w.v[k] = alpha * P;            // alpha * (product of this lane's earlier factors)
-            tt.v[k] = (1.0f - alpha) + 1e-10f;
-            P *= tt.v[k];
+            P *= (1.0f - alpha) + 1e-10f;
         }
         if (!active) P = 1.0f;
         // segmented inclusive product scan over the SUB lanes of the ray
         float x = P;
+#pragma unroll
         for (int d = 1; d < SUB; d <<= 1) {
             const float y = __shfl_up(x, d, 64);
             if (q >= d) x *= y;
@@ -115,35 +161,50 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
         if (a.weights && active) {
             *reinterpret_cast<float4*>(a.weights + s0) = make_float4(w.v[0], w.v[1], w.v[2], w.v[3]);
         }
-
-        // ---- phase 2: per-channel weighted sums
-        const float accv = group_sum((w.v[0] + w.v[1]) + (w.v[2] + w.v[3]), SUB);
-        const float depv = group_sum(dot4(w, zz), SUB);
-        float rgbv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            f4 v = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, c, active);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v.v[k] = 1.0f / (1.0f + expf(-v.v[k]));
-            rgbv[c] = group_sum(dot4(w, v), SUB);
-            if (a.white_bkgd) rgbv[c] += 1.0f - accv;
-        }
-        const bool writer = active && q == 0;
+        const float accv = group_sum<SUB>((w.v[0] + w.v[1]) + (w.v[2] + w.v[3]));
+        const float depv = group_sum<SUB>(dot4(w, zz));
         if (writer) {
-            if (a.rgb) { a.rgb[ray * 3 + 0] = rgbv[0]; a.rgb[ray * 3 + 1] = rgbv[1]; a.rgb[ray * 3 + 2] = rgbv[2]; }
             if (a.depth) a.depth[ray] = depv;
             if (a.acc) a.acc[ray] = accv;
         }
 
-        // learned fields: two passes (semantic, instance) over their channel ranges
-#pragma unroll 1
-        for (int field = 0; field < 2; ++field) {
-            const int nch = field == 0 ? a.C : a.K;
-            const int ch0 = field == 0 ? CH_SEM : CH_INST;
-            float* outp = field == 0 ? a.sem : a.inst;
-            if (nch == 0 || outp == nullptr) continue;
-            f4 mx, den;
-            if (a.sem_mode == 1) {   // softmax over the field's channels, per sample (online max/sum)
+        // ---- fixed (bbox-prior) fields
+        const bool want_fs = a.fix_sem && a.label_sem && a.C, want_fi = a.fix_inst && a.label_inst && a.K;
+        if (want_fs || want_fi) {
+            int ls[4] = {-1, -1, -1, -1}, li[4] = {-1, -1, -1, -1};
+            if (active && want_fs) { const int4 t = *reinterpret_cast<const int4*>(a.label_sem + s0); ls[0] = t.x; ls[1] = t.y; ls[2] = t.z; ls[3] = t.w; }
+            if (active && want_fi) { const int4 t = *reinterpret_cast<const int4*>(a.label_inst + s0); li[0] = t.x; li[1] = t.y; li[2] = t.z; li[3] = t.w; }
+            if (a.use_hist) {
+                // LDS ops of one wave execute in order and only this wave touches its histograms: no barrier
+                for (int c = q; c < CK; c += SUB) hist[c] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t fx = (uint32_t)(w.v[k] * CMP_FIX_SCALE + 0.5f);
+                    if (want_fs && ls[k] >= 0 && ls[k] < a.C) atomicAdd(&hist[ls[k]], fx);
+                    if (want_fi && li[k] >= 0 && li[k] < a.K) atomicAdd(&hist[a.C + li[k]], fx);
+                }
+                if (ray < a.R) {
+                    if (want_fs) for (int c = q; c < a.C; c += SUB) a.fix_sem[ray * a.C + c] = (float)hist[c] * (1.0f / CMP_FIX_SCALE);
+                    if (want_fi) for (int c = q; c < a.K; c += SUB) a.fix_inst[ray * a.K + c] = (float)hist[a.C + c] * (1.0f / CMP_FIX_SCALE);
+                }
+            } else {
+                for (int c = 0; c < CK; ++c) {
+                    const bool is_s = c < a.C;
+                    if ((is_s && !want_fs) || (!is_s && !want_fi)) continue;
+                    const int cc = is_s ? c : c - a.C;
+                    float p = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) p += ((is_s ? ls[k] : li[k]) == cc) ? w.v[k] : 0.0f;
+                    const float r = group_sum<SUB>(p);
+                    if (writer) (is_s ? a.fix_sem : a.fix_inst)[ray * (is_s ? a.C : a.K) + cc] = r;
+                }
+            }
+        }
+
+        // ---- softmax mode: per-sample max / denominator of each learned field (extra pass over its rows)
+        f4 mx_s, den_s, mx_i, den_i;
+        if constexpr (SOFTMAX) {
+            auto field_stats = [&](int nch, int ch0, f4& mx, f4& den) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { mx.v[k] = -INFINITY; den.v[k] = 0.0f; }
                 for (int c = 0; c < nch; ++c) {
@@ -155,58 +216,61 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
                         mx.v[k] = m2;
                     }
                 }
-            }
-            int c = 0;
-            // 4 channel rows in flight per lane (>= 3 KiB per wave outstanding)
-            for (; c + 4 <= nch; c += 4) {
-                f4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, ch0 + c + j, active);
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (a.sem_mode == 1) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[j].v[k] = expf(v[j].v[k] - mx.v[k]) / den.v[k];
-                    }
-                    r[j] = group_sum(dot4(w, v[j]), SUB);
-                }
-                if (writer) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) outp[ray * nch + c + j] = r[j];
-                }
-            }
-            for (; c < nch; ++c) {
-                f4 v = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, ch0 + c, active);
-                if (a.sem_mode == 1) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v.v[k] = expf(v.v[k] - mx.v[k]) / den.v[k];
-                }
-                const float r = group_sum(dot4(w, v), SUB);
-                if (writer) outp[ray * nch + c] = r;
-            }
+            };
+            field_stats(a.C, 4, mx_s, den_s);
+            field_stats(a.K, 4 + a.C, mx_i, den_i);
         }
 
-        // fixed (bbox-prior) fields: weighted histogram of the per-sample labels
+        // ---- phase 2: all composited channels, CMP_UB rows per batch.  Each row's weighted partial sum is
+        // taken as soon as the row is used and its register is immediately re-armed with the row of the NEXT
+        // batch, so 8 loads (6-8 KiB per wave) are in flight through the butterflies below.
 #pragma unroll 1
-        for (int field = 0; field < 2; ++field) {
-            const int nch = field == 0 ? a.C : a.K;
-            const int32_t* lab = field == 0 ? a.label_sem : a.label_inst;
-            float* outp = field == 0 ? a.fix_sem : a.fix_inst;
-            if (nch == 0 || outp == nullptr || lab == nullptr) continue;
-            int l[4] = {-1, -1, -1, -1};
-            if (active) {
-                const int4 t = *reinterpret_cast<const int4*>(lab + s0);
-                l[0] = t.x; l[1] = t.y; l[2] = t.z; l[3] = t.w;
-            }
-            for (int c = 0; c < nch; ++c) {
-                float p = 0.0f;
+        for (int q0 = 0; q0 < nq; q0 += CMP_UB) {
+            float r[CMP_UB];
+            const bool more = q0 + CMP_UB < nq;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p += (l[k] == c) ? w.v[k] : 0.0f;
-                const float r = group_sum(p, SUB);
-                if (writer) outp[ray * nch + c] = r;
+            for (int j = 0; j < CMP_UB; ++j) {
+                const int qq = q0 + j;
+                f4 v = nxt[j];
+                if (qq < 3) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v.v[k] = 1.0f / (1.0f + expf(-v.v[k]));
+                } else if constexpr (SOFTMAX) {
+                    const bool fs = (qq - 3) < a.C;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v.v[k] = expf(v.v[k] - (fs ? mx_s.v[k] : mx_i.v[k])) / (fs ? den_s.v[k] : den_i.v[k]);
+                }
+                r[j] = dot4(w, v);
+                const int q2 = qq + CMP_UB;               // >= 8 > 3: never an rgb row -> raw channel q2 + 1
+                if (more) nxt[j] = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, q2 + 1, active && q2 < nq);
+            }
+            group_sum_batch<SUB, CMP_UB>(r);
+            if (writer) {
+#pragma unroll
+                for (int j = 0; j < CMP_UB; ++j) {
+                    const int qq = q0 + j;
+                    if (qq >= nq) continue;
+                    if (qq < 3) { if (a.rgb) a.rgb[ray * 3 + qq] = a.white_bkgd ? r[j] + (1.0f - accv) : r[j]; }
+                    else if (qq - 3 < a.C) { if (a.sem) a.sem[ray * a.C + (qq - 3)] = r[j]; }
+                    else { if (a.inst) a.inst[ray * a.K + (qq - 3 - a.C)] = r[j]; }
+                }
             }
         }
+    }
+}
+
+template <bool CH_MAJOR, bool SOFTMAX>
+static void launch_composite(int sub, int grid, size_t lds, hipStream_t st, const CompositeArgs& a)
+{
+    switch (sub) {
+    case 1: hipLaunchKernelGGL((k_composite<CH_MAJOR, 1, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_composite<CH_MAJOR, 2, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_composite<CH_MAJOR, 4, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((k_composite<CH_MAJOR, 8, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    case 16: hipLaunchKernelGGL((k_composite<CH_MAJOR, 16, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    case 32: hipLaunchKernelGGL((k_composite<CH_MAJOR, 32, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_composite<CH_MAJOR, 64, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
     }
 }
 
@@ -233,13 +297,16 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
     int sub = 1;
     while (sub < n_samples / 4) sub <<= 1;
     const int rpw = 64 / sub;
+    const size_t hist_bytes = (size_t)4 * rpw * (n_sem + n_inst) * sizeof(uint32_t);
+    const bool want_fix = (fix_sem && label_sem && n_sem) || (fix_inst && label_inst && n_inst);
+    a.use_hist = (want_fix && hist_bytes <= 48 * 1024) ? 1 : 0;
+    const size_t lds = a.use_hist ? hist_bytes : 0;
     const int64_t n_groups = (n_rays + rpw - 1) / rpw;
     const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
     const bool ch_major = raw_stride_s == 1 && (raw_stride_c % 4) == 0 && (((uintptr_t)raw) & 15) == 0;
-    if (ch_major)
-        hipLaunchKernelGGL(k_composite<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(k_composite<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (ch_major) { if (sem_mode) launch_composite<true, true>(sub, grid, lds, st, a); else launch_composite<true, false>(sub, grid, lds, st, a); }
+    else { if (sem_mode) launch_composite<false, true>(sub, grid, lds, st, a); else launch_composite<false, false>(sub, grid, lds, st, a); }
     PNR_CHECK_LAUNCH("pnr_composite");
     return PNR_OK;
 }
