@@ -46,6 +46,19 @@ def mlp_flops_per_sample(D=8, W=256, ex=63, ed=27, n_sem=N_SEM, n_inst=N_INST):
     return 2 * mac
 
 
+def traffic(kernel, n_rays_launch):
+    """HBM bytes per launch of `kernel` from the last committed rocprofv3 PMC passes of this same bench
+    command (profiles/latest_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed
+    process, so this is the recorded value for the 65,536-ray fine-level launch, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            t = json.load(f)[kernel]
+        return int(t["hbm_bytes_per_launch"]) if n_rays_launch == 65536 else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,8 +137,8 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
             roofline = {"kernel": "k_mlp_fused (fine level, %d rays x %d samples)" % (rc.shape[0], N_C + N_F),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4),
-                        "flop_per_launch": flops}
+                        "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", rc.shape[0]),
+                        "ms_per_launch": round(ms, 4), "flop_per_launch": flops}
             # secondary: compositing scan (HBM-bound), algorithmic bytes per SURVEY.md 8d
             lab = torch.zeros((rc.shape[0], N_C + N_F), device=dev, dtype=torch.int32)
             for _ in range(2):
@@ -143,7 +156,7 @@ def main():
             gbs = rc.shape[0] * bytes_ray / (cms * 1e-3) / 1e9
             extra["roofline_composite"] = {"kernel": "k_composite<channel-major>", "bound": "hbm",
                                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k_composite", rc.shape[0]),
                                            "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray}
 
     cpu_baseline = None

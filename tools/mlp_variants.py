@@ -39,4 +39,7 @@ for spec in (sys.argv[1:] or ["default:3"]):
     env = dict(os.environ, PNR_MLP_VARIANT=v or "3")
     if lib != "default":
         env["PNR_LIB_PATH"] = os.path.join(ROOT, "build", "ab", "libpnr_%s.so" % lib)
-    subprocess.run([sys.executable, "-c", CHILD, spec], env=env, check=False)
+    try:
+        subprocess.run([sys.executable, "-c", CHILD, spec], env=env, check=False, timeout=90)
+    except subprocess.TimeoutExpired:
+        print("%-14s TIMEOUT (hang?)" % spec, flush=True)
