@@ -14,6 +14,7 @@
  *   pnr_embed           Embedder / get_embedder                           (8a row a4)
  *   pnr_mlp_*           Network (NeRF 8x256 MLP + semantic/instance heads) (8a row a5)
  *   pnr_composite       raw2outputs (+ panoptic logit / fixed-field maps) (8a row a6)
+ *   pnr_composite_backward   autograd backward of raw2outputs            (8a row a9)
  *   pnr_sample_pdf      sample_pdf + sorted merge with the coarse z       (8a row a7)
  *   pnr_bbox_hits       ray / 3D-bbox intersection (bbox prior)           (8a row a8)
  *   pnr_sample_labels   per-sample fixed semantic / instance labels        (8a row a8)
@@ -108,6 +109,16 @@ int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw_stride_c, 
                   const int32_t* label_inst, int64_t n_rays, int n_samples, int n_sem, int n_inst,
                   int sem_mode, int white_bkgd, float* rgb, float* depth, float* acc, float* weights,
                   float* sem, float* inst, float* fix_sem, float* fix_inst, void* stream);
+
+/* ---- a9 (backward of a6): gradient of the composited maps w.r.t. raw.  Channel-major images only
+ * (raw_stride_s == 1).  g_* are the upstream gradients of the forward outputs of the same name
+ * (any may be NULL = zero); g_weights (R,N) is the gradient of the weights output.  d_raw has raw's
+ * shape and layout.  sem_mode 0 (logit compositing) only; no gradient flows into z (sample_pdf's
+ * output is detached in the reference). */
+int pnr_composite_backward(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                           const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                           const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                           const float* g_inst, const float* g_weights, float* d_raw, void* stream);
 
 /* ---- a7: sample_pdf + merge.  z (R,Nc), weights (R,Nc) coarse; u (R,Nf) or NULL (det).
  * z_samples (R,Nf) and inds (R,Nf) int32 may be NULL; z_fine (R,Nc+Nf) sorted union or NULL.

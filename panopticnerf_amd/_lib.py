@@ -48,6 +48,8 @@ SIGNATURES = {
     "pnr_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_f]),
     "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
+                                       c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),

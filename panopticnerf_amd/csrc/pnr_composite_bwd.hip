@@ -1,0 +1,185 @@
+// K4-bwd: backward of raw2outputs (the reverse scan).  HBM-bound: reads raw
+// once, writes d_raw once.  Same lane mapping as the forward kernel (pnr_composite.hip): a ray is
+// owned by SUB = pow2ceil(N/4) lanes, 4 consecutive samples per lane; channel-major images.
+//
+//   w_i = alpha_i T_i,  T_i = prod_{j<i} (1 - alpha_j + 1e-10),  alpha_i = 1 - exp(-relu(sigma_i) delta_i)
+//   out_c = sum_i w_i v_ci        (v = sigmoid(raw) for rgb, raw for the logit fields, z for depth, 1 for acc)
+//   G_i   = dL/dw_i = sum_c g_c v_ci + g_depth z_i + g_acc + g_w_i
+//   dL/dv_ci = w_i g_c
+//   dL/dsigma_i = [sigma_i > 0] delta_i (1 - alpha_i) ( G_i T_i - S_i / (1 - alpha_i + 1e-10) ),
+//                 S_i = sum_{k>i} G_k w_k      (segmented reverse scan over the ray)
+// sample_pdf's output is detached in the reference, so no gradient flows into z.
+// Fixed (bbox-prior) fields have no learnable input.  Softmax-composited fields (sem_mode 1) are
+// not differentiated here (forward-only option); the caller is told so.
+#include "pnr_common.h"
+
+struct CompositeBwdArgs {
+    const float* raw; int64_t sc;          // channel-major: element (s, c) at raw[c*sc + s]
+    const float* z; const float* rays; const float* noise;
+    int64_t R; int N, C, K;
+    const float *g_rgb, *g_depth, *g_acc, *g_sem, *g_inst, *g_w;   // upstream grads (any may be null)
+    float* d_raw;                          // (4+C+K, R*N) channel-major
+};
+
+struct f4 { float v[4]; };
+
+__device__ __forceinline__ f4 ld4(const float* p, bool active)
+{
+    f4 o;
+    if (!active) { o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.0f; return o; }
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+    return o;
+}
+__device__ __forceinline__ void st4(float* p, const f4& v, bool active)
+{
+    if (active) *reinterpret_cast<float4*>(p) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+}
+
+template <int SUB>
+__global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
+{
+    constexpr int RPW = 64 / SUB;
+    const int lane = threadIdx.x & 63;
+    const int N = a.N, nq4 = N >> 2;
+    const int q = lane & (SUB - 1), g = lane / SUB;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_groups = (a.R + RPW - 1) / RPW;
+
+    for (int64_t grp = wave_global; grp < n_groups; grp += n_waves) {
+        const int64_t ray = grp * RPW + g;
+        const bool active = (ray < a.R) && (q < nq4);
+        const int64_t rayc = ray < a.R ? ray : a.R - 1;
+        const int64_t s0 = rayc * N + (active ? 4 * q : 0);
+
+        // ---- recompute alpha, T, w (as the forward kernel does)
+        const f4 zz = ld4(a.z + s0, active);
+        f4 sg = ld4(a.raw + 3 * a.sc + s0, active);
+        if (a.noise) { const f4 nz = ld4(a.noise + s0, active); for (int k = 0; k < 4; ++k) sg.v[k] += nz.v[k]; }
+        const float dx = a.rays[rayc * 8 + 3], dy = a.rays[rayc * 8 + 4], dz = a.rays[rayc * 8 + 5];
+        const float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float znext = __shfl_down(zz.v[0], 1, 64);
+        f4 alpha, dist, Tl;            // Tl: product of this lane's earlier factors
+        float P = 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * q + k;
+            const float zn = (k < 3) ? zz.v[k + 1] : znext;
+            float d = (i + 1 < N) ? (zn - zz.v[k]) : 1e10f;
+            d *= dn;
+            dist.v[k] = d;
+            alpha.v[k] = 1.0f - expf(-(fmaxf(sg.v[k], 0.0f) * d));
+            Tl.v[k] = P;
+            P *= (1.0f - alpha.v[k]) + 1e-10f;
+        }
+        if (!active) P = 1.0f;
+        float x = P;
+#pragma unroll
+        for (int d = 1; d < SUB; d <<= 1) {
+            const float y = __shfl_up(x, d, 64);
+            if (q >= d) x *= y;
+        }
+        float excl = __shfl_up(x, 1, 64);
+        if (q == 0) excl = 1.0f;
+        f4 T, w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { T.v[k] = Tl.v[k] * excl; w.v[k] = active ? alpha.v[k] * T.v[k] : 0.0f; }
+
+        // ---- G_i and the per-channel value gradients (one pass over the channel rows)
+        f4 G;
+        {
+            const float gd = a.g_depth ? a.g_depth[rayc] : 0.0f, ga = a.g_acc ? a.g_acc[rayc] : 0.0f;
+            const f4 gw = a.g_w ? ld4(a.g_w + s0, active) : f4{{0, 0, 0, 0}};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) G.v[k] = fmaf(gd, zz.v[k], ga) + gw.v[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float gc = a.g_rgb ? a.g_rgb[rayc * 3 + c] : 0.0f;
+            const f4 r = ld4(a.raw + (int64_t)c * a.sc + s0, active);
+            f4 dr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = 1.0f / (1.0f + expf(-r.v[k]));
+                G.v[k] = fmaf(gc, v, G.v[k]);
+                dr.v[k] = w.v[k] * gc * v * (1.0f - v);
+            }
+            st4(a.d_raw + (int64_t)c * a.sc + s0, dr, active);
+        }
+        const int CK = a.C + a.K;
+#pragma unroll 4
+        for (int c = 0; c < CK; ++c) {
+            const bool is_s = c < a.C;
+            const float* gp = is_s ? a.g_sem : a.g_inst;
+            const float gc = gp ? gp[rayc * (is_s ? a.C : a.K) + (is_s ? c : c - a.C)] : 0.0f;
+            const f4 r = ld4(a.raw + (int64_t)(4 + c) * a.sc + s0, active);
+            f4 dr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { G.v[k] = fmaf(gc, r.v[k], G.v[k]); dr.v[k] = w.v[k] * gc; }
+            st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
+        }
+
+        // ---- S_i = sum_{k>i} G_k w_k : lane-local suffix, then a segmented reverse (suffix) scan over lanes
+        f4 gwk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gwk.v[k] = active ? G.v[k] * w.v[k] : 0.0f;
+        const float lane_tot = (gwk.v[0] + gwk.v[1]) + (gwk.v[2] + gwk.v[3]);
+        float y = lane_tot;                 // inclusive suffix sum over lanes q..SUB-1 of the group
+#pragma unroll
+        for (int d = 1; d < SUB; d <<= 1) {
+            const float t = __shfl_down(y, d, 64);
+            if (q + d < SUB) y += t;
+        }
+        float after = __shfl_down(y, 1, 64);     // sum over the lanes after this one
+        if (q == SUB - 1) after = 0.0f;
+        f4 S;
+        S.v[3] = after;
+        S.v[2] = S.v[3] + gwk.v[3];
+        S.v[1] = S.v[2] + gwk.v[2];
+        S.v[0] = S.v[1] + gwk.v[1];
+        f4 ds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float om = 1.0f - alpha.v[k];
+            const float dalpha = G.v[k] * T.v[k] - S.v[k] / (om + 1e-10f);
+            ds.v[k] = (sg.v[k] > 0.0f) ? dist.v[k] * om * dalpha : 0.0f;
+        }
+        st4(a.d_raw + 3 * a.sc + s0, ds, active);
+    }
+}
+
+PNR_EXPORT int pnr_composite_backward(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                      const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                                      const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                      const float* g_inst, const float* g_weights, float* d_raw, void* stream)
+{
+    PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0,
+                "pnr_composite_backward: n_samples=%d must be a multiple of 4 in [4,256]", n_samples);
+    if (n_rays <= 0) return PNR_OK;
+    PNR_REQUIRE(raw && z && rays && d_raw, "pnr_composite_backward: null pointer");
+    PNR_REQUIRE((raw_stride_c % 4) == 0 && (((uintptr_t)raw | (uintptr_t)d_raw | (uintptr_t)z | (uintptr_t)noise |
+                                            (uintptr_t)g_weights) & 15) == 0,
+                "pnr_composite_backward: channel-major, 16-byte aligned images required");
+    CompositeBwdArgs a;
+    a.raw = raw; a.sc = raw_stride_c; a.z = z; a.rays = rays; a.noise = noise; a.R = n_rays; a.N = n_samples;
+    a.C = n_sem; a.K = n_inst; a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_sem = g_sem; a.g_inst = g_inst;
+    a.g_w = g_weights; a.d_raw = d_raw;
+    int sub = 1;
+    while (sub < n_samples / 4) sub <<= 1;
+    const int rpw = 64 / sub;
+    const int64_t n_groups = (n_rays + rpw - 1) / rpw;
+    const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
+    hipStream_t st = (hipStream_t)stream;
+    switch (sub) {
+    case 1: hipLaunchKernelGGL(k_composite_bwd<1>, dim3(grid), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_composite_bwd<2>, dim3(grid), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_composite_bwd<4>, dim3(grid), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_composite_bwd<8>, dim3(grid), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(k_composite_bwd<16>, dim3(grid), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(k_composite_bwd<32>, dim3(grid), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_composite_bwd<64>, dim3(grid), dim3(256), 0, st, a); break;
+    }
+    PNR_CHECK_LAUNCH("pnr_composite_backward");
+    return PNR_OK;
+}

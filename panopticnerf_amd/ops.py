@@ -182,6 +182,21 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
     return out
 
 
+def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None):
+    """Backward of composite() for channel-major raw.  grads: dict with any of rgb, depth, acc, semantic,
+    instance, weights (upstream gradients, contiguous fp32).  Returns d_raw (ch, R*N).  SURVEY 8a row a9."""
+    raw, z, rays = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays")
+    noise = _chk(noise, "noise")
+    R, N = z.shape
+    g = {k: _chk(v.contiguous().float(), "g_" + k) for k, v in grads.items() if v is not None}
+    d_raw = torch.empty_like(raw)
+    _lib.check(_lib.load().pnr_composite_backward(_p(raw), R * N, _p(z), _p(rays), _p(noise), R, N, n_sem, n_inst,
+                                                  _p(g.get("rgb")), _p(g.get("depth")), _p(g.get("acc")),
+                                                  _p(g.get("semantic")), _p(g.get("instance")), _p(g.get("weights")),
+                                                  _p(d_raw), _stream()), "pnr_composite_backward")
+    return d_raw
+
+
 def sample_pdf(z, weights, n_importance, u=None, want_samples=True):
     """Coarse z, weights (R,Nc) -> z_fine (R,Nc+Nf) sorted [, z_samples (R,Nf), inds (R,Nf)].
     SURVEY 8a row a7."""
