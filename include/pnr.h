@@ -13,6 +13,7 @@
  *   pnr_points          pts = o + d*z                                     (8a row a3)
  *   pnr_embed           Embedder / get_embedder                           (8a row a4)
  *   pnr_mlp_*           Network (NeRF 8x256 MLP + semantic/instance heads) (8a row a5)
+ *   pnr_mlp_forward_train / pnr_mlp_backward   autograd of the Network   (8a row a9)
  *   pnr_composite       raw2outputs (+ panoptic logit / fixed-field maps) (8a row a6)
  *   pnr_composite_backward   autograd backward of raw2outputs            (8a row a9)
  *   pnr_sample_pdf      sample_pdf + sorted merge with the coarse z       (8a row a7)
@@ -99,6 +100,24 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, vo
 int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                     int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
                     int64_t raw_stride_c, void* stream);
+
+/* ---- a9 (training): forward that also saves what the backward needs, the data-gradient pass, and the
+ * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
+ *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output,
+ *          one slot-ordered [S][width] region per tensor (S = n_rays*n_samples);
+ *   dys  : bf16, dys_off[D+4] elements -- every layer's pre-activation gradient dY, same layout, written by
+ *          pnr_mlp_backward for the weight-gradient GEMMs dW = dY^T X (plain S-reduction GEMMs, done by the caller);
+ *   d_raw: (4+n_sem+n_inst, S) channel-major fp32 (pnr_composite_backward's output).
+ * Slot order (csrc/pnr_mlp_layout.h): slot fb*32 + hi*16 + r <-> feature fb*32 + (r&3) + 8*(r>>2) + 4*hi. */
+int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples, int64_t* acts_off_host /* D+7 */,
+                         int64_t* dys_off_host /* D+5 */);
+int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                          int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                          int64_t raw_stride_c, void* acts, void* stream);
+int64_t pnr_mlp_bwd_packed_bytes(const pnr_mlp_desc* desc);
+int pnr_mlp_pack_bwd(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, void* packed_host);
+int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd, const float* d_raw, const void* acts,
+                     void* dys, int64_t n_rays, int n_samples, void* stream);
 
 /* ---- a6: raw2outputs.  raw strides as above.  noise (R,N) or NULL; label_* (R,N) int32 or
  * NULL (fixed bbox-prior field, -1 = none).  sem_mode 0: composite logits; 1: softmax first.

@@ -25,187 +25,21 @@
 // LDS-counter flow control instead of the barrier (-3 %), DMA two chunks ahead with counted vmcnt
 // (-9 %), staggering or spreading the DMA pieces through the MFMA stream (-2..-13 %), ping-pong
 // unrolling of the layer loop (-3 %, code size), one wave per SIMD with 1 or 2 tiles (-30 %).
-#include "pnr_common.h"
-#include "pnr_mlp_layout.h"
+#include <string.h>
+
 #include "pnr_mlp_plan.h"
 
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef __attribute__((address_space(3))) void lds_void;
-// The chunk table is read through the constant address space so that hipcc emits scalar
-// (s_load) instead of vector loads: a vector load here costs an L2 round trip AND a vmcnt(0)
-// that drains the in-flight LDS-DMA, once per chunk.
-typedef const __attribute__((address_space(4))) pnr_chunk_entry* table_ptr;
-
-struct MlpArgs {
-    const uint8_t* data;            // fragment stream (device)
-    const pnr_chunk_entry* table;   // chunk table (device)
-    int n_chunks, slot_bytes;
-    const float* rays; const float* z;
-    int S, N, n_groups;
-    float* raw; int64_t ss, sc;
-    int D, skip, n_sem, n_inst;
-};
-
-enum { MODE_RELU = 0, MODE_LINEAR = 1 };
-
-template <int PREC> struct PrecT;
-template <> struct PrecT<PNR_PREC_BF16> { static constexpr int RPB = 8; };    // B regs per 32 input features
-template <> struct PrecT<PNR_PREC_FP32> { static constexpr int RPB = 16; };
-
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
-{
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(uint32_t, v);
-}
-
-// One k-step: 16 bytes of A per lane against 4 B registers.
-template <int PREC>
-__device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x16 acc)
-{
-    if constexpr (PREC == PNR_PREC_BF16) {
-        u32x4 bv;
-        bv[0] = b[0]; bv[1] = b[1]; bv[2] = b[2]; bv[3] = b[3];
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv),
-                                                        acc, 0, 0, 0);
-    } else {
-        // NB: __builtin_bit_cast(float, a[j]) on an ext-vector ELEMENT miscompiles with ROCm 7.2's
-        // clang (every j reads element 0); copy the element to a scalar first.
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t av = a[j], bv = b[j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av), __uint_as_float(bv), acc, 0, 0, 0);
-        }
-        return acc;
-    }
-}
-
-// ---- weight stream: two LDS slots; chunk c+1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
-template <int WAVES, int GDB_>
-struct Ctx {
-    static constexpr int GDB = GDB_;   // A-fragment read-ahead (fragments per tile in flight)
-    const MlpArgs& a;
-    char* smem;
-    int lane, wave, hi;
-    int ci, slot;
-    pnr_chunk_entry e1, e2;            // table entries of chunks ci+1, ci+2 (scalar loads, fetched a chunk early)
-
-    __device__ __forceinline__ int wrap(int i) const { return i >= a.n_chunks ? i - a.n_chunks : i; }
-    __device__ __forceinline__ pnr_chunk_entry entry(int idx) const
-    {
-        table_ptr t = (table_ptr)(uintptr_t)a.table;
-        pnr_chunk_entry e;
-        e.off_frag = t[idx].off_frag;
-        e.nfrag = t[idx].nfrag;
-        return e;
-    }
-    // L2 -> LDS copy of a chunk into slot `sl` (asynchronous LDS-DMA, 1 KiB per wave-instruction)
-    __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int sl) const
-    {
-        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
-        char* dst = smem + sl * a.slot_bytes;
-        for (int f = wave; f < (int)e.nfrag; f += WAVES)
-            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
-                                             (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
-    }
-    __device__ __forceinline__ void start()
-    {
-        ci = 0; slot = 0;
-        issue(entry(0), 0);
-        e1 = entry(wrap(1));
-        e2 = entry(wrap(2));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    __device__ __forceinline__ void begin() const { issue(e1, slot ^ 1); }
-    __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
-    // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
-    __device__ __forceinline__ void finish()
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        slot ^= 1;
-        ci = wrap(ci + 1);
-        e1 = e2;
-        e2 = entry(wrap(wrap(ci + 1) + 1));
-    }
-};
-
-__device__ __forceinline__ void load_bias(const char* bias, int hi, f32x16& acc)
-{
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (8 * m + 4 * hi) * 4);
-        acc[4 * m + 0] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
-    }
-}
-
-// All MFMAs of one chunk: FBC output blocks x KS k-steps x TILES sample tiles.  The FBC blocks are
-// FBC independent accumulator chains issued round-robin per k-step.  A fragments are read from LDS
-// G k-steps ahead of their MFMAs; the sched_group_barrier sequence pins that interleave (hipcc
-// otherwise either sinks every read to just before its use or hoists all of them to the chunk top,
-// +64-96 VGPRs and spills at 2 waves/SIMD).
-template <int PREC, int TILES, int FBC, int G, int NA, int NB>
-__device__ __forceinline__ void mma_chunk(const char* frag, const uint32_t (&inA)[TILES][NA],
-                                          const uint32_t (&inB)[TILES][NB > 0 ? NB : 1], f32x16 (&acc)[FBC][TILES])
-{
-    constexpr int KSA = NA / 4, KSB = NB / 4, KS = KSA + KSB, NG = (KS + G - 1) / G;
-    constexpr int MPK = PREC == PNR_PREC_BF16 ? 1 : 4;   // MFMAs per k-step per tile per block
-    u32x4 A[2][G][FBC];
-#pragma unroll
-    for (int j = 0; j < G; ++j)
-#pragma unroll
-        for (int b = 0; b < FBC; ++b)
-            if (j < KS) A[0][j][b] = *reinterpret_cast<const u32x4*>(frag + (b * KS + j) * PNR_FRAG_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int ks = (g + 1) * G + j;
-#pragma unroll
-                for (int b = 0; b < FBC; ++b)
-                    if (ks < KS) A[(g + 1) & 1][j][b] = *reinterpret_cast<const u32x4*>(frag + (b * KS + ks) * PNR_FRAG_BYTES);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int ks = g * G + j;
-            if (ks < KS) {
-#pragma unroll
-                for (int b = 0; b < FBC; ++b)
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        if (ks < KSA) acc[b][t] = kstep<PREC>(A[g & 1][j][b], &inA[t][4 * (ks < KSA ? ks : 0)], acc[b][t]);
-                        else if constexpr (NB > 0) acc[b][t] = kstep<PREC>(A[g & 1][j][b], &inB[t][4 * (ks >= KSA ? ks - KSA : 0)], acc[b][t]);
-                    }
-            }
-        }
-        // the next group's G*FBC ds_reads go out during the FIRST half of this group's MFMAs
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int j = 0; j < (G + 1) / 2; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, FBC * TILES * MPK, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * FBC, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+#include "pnr_mlp_core.h"
 
 // Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
+// save != nullptr (training, bf16): the output block is also stored slot-ordered for the backward.
 template <int PREC, int TILES, class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
 __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][NA],
                                            const uint32_t (&inB)[TILES][NB > 0 ? NB : 1],
-                                           uint32_t (&out)[TILES][NOUT])
+                                           uint32_t (&out)[TILES][NOUT], uint16_t* save = nullptr,
+                                           const int* samp = nullptr)
 {
     constexpr int RPB = PrecT<PREC>::RPB;
     constexpr int KS = NA / 4 + NB / 4;
@@ -237,6 +71,7 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
                         if (MODE == MODE_RELU) { lo = fmaxf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }
                         out[t][fb * RPB + p] = pack_bf16(lo, hi);
                     }
+                    if (save) store_slots(save, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][fb * RPB]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -332,7 +167,9 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
     }
 }
 
-template <int PREC, int W, int TILES, int WAVES, int MINW>
+// TRAIN: additionally saves gamma(x), gamma(d) and every layer's (bf16, post-activation) output,
+// slot-ordered, for the backward kernel and the weight-gradient GEMMs (MlpArgs::acts).
+template <int PREC, int W, int TILES, int WAVES, int MINW, bool TRAIN>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 {
     using CTX = Ctx<WAVES, 4>;
@@ -387,17 +224,25 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
             vd[t][0] = dx / nrm; vd[t][1] = dy / nrm; vd[t][2] = dz / nrm;
             embed_lane<PREC, 5, 32, GXR>(px, py, pz, c.hi, ex[t]);
+            if constexpr (TRAIN) {
+                if (samp[t] >= 0) {   // EX: [S][64], slot = hi*32 + v
+                    u32x4* p = reinterpret_cast<u32x4*>(a.acts + a.acts_off[0] + (size_t)samp[t] * 64 + c.hi * 32);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { u32x4 v; v[0] = ex[t][4 * k]; v[1] = ex[t][4 * k + 1]; v[2] = ex[t][4 * k + 2]; v[3] = ex[t][4 * k + 3]; p[k] = v; }
+                }
+            }
         }
+        auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
         // trunk
         uint32_t cur[TILES][HR], nxt[TILES][HR];
-        layer_regs<PREC, TILES, CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur);
+        layer_regs<PREC, TILES, CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur, sv(2), samp);
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             if (l - 1 == a.skip)
-                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt);
+                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt, sv(2 + l), samp);
             else
-                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt);
+                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt, sv(2 + l), samp);
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -406,12 +251,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         // heads (h = cur stays live until the rgb/sigma block)
         if (a.n_sem) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), samp);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh);
+            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), samp);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
         // next sample group's inputs: issued here so their HBM latency hides under the feature/views layers
@@ -420,19 +265,22 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #pragma unroll
             for (int t = 0; t < TILES; ++t) nextin[t] = fetch(g2, t);
         }
-        layer_regs<PREC, TILES, CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt);
+        layer_regs<PREC, TILES, CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt, sv(2 + a.D), samp);
         uint32_t ed[TILES][GDR];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) embed_lane<PREC, 2, 16, GDR>(vd[t][0], vd[t][1], vd[t][2], c.hi, ed[t]);
+        for (int t = 0; t < TILES; ++t) {
+            embed_lane<PREC, 2, 16, GDR>(vd[t][0], vd[t][1], vd[t][2], c.hi, ed[t]);
+            if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp[t], 0, c.hi, ed[t]);   // ED: [S][32]
+        }
         uint32_t g[TILES][GR];
-        layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g);
+        layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), samp);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the refill issued past the last chunk
 }
 
 // ------------------------------------------------------------------------------- launcher
-template <int PREC, int W, int TILES, int WAVES, int MINW>
+template <int PREC, int W, int TILES, int WAVES, int MINW, bool TRAIN = false>
 static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
@@ -441,7 +289,7 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
     PNR_REQUIRE(a.n_chunks >= 3, "pnr_mlp_forward: network too small for the weight stream");
     const int per_group = 32 * TILES * WAVES;
     a.n_groups = (a.S + per_group - 1) / per_group;
-    auto kern = k_mlp_fused<PREC, W, TILES, WAVES, MINW>;
+    auto kern = k_mlp_fused<PREC, W, TILES, WAVES, MINW, TRAIN>;
     static thread_local int wg_per_cu = 0;
     if (wg_per_cu == 0) {
         PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -457,9 +305,9 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
     return PNR_OK;
 }
 
-PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                               int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
-                               int64_t raw_stride_c, void* stream)
+static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                            int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c,
+                            void* acts, void* stream)
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
@@ -468,11 +316,13 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
     PNR_REQUIRE(packed && rays && z && raw, "pnr_mlp_forward: null pointer");
     PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_forward: R*N=%lld exceeds 2^31",
                 (long long)(n_rays * n_samples));
-    PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)packed) & 15) == 0,
-                "pnr_mlp_forward: rays / packed must be 16-byte aligned");
+    PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)packed) & 15) == 0 && (((uintptr_t)acts) & 15) == 0,
+                "pnr_mlp_forward: rays / packed / acts must be 16-byte aligned");
+    PNR_REQUIRE(!acts || desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_train: the training path is bf16 only");
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     MlpArgs a;
+    memset(&a, 0, sizeof(a));
     a.data = (const uint8_t*)packed + plan.data_off;
     a.table = (const pnr_chunk_entry*)((const uint8_t*)packed + plan.table_off);
     a.n_chunks = (int)plan.chunks.size();
@@ -480,12 +330,46 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
     a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples; a.n_groups = 0;
     a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.acts = (uint16_t*)acts;
+    if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
     // fp32 parity mode: 4 waves x 1 tile, one wave per SIMD (its activations need ~300 registers)
-    if (desc->precision == PNR_PREC_BF16)
+    if (desc->precision == PNR_PREC_BF16) {
+        if (acts)
+            return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2, true>(a, st)
+                                  : launch_mlp<PNR_PREC_BF16, 128, 1, 8, 2, true>(a, st);
         return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2>(a, st) : launch_mlp<PNR_PREC_BF16, 128, 1, 8, 2>(a, st);
+    }
     return desc->W == 256 ? launch_mlp<PNR_PREC_FP32, 256, 1, 4, 1>(a, st) : launch_mlp<PNR_PREC_FP32, 128, 1, 4, 1>(a, st);
+}
+
+PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                               int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                               int64_t raw_stride_c, void* stream)
+{
+    return mlp_forward_impl(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, nullptr, stream);
+}
+
+PNR_EXPORT int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                     int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                                     int64_t raw_stride_c, void* acts, void* stream)
+{
+    PNR_REQUIRE(acts || n_rays == 0, "pnr_mlp_forward_train: acts is null");
+    return mlp_forward_impl(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, acts, stream);
+}
+
+PNR_EXPORT int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples, int64_t* acts_off_host,
+                                    int64_t* dys_off_host)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(acts_off_host && dys_off_host && n_samples >= 0, "pnr_mlp_train_layout: bad arguments");
+    int64_t a[24], d[24];
+    pnr_train_layout(*desc, n_samples, a, d);
+    memcpy(acts_off_host, a, sizeof(int64_t) * (size_t)(desc->D + 7));
+    memcpy(dys_off_host, d, sizeof(int64_t) * (size_t)(desc->D + 5));
+    return PNR_OK;
 }
 
 PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

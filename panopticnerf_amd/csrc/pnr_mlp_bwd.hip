@@ -1,0 +1,206 @@
+// K3-bwd: data-gradient pass of the fused NeRF MLP, bf16 MFMA.
+// Mirrors the forward kernel (pnr_mlp.hip): every backward layer is  dX^T = W^T * dY^T  with the
+// transposed weights streamed through LDS as the MFMA A operand and the gradients register-resident
+// as the B operand, so gradients flow from d_raw back to layer 1 without leaving the register file.
+//   dY_l = dX_{l+1} (.) [X_{l+1} > 0]   (ReLU mask from the activations the forward saved, bf16)
+// Every dY_l is also stored slot-ordered (MlpArgs::dys) for the weight-gradient GEMMs
+// dW_l = dY_l^T X_l, which are plain (S-reduction) GEMMs done outside this kernel.
+// Execution order / k-segments: pnr_mlp_plan.h (pnr_build_bwd_plan).  No gradient is needed for
+// gamma(x), gamma(d) (the inputs are not learnable), so layer 0 and the view-direction columns have
+// no data-gradient step.
+//
+// 4 waves x 1 tile per workgroup, one wave per SIMD (the concatenated dH input needs 136 B registers):
+// correctness-first geometry; the forward kernel's tuning has not been carried over yet.
+#include <string.h>
+
+#include "pnr_mlp_plan.h"
+#include "pnr_mlp_core.h"
+
+int pnr_mlp_validate(const pnr_mlp_desc* d);
+
+// One backward layer.  in: NA B registers (k-segments concatenated).  out[t][OFF + fb*8 + p].
+// mask  : slot-ordered [S][NFB_OUT*32] activations whose ReLU gates this gradient (nullptr: linear)
+// store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient (nullptr: not stored)
+template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF>
+__device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
+                                          const uint16_t* mask, uint16_t* store, const int (&samp)[TILES])
+{
+    constexpr int FBC = 2, KS = NA / 4, G = 2;
+    static_assert(NFB_OUT % FBC == 0 && NOUT >= OFF + NFB_OUT * 8, "bad backward layer geometry");
+    uint32_t dummy[TILES][1];
+#pragma unroll
+    for (int cb = 0; cb < NFB_OUT / FBC; ++cb) {
+        c.begin();
+        const char* base = c.base();
+        u32x4 mk[FBC][TILES][2];
+        if (mask) {
+#pragma unroll
+            for (int b = 0; b < FBC; ++b)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const u32x4* mp = reinterpret_cast<const u32x4*>(
+                        slot_ptr(const_cast<uint16_t*>(mask), NFB_OUT * 32, samp[t] < 0 ? 0 : samp[t], cb * FBC + b, c.hi));
+                    mk[b][t][0] = mp[0];
+                    mk[b][t][1] = mp[1];
+                }
+        }
+        f32x16 acc[FBC][TILES];
+#pragma unroll
+        for (int b = 0; b < FBC; ++b)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.0f;
+        mma_chunk<PNR_PREC_BF16, TILES, FBC, G, NA, 0>(base + c.lane * 16, in, dummy, acc);
+#pragma unroll
+        for (int b = 0; b < FBC; ++b) {
+            const int fb = cb * FBC + b;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    float lo = acc[b][t][2 * p], hi = acc[b][t][2 * p + 1];
+                    if (mask) {
+                        const uint32_t m = mk[b][t][p >> 2][p & 3];
+                        if ((m & 0xffffu) == 0) lo = 0.0f;       // ReLU output is >= 0: zero bits <=> gate closed
+                        if ((m >> 16) == 0) hi = 0.0f;
+                    }
+                    out[t][OFF + fb * 8 + p] = pack_bf16(lo, hi);
+                }
+                if (store) store_slots(store, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][OFF + fb * 8]);
+            }
+        }
+        c.finish();
+    }
+}
+
+// NB blocks (32 channels each) of the upstream gradient d_raw as B registers in FEAT slot order.
+template <int NB>
+__device__ __forceinline__ void load_draw(const MlpArgs& a, int s, int hi, int ch_base, int n_out, uint32_t (&out)[NB * 8])
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * p + e;
+                const int row = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                v[e] = (s >= 0 && row < n_out) ? a.d_raw[(int64_t)(ch_base + row) * a.S + s] : 0.0f;
+            }
+            out[b * 8 + p] = pack_bf16(v[0], v[1]);
+        }
+}
+
+template <int W, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
+{
+    using CTX = Ctx<WAVES, 4>;
+    constexpr int TILES = 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NFB = W / 32, HFB = W / 64;
+    constexpr int HR = NFB * 8, GR = HFB * 8;
+    constexpr int OBR = PNR_BWD_OUT_SLOTS / 32 * 8;       // B registers of a head's output gradient
+    constexpr int CATR = HR + 8 + GR + GR;                // [dY_feature | d rgb,sigma | dY_sem0 | dY_inst0]
+
+    CTX c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
+          (int)((threadIdx.x & 63) >> 5), 0, 0, {0, 0}, {0, 0}};
+    const int n = c.lane & 31;
+    c.start();
+    const int D = a.D;
+    uint16_t* const acts = a.acts;
+    uint16_t* const dys = a.dys;
+
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        int samp[TILES];
+        {
+            const int s = ((grp * WAVES + c.wave) * TILES) * 32 + n;
+            samp[0] = s < a.S ? s : -1;
+        }
+        uint32_t cat[TILES][CATR];
+#pragma unroll
+        for (int i = 0; i < CATR; ++i) cat[0][i] = 0;
+        uint32_t drs[TILES][8];
+        load_draw<1>(a, samp[0], c.hi, 0, 4, drs[0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cat[0][HR + i] = drs[0][i];
+
+        // d g = W_rgb^T d rgb ; gate by g ; -> dY_views
+        uint32_t dyv[TILES][GR];
+        layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.acts_off[3 + D], dys + a.dys_off[0], samp);
+        // d f = W_views[:, :W]^T dY_views  (feature_linear has no activation) -> dY_feature
+        layer_bwd<TILES, CTX, GR, NFB, CATR, 0>(c, dyv, cat, nullptr, dys + a.dys_off[1], samp);
+        if (a.n_sem) {
+            uint32_t ds[TILES][OBR];
+            load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.acts_off[4 + D], dys + a.dys_off[2], samp);
+        }
+        if (a.n_inst) {
+            uint32_t di[TILES][OBR];
+            load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.acts_off[5 + D], dys + a.dys_off[3], samp);
+        }
+        // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
+        uint32_t dy[TILES][HR], dn[TILES][HR];
+        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.acts_off[1 + D], dys + a.dys_off[3 + D], samp);
+        // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
+#pragma unroll 1
+        for (int l = D - 1; l >= 1; --l) {
+            layer_bwd<TILES, CTX, HR, NFB, HR, 0>(c, dy, dn, acts + a.acts_off[1 + l], dys + a.dys_off[3 + l], samp);
+#pragma unroll
+            for (int i = 0; i < HR; ++i) dy[0][i] = dn[0][i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int W, int WAVES>
+static int launch_bwd(const MlpArgs& a0, hipStream_t stream)
+{
+    MlpArgs a = a0;
+    const int lds_bytes = 2 * a.slot_bytes;
+    PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_backward: weight double buffer of %d bytes exceeds the 160 KiB LDS", lds_bytes);
+    const int per_group = 32 * WAVES;
+    a.n_groups = (a.S + per_group - 1) / per_group;
+    auto kern = k_mlp_bwd<W, WAVES>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        configured = true;
+    }
+    const int grid = a.n_groups < 256 ? a.n_groups : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
+    PNR_CHECK_LAUNCH("pnr_mlp_backward");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd, const float* d_raw, const void* acts,
+                                void* dys, int64_t n_rays, int n_samples, void* stream)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_backward: bf16 only");
+    PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS,
+                "pnr_mlp_backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_mlp_backward: bad size");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(packed_bwd && d_raw && acts && dys, "pnr_mlp_backward: null pointer");
+    PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_backward: R*N exceeds 2^31");
+    PNR_REQUIRE((((uintptr_t)packed_bwd | (uintptr_t)acts | (uintptr_t)dys) & 15) == 0,
+                "pnr_mlp_backward: buffers must be 16-byte aligned");
+    PnrBPlan plan;
+    pnr_build_bwd_plan(*desc, plan);
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.data = (const uint8_t*)packed_bwd + plan.data_off;
+    a.table = (const pnr_chunk_entry*)((const uint8_t*)packed_bwd + plan.table_off);
+    a.n_chunks = (int)plan.chunks.size();
+    a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
+    a.S = (int)(n_rays * n_samples); a.N = n_samples;
+    a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
+    pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
+    hipStream_t st = (hipStream_t)stream;
+    return desc->W == 256 ? launch_bwd<256, 4>(a, st) : launch_bwd<128, 4>(a, st);
+}

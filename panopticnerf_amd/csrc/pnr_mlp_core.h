@@ -1,0 +1,197 @@
+// Device-side core shared by the fused MLP forward (pnr_mlp.hip) and backward (pnr_mlp_bwd.hip)
+// kernels: MFMA k-step, the double-buffered LDS weight stream, and the chunk MFMA loop.
+// See pnr_mlp.hip's header for the design and pnr_mlp_layout.h for the packed layout.
+#pragma once
+#include "pnr_common.h"
+#include "pnr_mlp_layout.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+// The chunk table is read through the constant address space so that hipcc emits scalar
+// (s_load) instead of vector loads: a vector load here costs an L2 round trip AND a vmcnt(0)
+// that drains the in-flight LDS-DMA, once per chunk.
+typedef const __attribute__((address_space(4))) pnr_chunk_entry* table_ptr;
+
+struct MlpArgs {
+    const uint8_t* data;            // fragment stream (device)
+    const pnr_chunk_entry* table;   // chunk table (device)
+    int n_chunks, slot_bytes;
+    const float* rays; const float* z;
+    int S, N, n_groups;
+    float* raw; int64_t ss, sc;
+    int D, skip, n_sem, n_inst;
+    // training only (null otherwise).  acts: activations saved by the forward for the backward,
+    // bf16, one [S][width] slot-ordered region per tensor (pnr_train_layout); d_raw: upstream gradient
+    // of raw, (ch, S) channel-major fp32; dys: pre-activation gradients written by the backward.
+    uint16_t* acts; const float* d_raw; uint16_t* dys;
+    int64_t acts_off[24], dys_off[24];
+};
+
+// 16 consecutive slots (one 32-row block's share of lane (n,hi)) of a slot-ordered [S][width] bf16 tensor
+__device__ __forceinline__ uint16_t* slot_ptr(uint16_t* base, int width, int s, int fb, int hi)
+{
+    return base + (size_t)s * width + fb * 32 + hi * 16;
+}
+__device__ __forceinline__ void store_slots(uint16_t* base, int width, int s, int fb, int hi, const uint32_t* r8)
+{
+    if (s < 0) return;
+    u32x4* p = reinterpret_cast<u32x4*>(slot_ptr(base, width, s, fb, hi));
+    u32x4 a, b;
+    a[0] = r8[0]; a[1] = r8[1]; a[2] = r8[2]; a[3] = r8[3];
+    b[0] = r8[4]; b[1] = r8[5]; b[2] = r8[6]; b[3] = r8[7];
+    p[0] = a; p[1] = b;
+}
+
+enum { MODE_RELU = 0, MODE_LINEAR = 1 };
+
+template <int PREC> struct PrecT;
+template <> struct PrecT<PNR_PREC_BF16> { static constexpr int RPB = 8; };    // B regs per 32 input features
+template <> struct PrecT<PNR_PREC_FP32> { static constexpr int RPB = 16; };
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// One k-step: 16 bytes of A per lane against 4 B registers.
+template <int PREC>
+__device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x16 acc)
+{
+    if constexpr (PREC == PNR_PREC_BF16) {
+        u32x4 bv;
+        bv[0] = b[0]; bv[1] = b[1]; bv[2] = b[2]; bv[3] = b[3];
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv),
+                                                        acc, 0, 0, 0);
+    } else {
+        // NB: __builtin_bit_cast(float, a[j]) on an ext-vector ELEMENT miscompiles with ROCm 7.2's
+        // clang (every j reads element 0); copy the element to a scalar first.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t av = a[j], bv = b[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av), __uint_as_float(bv), acc, 0, 0, 0);
+        }
+        return acc;
+    }
+}
+
+// ---- weight stream: two LDS slots; chunk c+1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
+template <int WAVES, int GDB_>
+struct Ctx {
+    static constexpr int GDB = GDB_;   // A-fragment read-ahead (fragments per tile in flight)
+    const MlpArgs& a;
+    char* smem;
+    int lane, wave, hi;
+    int ci, slot;
+    pnr_chunk_entry e1, e2;            // table entries of chunks ci+1, ci+2 (scalar loads, fetched a chunk early)
+
+    __device__ __forceinline__ int wrap(int i) const { return i >= a.n_chunks ? i - a.n_chunks : i; }
+    __device__ __forceinline__ pnr_chunk_entry entry(int idx) const
+    {
+        table_ptr t = (table_ptr)(uintptr_t)a.table;
+        pnr_chunk_entry e;
+        e.off_frag = t[idx].off_frag;
+        e.nfrag = t[idx].nfrag;
+        return e;
+    }
+    // L2 -> LDS copy of a chunk into slot `sl` (asynchronous LDS-DMA, 1 KiB per wave-instruction)
+    __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int sl) const
+    {
+        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
+        char* dst = smem + sl * a.slot_bytes;
+        for (int f = wave; f < (int)e.nfrag; f += WAVES)
+            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
+                                             (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
+    }
+    __device__ __forceinline__ void start()
+    {
+        ci = 0; slot = 0;
+        issue(entry(0), 0);
+        e1 = entry(wrap(1));
+        e2 = entry(wrap(2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void begin() const { issue(e1, slot ^ 1); }
+    __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
+    // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
+    __device__ __forceinline__ void finish()
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot ^= 1;
+        ci = wrap(ci + 1);
+        e1 = e2;
+        e2 = entry(wrap(wrap(ci + 1) + 1));
+    }
+};
+
+__device__ __forceinline__ void load_bias(const char* bias, int hi, f32x16& acc)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (8 * m + 4 * hi) * 4);
+        acc[4 * m + 0] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+    }
+}
+
+// All MFMAs of one chunk: FBC output blocks x KS k-steps x TILES sample tiles.  The FBC blocks are
+// FBC independent accumulator chains issued round-robin per k-step.  A fragments are read from LDS
+// G k-steps ahead of their MFMAs; the sched_group_barrier sequence pins that interleave (hipcc
+// otherwise either sinks every read to just before its use or hoists all of them to the chunk top,
+// +64-96 VGPRs and spills at 2 waves/SIMD).
+template <int PREC, int TILES, int FBC, int G, int NA, int NB>
+__device__ __forceinline__ void mma_chunk(const char* frag, const uint32_t (&inA)[TILES][NA],
+                                          const uint32_t (&inB)[TILES][NB > 0 ? NB : 1], f32x16 (&acc)[FBC][TILES])
+{
+    constexpr int KSA = NA / 4, KSB = NB / 4, KS = KSA + KSB, NG = (KS + G - 1) / G;
+    constexpr int MPK = PREC == PNR_PREC_BF16 ? 1 : 4;   // MFMAs per k-step per tile per block
+    u32x4 A[2][G][FBC];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int b = 0; b < FBC; ++b)
+            if (j < KS) A[0][j][b] = *reinterpret_cast<const u32x4*>(frag + (b * KS + j) * PNR_FRAG_BYTES);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int ks = (g + 1) * G + j;
+#pragma unroll
+                for (int b = 0; b < FBC; ++b)
+                    if (ks < KS) A[(g + 1) & 1][j][b] = *reinterpret_cast<const u32x4*>(frag + (b * KS + ks) * PNR_FRAG_BYTES);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int ks = g * G + j;
+            if (ks < KS) {
+#pragma unroll
+                for (int b = 0; b < FBC; ++b)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        if (ks < KSA) acc[b][t] = kstep<PREC>(A[g & 1][j][b], &inA[t][4 * (ks < KSA ? ks : 0)], acc[b][t]);
+                        else if constexpr (NB > 0) acc[b][t] = kstep<PREC>(A[g & 1][j][b], &inB[t][4 * (ks >= KSA ? ks - KSA : 0)], acc[b][t]);
+                    }
+            }
+        }
+        // the next group's G*FBC ds_reads go out during the FIRST half of this group's MFMAs
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < (G + 1) / 2; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, FBC * TILES * MPK, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * FBC, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+

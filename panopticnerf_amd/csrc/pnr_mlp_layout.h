@@ -31,6 +31,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "pnr.h"
+
 #define PNR_PACK_MAGIC 0x504e5231u /* "PNR1" */
 #define PNR_FRAG_BYTES 1024
 
@@ -79,3 +81,31 @@ static inline int pnr_seg_col(int kind, int L, int hi, int v)
 }
 // values per lane of a segment
 static inline int pnr_seg_vl(int kind, int nfeat) { return kind == PNR_SEG_GX ? 32 : kind == PNR_SEG_GD ? 16 : nfeat / 2; }
+
+// Training buffers (bf16 elements; every region is a slot-ordered [S][width] tensor, 16-byte aligned).
+//   acts_off: [0] EX (64)  [1] ED (32)  [2+l] X_{l+1}, l < D (W)  [2+D] F (W)  [3+D] G (W/2)
+//             [4+D] SH_sem (W/2)  [5+D] SH_inst (W/2)  [6+D] total
+//   dys_off : [0] DY_views (W/2)  [1] DY_feature (W)  [2] DY_sem0 (W/2)  [3] DY_inst0 (W/2)
+//             [4+l] DY_l, l < D (W)  [4+D] total
+// Slot order of a width-n feature tensor: slot fb*32 + hi*16 + r <-> feature fb*32 + row(r,hi); of EX: slot
+// hi*32 + v <-> pnr_seg_col(GX, L, hi, v); of ED: slot hi*16 + v <-> pnr_seg_col(GD, L, hi, v).
+static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* acts_off, int64_t* dys_off)
+{
+    int64_t o = 0;
+    auto take = [&](int64_t w) { const int64_t r = o; o += w * S; o = (o + 7) & ~(int64_t)7; return r; };
+    acts_off[0] = take(64);
+    acts_off[1] = take(32);
+    for (int l = 0; l < d.D; ++l) acts_off[2 + l] = take(d.W);
+    acts_off[2 + d.D] = take(d.W);
+    acts_off[3 + d.D] = take(d.W / 2);
+    acts_off[4 + d.D] = take(d.W / 2);
+    acts_off[5 + d.D] = take(d.W / 2);
+    acts_off[6 + d.D] = o;
+    o = 0;
+    dys_off[0] = take(d.W / 2);
+    dys_off[1] = take(d.W);
+    dys_off[2] = take(d.W / 2);
+    dys_off[3] = take(d.W / 2);
+    for (int l = 0; l < d.D; ++l) dys_off[4 + l] = take(d.W);
+    dys_off[4 + d.D] = o;
+}

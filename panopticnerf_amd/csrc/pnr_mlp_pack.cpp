@@ -160,3 +160,97 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
     }
     return PNR_OK;
 }
+
+// ---- backward image: the transposed weights, same fragment format (rows = input features i of the
+// forward layer, k = its output features o in FEAT slot order).  bf16.
+static int bwd_validate(const pnr_mlp_desc* d)
+{
+    int rc = pnr_mlp_validate(d);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
+    PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
+                "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
+    return PNR_OK;
+}
+
+PNR_EXPORT int64_t pnr_mlp_bwd_packed_bytes(const pnr_mlp_desc* desc)
+{
+    if (bwd_validate(desc) != PNR_OK) return PNR_EINVAL;
+    PnrBPlan plan;
+    pnr_build_bwd_plan(*desc, plan);
+    return (int64_t)plan.total_bytes;
+}
+
+PNR_EXPORT int pnr_mlp_pack_bwd(const pnr_mlp_desc* desc, const pnr_mlp_params_host* p, void* packed_host)
+{
+    int rc = bwd_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(p && packed_host, "pnr_mlp_pack_bwd: null pointer");
+    PNR_REQUIRE(p->pts_w && p->alpha_w && p->feature_w && p->views_w && p->rgb_w, "pnr_mlp_pack_bwd: missing trunk parameter");
+    if (desc->n_sem) PNR_REQUIRE(p->sem0_w && p->sem1_w, "pnr_mlp_pack_bwd: missing semantic head");
+    if (desc->n_inst) PNR_REQUIRE(p->inst0_w && p->inst1_w, "pnr_mlp_pack_bwd: missing instance head");
+    PnrBPlan plan;
+    pnr_build_bwd_plan(*desc, plan);
+    uint8_t* img = (uint8_t*)packed_host;
+    memset(img, 0, plan.total_bytes);
+    pnr_pack_header hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.magic = PNR_PACK_MAGIC;
+    hdr.version = 2;
+    hdr.n_chunks = (uint32_t)plan.chunks.size();
+    hdr.max_chunk_frags = (uint32_t)plan.max_chunk_frags;
+    hdr.table_off = (uint32_t)plan.table_off;
+    hdr.data_off = (uint32_t)plan.data_off;
+    hdr.total_bytes = plan.total_bytes;
+    memcpy(hdr.desc, desc, sizeof(pnr_mlp_desc));
+    memcpy(img, &hdr, sizeof(hdr));
+    pnr_chunk_entry* table = (pnr_chunk_entry*)(img + plan.table_off);
+    const int W = desc->W, H = W / 2, EX = 3 + 6 * desc->xyz_L, ED = 3 + 6 * desc->dir_L;
+
+    for (size_t ci = 0; ci < plan.chunks.size(); ++ci) {
+        const PnrChunk& ch = plan.chunks[ci];
+        const PnrBLayer& L = plan.layers[ch.layer];
+        table[ci].off_frag = (uint32_t)ch.off_frag;
+        table[ci].nfrag = (uint32_t)ch.nfrag;
+        uint8_t* base = img + plan.data_off + (size_t)ch.off_frag * PNR_FRAG_BYTES;
+        // W_forward[o][i] of the k-segment's layer, 0 outside it
+        auto wt = [&](int kseg, int o, int i) -> float {
+            switch (kseg) {
+            case PNR_K_RGBS:
+                if (L.kind == PNR_B_DG) return o < 3 ? p->rgb_w[(size_t)o * H + i] : 0.0f;     // d g
+                return o == 3 ? p->alpha_w[i] : 0.0f;                                          // d h (sigma row)
+            case PNR_K_VIEWS: return o < H ? p->views_w[(size_t)o * (W + ED) + i] : 0.0f;      // feature columns
+            case PNR_K_SEM1: return (desc->n_sem && o < desc->n_sem) ? p->sem1_w[(size_t)o * H + i] : 0.0f;
+            case PNR_K_INST1: return (desc->n_inst && o < desc->n_inst) ? p->inst1_w[(size_t)o * H + i] : 0.0f;
+            case PNR_K_FEATURE: return p->feature_w[(size_t)o * W + i];
+            case PNR_K_SEM0: return desc->n_sem ? p->sem0_w[(size_t)o * W + i] : 0.0f;
+            case PNR_K_INST0: return desc->n_inst ? p->inst0_w[(size_t)o * W + i] : 0.0f;
+            case PNR_K_TRUNK: {
+                const int l = L.index;
+                const bool sk = (l - 1 == desc->skip);
+                return p->pts_w[l][(size_t)o * (sk ? EX + W : W) + (sk ? EX + i : i)];
+            }
+            }
+            return 0.0f;
+        };
+        int frag_idx = 0;
+        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
+            const int fb = ch.fb + fbl;
+            for (int seg = 0; seg < L.nseg; ++seg) {
+                const int vl = L.seg_slots[seg] / 2;
+                for (int ks = 0; ks < vl / 8; ++ks, ++frag_idx) {
+                    uint8_t* frag = base + (size_t)frag_idx * PNR_FRAG_BYTES;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int irow = fb * 32 + (lane & 31), hi = lane >> 5;
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = pnr_seg_col(PNR_SEG_FEAT, 0, hi, ks * 8 + j);
+                            const uint16_t h = f32_to_bf16_rne(wt(L.seg_kind[seg], o, irow));
+                            memcpy(frag + lane * 16 + j * 2, &h, 2);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return PNR_OK;
+}

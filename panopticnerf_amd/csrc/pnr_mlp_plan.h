@@ -5,6 +5,7 @@
 #pragma once
 #include <stddef.h>
 
+#include <utility>
 #include <vector>
 
 #include "pnr.h"
@@ -63,6 +64,63 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         for (int fb = 0; fb < L.n_fb; fb += L.fbc) {
             PnrChunk c;
             c.layer = (int)li; c.fb = fb; c.nfb = L.fbc; c.off_frag = off; c.nfrag = L.fbc * L.nks + 1;   // + bias fragment
+            off += c.nfrag;
+            if (c.nfrag > mx) mx = c.nfrag;
+            plan.chunks.push_back(c);
+        }
+    }
+    plan.max_chunk_frags = mx;
+    plan.table_off = sizeof(pnr_pack_header);
+    size_t t = plan.table_off + plan.chunks.size() * sizeof(pnr_chunk_entry);
+    plan.data_off = (t + 1023) & ~(size_t)1023;
+    plan.total_bytes = plan.data_off + (size_t)off * PNR_FRAG_BYTES;
+}
+
+// ---- backward (dgrad) plan, bf16 only.  Every backward layer computes  dX^T = W^T * dY^T  for one tensor X:
+// rows = X's features (32-row blocks), k = the forward layer's OUTPUT features, supplied by up to four
+// k-segments in FEAT slot order (pnr_seg_col).  Chunks hold 2 row blocks and no bias fragment.
+// Execution order: DG | DF | [DSHS] | [DSHI] | DH | DX(D-1) ... DX(1).
+enum { PNR_B_DG = 0, PNR_B_DF, PNR_B_DSHS, PNR_B_DSHI, PNR_B_DH, PNR_B_DX };
+enum { PNR_K_RGBS = 0, PNR_K_VIEWS, PNR_K_SEM1, PNR_K_INST1, PNR_K_FEATURE, PNR_K_SEM0, PNR_K_INST0, PNR_K_TRUNK };
+#define PNR_BWD_OUT_SLOTS 64      /* k-slots reserved for a head's outputs (n_sem, n_inst <= 64 when training) */
+
+struct PnrBLayer {
+    int kind, index;        // index: trunk layer l for PNR_B_DX
+    int rows, n_fb;         // X's width, 32-row blocks
+    int nseg;
+    int seg_kind[4], seg_slots[4];
+    int nks;                // k-steps per 32-row block
+};
+struct PnrBPlan {
+    std::vector<PnrBLayer> layers;
+    std::vector<PnrChunk> chunks;
+    int max_chunk_frags;
+    size_t table_off, data_off, total_bytes;
+};
+
+static inline void pnr_build_bwd_plan(const pnr_mlp_desc& d, PnrBPlan& plan)
+{
+    const int W = d.W, H = d.W / 2;
+    auto add = [&](int kind, int index, int rows, std::initializer_list<std::pair<int, int>> segs) {
+        PnrBLayer L;
+        L.kind = kind; L.index = index; L.rows = rows; L.n_fb = rows / 32; L.nseg = 0; L.nks = 0;
+        for (auto& sg : segs) { L.seg_kind[L.nseg] = sg.first; L.seg_slots[L.nseg] = sg.second; L.nks += sg.second / 16; ++L.nseg; }
+        plan.layers.push_back(L);
+    };
+    plan.layers.clear();
+    plan.chunks.clear();
+    add(PNR_B_DG, 0, H, {{PNR_K_RGBS, 32}});
+    add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}});
+    if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
+    if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
+    add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
+    for (int l = d.D - 1; l >= 1; --l) add(PNR_B_DX, l, W, {{PNR_K_TRUNK, W}});
+    int off = 0, mx = 0;
+    for (size_t li = 0; li < plan.layers.size(); ++li) {
+        const PnrBLayer& L = plan.layers[li];
+        for (int fb = 0; fb < L.n_fb; fb += 2) {
+            PnrChunk c;
+            c.layer = (int)li; c.fb = fb; c.nfb = 2; c.off_frag = off; c.nfrag = 2 * L.nks;
             off += c.nfrag;
             if (c.nfrag > mx) mx = c.nfrag;
             plan.chunks.push_back(c);

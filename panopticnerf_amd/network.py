@@ -82,6 +82,18 @@ class Network(nn.Module):
             self._packed[key] = hit = (ver, desc, img)
         return hit[1], hit[2]
 
+    def packed_bwd(self, level, device):
+        """Transposed-weight image of level's NeRF for the backward kernel (bf16); rebuilt on parameter change."""
+        key = ("bwd", level if self.nerf_1 is not None else 0, str(device))
+        ver = self._version(level)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            net = self.nerf(level)
+            desc = net.desc("bf16")
+            sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+            self._packed[key] = hit = (ver, desc, ops.pack_mlp_bwd(desc, sd).to(device))
+        return hit[1], hit[2]
+
     def forward(self, *a, **k):
         raise RuntimeError("Network is evaluated by Renderer.render() through the fused HIP kernel; "
                            "there is no torch forward (and no CPU fallback).")

@@ -110,6 +110,74 @@ def pack_mlp(desc, params):
     return img
 
 
+def pack_mlp_bwd(desc, params):
+    """Transposed-weight image for pnr_mlp_backward (CPU uint8 tensor).  bf16, n_sem/n_inst <= 64."""
+    lib = _lib.load()
+    nbytes = lib.pnr_mlp_bwd_packed_bytes(ctypes.byref(desc))
+    if nbytes < 0:
+        _lib.check(int(nbytes), "pnr_mlp_bwd_packed_bytes")
+    keep = []
+
+    def fp(name):
+        if name not in params:
+            return None
+        t = params[name].detach().to("cpu", torch.float32).contiguous()
+        keep.append(t)
+        return ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+
+    P = MlpParamsHost()
+    D = desc.D
+    pw = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.weight") for i in range(D)])
+    pb = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.bias") for i in range(D)])
+    P.pts_w, P.pts_b = pw, pb
+    P.alpha_w, P.alpha_b = fp("alpha_linear.weight"), fp("alpha_linear.bias")
+    P.feature_w, P.feature_b = fp("feature_linear.weight"), fp("feature_linear.bias")
+    P.views_w, P.views_b = fp("views_linears.0.weight"), fp("views_linears.0.bias")
+    P.rgb_w, P.rgb_b = fp("rgb_linear.weight"), fp("rgb_linear.bias")
+    if desc.n_sem:
+        P.sem0_w, P.sem1_w = fp("semantic_linears.0.weight"), fp("semantic_linears.1.weight")
+    if desc.n_inst:
+        P.inst0_w, P.inst1_w = fp("instance_linears.0.weight"), fp("instance_linears.1.weight")
+    img = torch.empty(int(nbytes), dtype=torch.uint8)
+    _lib.check(lib.pnr_mlp_pack_bwd(ctypes.byref(desc), ctypes.byref(P), ctypes.c_void_p(img.data_ptr())),
+               "pnr_mlp_pack_bwd")
+    return img
+
+
+def train_layout(desc, n_samples):
+    """(acts_off, dys_off): element offsets (bf16 units) of the saved-activation / dY regions; last = total."""
+    a = (ctypes.c_int64 * (desc.D + 7))()
+    d = (ctypes.c_int64 * (desc.D + 5))()
+    _lib.check(_lib.load().pnr_mlp_train_layout(ctypes.byref(desc), int(n_samples), a, d), "pnr_mlp_train_layout")
+    return list(a), list(d)
+
+
+def mlp_forward_train(desc, packed, rays, z):
+    """Forward that also saves activations for the backward.  Returns (raw (ch,S) channel-major, acts bf16)."""
+    rays, z = _chk(rays, "rays"), _chk(z, "z")
+    packed = _chk(packed, "packed", torch.uint8)
+    R, N = z.shape
+    S = R * N
+    acts_off, _ = train_layout(desc, S)
+    raw = torch.empty((n_channels(desc), S), device=z.device, dtype=torch.float32)
+    acts = torch.empty((acts_off[-1],), device=z.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().pnr_mlp_forward_train(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1, S,
+                                                 _p(acts), _stream()), "pnr_mlp_forward_train")
+    return raw, acts
+
+
+def mlp_backward(desc, packed_bwd, d_raw, acts, n_rays, n_samples):
+    """Data-gradient pass: d_raw (ch,S) + saved activations -> dys (bf16, every layer's pre-activation gradient)."""
+    d_raw = _chk(d_raw, "d_raw")
+    packed_bwd = _chk(packed_bwd, "packed_bwd", torch.uint8)
+    acts = _chk(acts, "acts", torch.bfloat16)
+    _, dys_off = train_layout(desc, n_rays * n_samples)
+    dys = torch.empty((dys_off[-1],), device=d_raw.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().pnr_mlp_backward(ctypes.byref(desc), _p(packed_bwd), _p(d_raw), _p(acts), _p(dys), n_rays,
+                                            n_samples, _stream()), "pnr_mlp_backward")
+    return dys
+
+
 def n_channels(desc):
     return 4 + desc.n_sem + desc.n_inst
 

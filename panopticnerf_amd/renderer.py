@@ -41,7 +41,7 @@ class Renderer:
         self.keep_weights = _get(cfg, "keep_weights", True)
 
     # --- one chunk of rays: the reference's render_rays (row a2)
-    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False):
+    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False):
         net, Nc, Nf = self.net, self.N_samples, self.N_importance
         n0 = net.nerf(0)
         C, K = n0.n_sem, n0.n_inst
@@ -55,16 +55,20 @@ class Renderer:
         z = ops.stratified(rays, Nc, self.lindisp, t_rand)
 
         def level(lv, zz):
-            desc, img = net.packed(lv, dev)
             ls = li = None
             if hits is not None:
                 ls, li = ops.sample_labels(zz, hits[0], hits[1], hits[2], box_ids)
-            raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
             noise = None
             if self.raw_noise_std > 0 and train:
                 noise = torch.randn(zz.shape, device=dev) * self.raw_noise_std
-            need_w = self.keep_weights or (lv == 0 and Nf > 0)
-            out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
+            if grad:
+                from . import train as _train       # autograd path
+                out = _train.level_train(self, lv, rays, zz, ls, li, noise)
+            else:
+                desc, img = net.packed(lv, dev)
+                raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
+                need_w = self.keep_weights or (lv == 0 and Nf > 0)
+                out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
             for k, v in out.items():
                 ret[f"{k}_{lv}"] = v
             ret[f"z_vals_{lv}"] = zz
@@ -74,7 +78,7 @@ class Renderer:
         if Nf > 0:
             if u is None and self.perturb > 0 and train:
                 u = torch.rand((rays.shape[0], Nf), device=dev)
-            z_fine, _, _ = ops.sample_pdf(z, o0["weights"], Nf, u, want_samples=False)
+            z_fine, _, _ = ops.sample_pdf(z, o0["weights"].detach().contiguous(), Nf, u, want_samples=False)
             level(1, z_fine)
         return ret
 
@@ -83,10 +87,12 @@ class Renderer:
         rays = batch["rays"]
         if not rays.is_cuda:
             raise RuntimeError("Renderer.render: batch['rays'] must be on the GPU (no CPU fallback)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()) and self.net.training:
-            raise NotImplementedError(
-                "Renderer.render: the backward pass (SURVEY.md 8a row a9) is not built yet; call under "
-                "torch.no_grad() / net.eval().  See DESIGN.md 'what comes next'.")
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
+        if grad and self.sem_mode != 0:
+            raise NotImplementedError("Renderer.render: gradients are implemented for logit compositing "
+                                      "(semantic_activation='none') only")
+        if grad and self.net.precision != "bf16":
+            raise NotImplementedError("Renderer.render: the backward kernels are bf16; set precision='bf16' to train")
         lead = rays.shape[:-1]
         rays = rays.reshape(-1, 8).float().contiguous()
         R = rays.shape[0]
@@ -106,7 +112,7 @@ class Renderer:
             e = min(R, s + self.chunk_size)
             outs.append(self.render_rays(rays[s:e], box, box_ids,
                                          None if t_rand is None else t_rand[s:e],
-                                         None if u is None else u[s:e], train))
+                                         None if u is None else u[s:e], train, grad))
         ret = {}
         for k in outs[0]:
             v = outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)

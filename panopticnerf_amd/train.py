@@ -1,0 +1,191 @@
+"""Training-side glue of the render path: the autograd Function that
+puts the HIP forward / backward kernels behind `Renderer.render`, the weight-gradient assembly,
+and the flat-bucket gradient all-reduce.
+
+What runs where: forward (pnr_mlp_forward_train + pnr_composite), compositing backward
+(pnr_composite_backward) and the MLP data-gradient pass (pnr_mlp_backward) are hand-written HIP.
+The weight gradients dW_l = dY_l^T X_l are plain GEMMs with a (S x 256)-deep reduction over
+samples; round 1 hands those (and the bias sums) to the library GEMM through torch.mm on the
+kernels' slot-ordered bf16 buffers, then un-permutes the small (<= 256 x 320) results.  A
+hand-written split-K kernel for them is listed in DESIGN.md section 7.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _row_of(r, hi):
+    return (r & 3) + 8 * (r >> 2) + 4 * hi
+
+
+def feat_slots(width, device):
+    """slot -> feature index of a slot-ordered width-`width` tensor (csrc/pnr_mlp_layout.h)."""
+    idx = torch.empty(width, dtype=torch.long)
+    for fb in range(width // 32):
+        for hi in (0, 1):
+            for r in range(16):
+                idx[fb * 32 + hi * 16 + r] = fb * 32 + _row_of(r, hi)
+    return idx.to(device)
+
+
+def embed_slots(n_half_freq, L, device):
+    """slot -> canonical gamma() column (or -1): EX (n_half_freq=5, 64 slots), ED (2, 32 slots)."""
+    nv = 32 if n_half_freq == 5 else 16
+    idx = torch.full((2 * nv,), -1, dtype=torch.long)
+    for hi in (0, 1):
+        for v in range(nv):
+            if v == 0:
+                c = 2 if hi else 0
+            elif v == 1:
+                c = -1 if hi else 1
+            else:
+                fp, j = divmod(v - 2, 6)
+                f = hi * n_half_freq + fp
+                c = 3 + 6 * f + j if (fp < n_half_freq and f < L) else -1
+            idx[hi * nv + v] = c
+    return idx.to(device)
+
+
+def _mm(a_t, b):
+    """a_t (S, m), b (S, n) -> a_t^T b (m, n) in fp32 (library GEMM, fp32 accumulate)."""
+    return torch.mm(a_t.float().t(), b.float())
+
+
+def weight_grads(nerf, desc, acts, dys, d_raw, S):
+    """dict name -> fp32 gradient (nn.Linear layout) from the kernels' buffers."""
+    dev = d_raw.device
+    D, W, H, C, K = nerf.D, nerf.W, nerf.W // 2, nerf.n_sem, nerf.n_inst
+    ao, do = ops.train_layout(desc, S)
+    A = lambda i, w: acts[ao[i]: ao[i] + S * w].view(S, w)
+    Y = lambda i, w: dys[do[i]: do[i] + S * w].view(S, w)
+    fW, fH = feat_slots(W, dev), feat_slots(H, dev)
+    ex_idx, ed_idx = embed_slots(5, nerf.xyz_L, dev), embed_slots(2, nerf.dir_L, dev)
+    EXn, EDn = 3 + 6 * nerf.xyz_L, 3 + 6 * nerf.dir_L
+
+    def unperm_cols(g_slot, idx, n_cols):           # (m, slots) -> (m, n_cols)
+        out = torch.zeros((g_slot.shape[0], n_cols), device=dev, dtype=torch.float32)
+        ok = idx >= 0
+        out[:, idx[ok]] = g_slot[:, ok]
+        return out
+
+    def unperm_rows(g, idx):                        # rows in slot order -> feature order
+        out = torch.empty_like(g)
+        out[idx] = g
+        return out
+
+    X_h = A(1 + D, W)                               # h = X_D
+    EX, ED = A(0, 64), A(1, 32)
+    F_, G_, SHS, SHI = A(2 + D, W), A(3 + D, H), A(4 + D, H), A(5 + D, H)
+    g = {}
+    dr = d_raw.view(-1, S)
+    # output layers: dY = rows of d_raw (fp32, already feature-ordered)
+    g["rgb_linear.weight"] = unperm_cols(torch.mm(dr[0:3], G_.float()), fH, H)
+    g["rgb_linear.bias"] = dr[0:3].sum(1)
+    g["alpha_linear.weight"] = unperm_cols(torch.mm(dr[3:4], X_h.float()), fW, W)
+    g["alpha_linear.bias"] = dr[3:4].sum(1)
+    if C:
+        g["semantic_linears.1.weight"] = unperm_cols(torch.mm(dr[4:4 + C], SHS.float()), fH, H)
+        g["semantic_linears.1.bias"] = dr[4:4 + C].sum(1)
+        dy = Y(2, H)
+        g["semantic_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_h), fW, W), fH)
+        g["semantic_linears.0.bias"] = unperm_rows(dy.float().sum(0), fH)
+    if K:
+        g["instance_linears.1.weight"] = unperm_cols(torch.mm(dr[4 + C:4 + C + K], SHI.float()), fH, H)
+        g["instance_linears.1.bias"] = dr[4 + C:4 + C + K].sum(1)
+        dy = Y(3, H)
+        g["instance_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_h), fW, W), fH)
+        g["instance_linears.0.bias"] = unperm_rows(dy.float().sum(0), fH)
+    dy = Y(0, H)                                    # views: input [feature, gamma(d)]
+    g["views_linears.0.weight"] = unperm_rows(torch.cat([unperm_cols(_mm(dy, F_), fW, W),
+                                                         unperm_cols(_mm(dy, ED), ed_idx, EDn)], 1), fH)
+    g["views_linears.0.bias"] = unperm_rows(dy.float().sum(0), fH)
+    dy = Y(1, W)
+    g["feature_linear.weight"] = unperm_rows(unperm_cols(_mm(dy, X_h), fW, W), fW)
+    g["feature_linear.bias"] = unperm_rows(dy.float().sum(0), fW)
+    for l in range(D):
+        dy = Y(4 + l, W)
+        if l == 0:
+            gw = unperm_cols(_mm(dy, EX), ex_idx, EXn)
+        elif l - 1 == nerf.skip:
+            gw = torch.cat([unperm_cols(_mm(dy, EX), ex_idx, EXn), unperm_cols(_mm(dy, A(1 + l, W)), fW, W)], 1)
+        else:
+            gw = unperm_cols(_mm(dy, A(1 + l, W)), fW, W)
+        g[f"pts_linears.{l}.weight"] = unperm_rows(gw, fW)
+        g[f"pts_linears.{l}.bias"] = unperm_rows(dy.float().sum(0), fW)
+    return g
+
+
+class LevelFn(torch.autograd.Function):
+    """One level (coarse or fine) of render_rays: NeRF MLP on every sample + raw2outputs.
+    Differentiable w.r.t. the NeRF's parameters only (z comes from the detached sampler)."""
+
+    OUT = ("rgb", "depth", "acc", "weights", "semantic", "instance")
+
+    @staticmethod
+    def forward(ctx, rend, lv, rays, z, ls, li, noise, names, *params):
+        net = rend.net
+        nerf = net.nerf(lv)
+        dev = rays.device
+        desc, img = net.packed(lv, dev, "bf16")
+        C, K = nerf.n_sem, nerf.n_inst
+        raw, acts = ops.mlp_forward_train(desc, img, rays, z)
+        out = ops.composite(raw, z, rays, C, K, True, noise, ls, li, 0, rend.white_bkgd, True)
+        ctx.rend, ctx.lv, ctx.names = rend, lv, names
+        ctx.save_for_backward(raw, acts, z, rays, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.has_noise = noise is not None
+        res = [out.get(k) for k in LevelFn.OUT]
+        res = [r if r is not None else torch.zeros(0, device=dev) for r in res]
+        fix = [out.get("fix_semantic"), out.get("fix_instance")]
+        fix = [f if f is not None else torch.zeros(0, device=dev) for f in fix]
+        ctx.mark_non_differentiable(*fix)
+        return tuple(res) + tuple(fix)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w, g_sem, g_inst, *_):
+        raw, acts, z, rays, noise = ctx.saved_tensors
+        rend, lv = ctx.rend, ctx.lv
+        net = rend.net
+        nerf = net.nerf(lv)
+        C, K = nerf.n_sem, nerf.n_inst
+        R, N = z.shape
+        grads = {"rgb": g_rgb, "depth": g_depth, "acc": g_acc, "weights": g_w,
+                 "semantic": g_sem if C else None, "instance": g_inst if K else None}
+        if rend.white_bkgd and g_rgb is not None:       # rgb += 1 - acc
+            grads["acc"] = (g_acc if g_acc is not None else 0) - g_rgb.sum(-1)
+        grads = {k: v for k, v in grads.items() if v is not None and v.numel()}
+        d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None)
+        desc, img_b = net.packed_bwd(lv, rays.device)
+        dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
+        wg = weight_grads(nerf, desc, acts, dys, d_raw, R * N)
+        return (None,) * 8 + tuple(wg[n].to(p_dtype) for n, p_dtype in ctx.names)
+
+
+def level_train(rend, lv, rays, z, ls, li, noise):
+    """Differentiable level: returns the same dict as ops.composite()."""
+    nerf = rend.net.nerf(lv)
+    named = list(nerf.named_parameters())
+    names = tuple((n, p.dtype) for n, p in named)
+    res = LevelFn.apply(rend, lv, rays, z, ls, li, noise, names, *[p for _, p in named])
+    out = {k: v for k, v in zip(LevelFn.OUT + ("fix_semantic", "fix_instance"), res) if v.numel()}
+    return out
+
+
+def allreduce_grads(module, world=None, group=None):
+    """Average the gradients of `module` across ranks with ONE flat bucket (~1.3 M fp32
+    = 5 MB per step is latency-bound on xGMI, so one all-reduce beats DDP's many buckets).
+    RCCL when the process group is 'nccl' (ROCm), gloo in the CPU tests."""
+    world = world or dist.get_world_size(group)
+    if world == 1:
+        return
+    ps = [p for p in module.parameters() if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world)
+    o = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
