@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3, help="secondary training-step measurement (0 = skip)")
+    ap.add_argument("--train-rays", type=int, default=4096)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,6 +161,53 @@ def main():
                                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k_composite", rc.shape[0]),
                                            "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray}
 
+    # secondary measurement (never the headline value): one training step on a 4096-ray batch per rank --
+    # render with autograd, MSE / CE-style losses on the maps, backward through the HIP kernels, flat-bucket
+    # gradient all-reduce over RCCL, Adam.  Guarded: a failure here must not lose the headline line.
+    train_info = None
+    if args.train_steps > 0:
+        try:
+            from panopticnerf_amd import train as pnr_train
+            tnet = make_network(cfg).to(dev).train()
+            synthetic.trained_like_(tnet)
+            trend = make_renderer(cfg, tnet)
+            opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
+            g = torch.Generator(device=dev).manual_seed(rank)
+            idx = torch.randint(0, n_rays, (args.train_rays,), generator=g, device=dev)
+            tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+            tgt_rgb = torch.rand((args.train_rays, 3), generator=g, device=dev)
+            tgt_sem = torch.randint(0, N_SEM, (args.train_rays,), generator=g, device=dev)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                o = trend.render(tb)
+                loss = 0
+                for lv in (0, 1):
+                    loss = loss + ((o[f"rgb_{lv}"][0] - tgt_rgb) ** 2).mean()
+                    loss = loss + 0.1 * torch.nn.functional.cross_entropy(o[f"semantic_{lv}"][0], tgt_sem)
+                loss.backward()
+                pnr_train.allreduce_grads(tnet, world)
+                opt.step()
+                return loss
+
+            l0 = step().item()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.train_steps):
+                ll = step()
+            sync()
+            tdt = (time.perf_counter() - t0) / args.train_steps
+            if world > 1:
+                tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tdt = float(tt.item())
+            train_info = {"ms_per_step": round(tdt * 1e3, 3), "rays_per_rank": args.train_rays,
+                          "Msamples_per_s_fwd_bwd": round(args.train_rays * world * (N_C + N_C + N_F) / tdt / 1e6, 2),
+                          "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
+                          "grad_allreduce": "flat bucket, %s" % ("RCCL (nccl)" if world > 1 else "single rank: skipped")}
+        except Exception as e:      # noqa: BLE001
+            train_info = {"error": "%s: %s" % (type(e).__name__, e)}
+
     cpu_baseline = None
     if rank == 0 and args.cpu_seconds > 0:
         from oracle import torch_oracle as to
@@ -223,6 +272,8 @@ def main():
                            "parallelism": "rays sharded, %d rank(s), no data-path collective" % world},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)
+        if train_info is not None:
+            line["train_step"] = train_info
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

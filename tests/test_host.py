@@ -78,6 +78,50 @@ def test_shard_roundtrip_single_process():
     assert shard.gather_maps({"a": rays}, 11, 0, 1)["a"] is rays
 
 
+def _ar_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticnerf_amd import train
+    torch.manual_seed(0)
+    net = make_network(NS(D=2, W=128, skips=[], num_classes=3, N_importance=8))
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    net.nerf_0.rgb_linear.bias.grad = None                     # a parameter without gradient is skipped
+    train.allreduce_grads(net, world)
+    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1)))
+             for i, p in enumerate(net.parameters()) if p.grad is not None)
+    ok = ok and net.nerf_0.rgb_linear.bias.grad is None
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_flat_bucket_grad_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ar_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_weight_grad_slot_maps_are_permutations():
+    from panopticnerf_amd import train
+    for w in (128, 256):
+        idx = train.feat_slots(w, "cpu")
+        assert sorted(idx.tolist()) == list(range(w))
+    ex = train.embed_slots(5, 10, "cpu")
+    assert sorted(i for i in ex.tolist() if i >= 0) == list(range(63)) and (ex < 0).sum() == 1
+    ed = train.embed_slots(2, 4, "cpu")
+    assert sorted(i for i in ed.tolist() if i >= 0) == list(range(27)) and (ed < 0).sum() == 5
+    assert sorted(i for i in train.embed_slots(5, 6, "cpu").tolist() if i >= 0) == list(range(39))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
