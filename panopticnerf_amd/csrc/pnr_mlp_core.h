@@ -60,6 +60,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
     return __builtin_bit_cast(uint32_t, v);
 }
 
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v)
+{
+    const i16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), z));
+}
+
 // One k-step: 16 bytes of A per lane against 4 B registers.
 template <int PREC>
 __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x16 acc)
