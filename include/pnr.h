@@ -91,6 +91,16 @@ int64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc);
 /* Pack host parameters into packed_host (pnr_mlp_packed_bytes bytes, host). Pure CPU. */
 int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, void* packed_host);
 
+/* Device-side packer: same image as pnr_mlp_pack (backward = 0) / pnr_mlp_pack_bwd (backward = 1), written
+ * straight from the live parameter tensors on the GPU -- no host round trip per optimiser step.
+ * params_dev: the struct itself (and its pts_w / pts_b pointer arrays) in HOST memory, every pointer in it a
+ * DEVICE pointer.  workspace: device scratch of pnr_mlp_pack_workspace_bytes bytes (fragment descriptors).
+ * packed: device buffer of pnr_mlp_packed_bytes / pnr_mlp_bwd_packed_bytes bytes.  Three small host->device
+ * copies (header, chunk table, descriptors) and one kernel are enqueued on `stream`. */
+int64_t pnr_mlp_pack_workspace_bytes(const pnr_mlp_desc* desc, int backward);
+int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
+                        void* workspace, void* packed, void* stream);
+
 /* Evaluate the network on every sample of every ray:
  *   pts = o + d*z, viewdir = d/||d||, raw = MLP(gamma(pts), gamma(viewdir)).
  * packed: device copy of the pnr_mlp_pack image.  rays (R,8), z (R,N).

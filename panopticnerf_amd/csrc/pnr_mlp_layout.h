@@ -33,6 +33,12 @@
 
 #include "pnr.h"
 
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PNR_HD __host__ __device__
+#else
+#define PNR_HD
+#endif
+
 #define PNR_PACK_MAGIC 0x504e5231u /* "PNR1" */
 #define PNR_FRAG_BYTES 1024
 
@@ -46,8 +52,8 @@ struct pnr_pack_header {
 };                                   // 128 bytes
 struct pnr_chunk_entry { uint32_t off_frag, nfrag; };   // offset from data_off in fragments
 
-static inline int pnr_row_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-static inline int pnr_kpl(int precision) { return precision == 0 ? 8 : 4; }
+PNR_HD static inline int pnr_row_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+PNR_HD static inline int pnr_kpl(int precision) { return precision == 0 ? 8 : 4; }
 
 enum { PNR_SEG_GX = 0, PNR_SEG_GD = 1, PNR_SEG_FEAT = 2 };
 
@@ -67,7 +73,7 @@ static constexpr int pnr_layer_fbc(int kind, int precision)
 }
 
 // canonical column (within the segment's own canonical vector) of lane-vector slot (hi, v); -1 = pad
-static inline int pnr_seg_col(int kind, int L, int hi, int v)
+PNR_HD static inline int pnr_seg_col(int kind, int L, int hi, int v)
 {
     if (kind == PNR_SEG_FEAT) return (v >> 4) * 32 + pnr_row_of(v & 15, hi);
     const int nfh = (kind == PNR_SEG_GX) ? 5 : 2;   // frequencies per half-wave
@@ -108,4 +114,57 @@ static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* a
     dys_off[3] = take(d.W / 2);
     for (int l = 0; l < d.D; ++l) dys_off[4 + l] = take(d.W);
     dys_off[4 + d.D] = o;
+}
+
+// ---- fragment descriptors: ONE description of where every element of a packed image comes from, consumed by
+// the host packer (pnr_mlp_pack / pnr_mlp_pack_bwd) and by the device packer (pnr_mlp_pack_device), so the two
+// produce identical images by construction.
+enum { PNR_F_WEIGHT = 0, PNR_F_WEIGHT_T = 1, PNR_F_BIAS = 2 };
+struct PnrFragDesc {
+    const float* src;       // weight matrix, row-major (out,in); bias vector for PNR_F_BIAS; null => zeros
+    const float* src2;      // PNR_F_BIAS: second bias vector (rgb/sigma block), else unused
+    int32_t kind;           // PNR_F_*
+    int32_t ld, col_off;    // leading dimension, first column of this k-segment / of the h columns (transposed)
+    int32_t row0;           // first row of the fragment's 32-row block (forward: output rows; transposed: input rows)
+    int32_t lo, hi, off;    // forward: valid output-row window [lo,hi) and row offset into src
+                            // transposed: valid window of the k index o (forward OUTPUT feature) and its offset into src
+                            // bias: window / offset of src
+    int32_t lo2, hi2, off2; // bias: window / offset of src2
+    int32_t seg_kind, L, ks;// forward: slot map of the k dimension (pnr_seg_col) and the k-step
+    int32_t nblk;           // bias: 32-row blocks in the fragment
+    int32_t pad[2];
+};
+
+// value of element j (k-slot within the k-step) of lane `lane` of a weight fragment
+PNR_HD static inline float pnr_frag_value(const PnrFragDesc& d, int kpl, int lane, int j)
+{
+    if (!d.src) return 0.0f;
+    const int i = lane & 31, hi = lane >> 5;
+    if (d.kind == PNR_F_WEIGHT) {
+        const int row = d.row0 + i;
+        const int col = pnr_seg_col(d.seg_kind, d.L, hi, d.ks * kpl + j);
+        if (row < d.lo || row >= d.hi || col < 0) return 0.0f;
+        return d.src[(int64_t)(row - d.off) * d.ld + d.col_off + col];
+    }
+    const int irow = d.row0 + i;                                   // transposed: rows are INPUT features
+    const int o = pnr_seg_col(PNR_SEG_FEAT, 0, hi, d.ks * kpl + j);
+    if (o < d.lo || o >= d.hi) return 0.0f;
+    return d.src[(int64_t)(o - d.off) * d.ld + d.col_off + irow];
+}
+PNR_HD static inline float pnr_bias_value(const PnrFragDesc& d, int idx)      // idx = block*32 + row in block
+{
+    if (idx >= d.nblk * 32) return 0.0f;
+    const int row = d.row0 + idx;
+    if (d.src && row >= d.lo && row < d.hi) return d.src[row - d.off];
+    if (d.src2 && row >= d.lo2 && row < d.hi2) return d.src2[row - d.off2];
+    return 0.0f;
+}
+PNR_HD static inline uint16_t pnr_f32_to_bf16(float f)
+{
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
 }

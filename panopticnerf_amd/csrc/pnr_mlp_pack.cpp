@@ -1,6 +1,8 @@
-// Host-side packer: dense nn.Linear parameters -> MFMA-fragment-ordered image
-// (layout: pnr_mlp_layout.h).  Pure CPU code; replaces nothing in the reference -- it is the
-// load-time counterpart of Network.__init__ / load_state_dict.
+// Packer: dense nn.Linear parameters -> MFMA-fragment-ordered image (layout: pnr_mlp_layout.h), forward and
+// transposed (backward) images, on the host (pnr_mlp_pack, pnr_mlp_pack_bwd) or on the device
+// (pnr_mlp_pack_device: reads the live parameter tensors, no host round trip per optimiser step).
+// Both go through the same fragment descriptors.  Replaces nothing in the reference -- it is the load-time
+// counterpart of Network.__init__ / load_state_dict.
 #include <math.h>
 #include <string.h>
 
@@ -9,16 +11,6 @@
 #include "pnr_common.h"
 #include "pnr_mlp_layout.h"
 #include "pnr_mlp_plan.h"
-
-static uint16_t f32_to_bf16_rne(float f)
-{
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
-    const uint32_t lsb = (u >> 16) & 1u;
-    u += 0x7fffu + lsb;
-    return (uint16_t)(u >> 16);
-}
 
 int pnr_mlp_validate(const pnr_mlp_desc* d)
 {
@@ -37,6 +29,186 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
     return PNR_OK;
 }
 
+static int bwd_validate(const pnr_mlp_desc* d)
+{
+    int rc = pnr_mlp_validate(d);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
+    PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
+                "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
+    return PNR_OK;
+}
+
+static int check_params(const pnr_mlp_desc* desc, const pnr_mlp_params_host* p, bool bias)
+{
+    PNR_REQUIRE(p, "pnr_mlp_pack: null params");
+    PNR_REQUIRE(p->pts_w && p->alpha_w && p->feature_w && p->views_w && p->rgb_w, "pnr_mlp_pack: missing trunk parameter");
+    if (bias) PNR_REQUIRE(p->pts_b && p->alpha_b && p->feature_b && p->views_b && p->rgb_b, "pnr_mlp_pack: missing trunk bias");
+    if (desc->n_sem) PNR_REQUIRE(p->sem0_w && p->sem1_w && (!bias || (p->sem0_b && p->sem1_b)), "pnr_mlp_pack: missing semantic head");
+    if (desc->n_inst) PNR_REQUIRE(p->inst0_w && p->inst1_w && (!bias || (p->inst0_b && p->inst1_b)), "pnr_mlp_pack: missing instance head");
+    return PNR_OK;
+}
+
+// ------------------------------------------------------------------------------- descriptors
+struct Image {
+    pnr_pack_header hdr;
+    std::vector<pnr_chunk_entry> table;
+    std::vector<PnrFragDesc> frags;      // one per fragment of the data area, in order
+    size_t table_off, data_off, total_bytes;
+};
+
+static PnrFragDesc zero_desc()
+{
+    PnrFragDesc f;
+    memset(&f, 0, sizeof(f));
+    return f;
+}
+
+static void fill_header(Image& im, const pnr_mlp_desc& d, int version, size_t n_chunks, int max_frags, size_t table_off,
+                        size_t data_off, size_t total)
+{
+    memset(&im.hdr, 0, sizeof(im.hdr));
+    im.hdr.magic = PNR_PACK_MAGIC;
+    im.hdr.version = (uint32_t)version;
+    im.hdr.n_chunks = (uint32_t)n_chunks;
+    im.hdr.max_chunk_frags = (uint32_t)max_frags;
+    im.hdr.table_off = (uint32_t)table_off;
+    im.hdr.data_off = (uint32_t)data_off;
+    im.hdr.total_bytes = total;
+    memcpy(im.hdr.desc, &d, sizeof(pnr_mlp_desc));
+    im.table_off = table_off; im.data_off = data_off; im.total_bytes = total;
+}
+
+static void describe_forward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p, Image& im)
+{
+    PnrPlan plan;
+    pnr_build_plan(d, plan);
+    fill_header(im, d, 1, plan.chunks.size(), plan.max_chunk_frags, plan.table_off, plan.data_off, plan.total_bytes);
+    const int W = d.W, H = W / 2, EX = 3 + 6 * d.xyz_L, ED = 3 + 6 * d.dir_L;
+    const int kpl = pnr_kpl(d.precision);
+    for (const PnrChunk& ch : plan.chunks) {
+        const PnrLayer& L = plan.layers[ch.layer];
+        im.table.push_back({(uint32_t)ch.off_frag, (uint32_t)ch.nfrag});
+        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
+            for (int seg = 0; seg < L.nseg; ++seg) {
+                const int kind = L.seg_kind[seg];
+                const int nks = pnr_seg_vl(kind, L.seg_nfeat[seg]) / kpl;
+                for (int ks = 0; ks < nks; ++ks) {
+                    PnrFragDesc f = zero_desc();
+                    f.kind = PNR_F_WEIGHT;
+                    f.row0 = (ch.fb + fbl) * 32;
+                    f.lo = 0; f.hi = L.out_dim; f.off = 0;
+                    f.seg_kind = kind; f.L = kind == PNR_SEG_GX ? d.xyz_L : d.dir_L; f.ks = ks;
+                    switch (L.kind) {
+                    case PNR_L_TRUNK0: f.src = p.pts_w[0]; f.ld = EX; break;
+                    case PNR_L_TRUNK:
+                        f.src = p.pts_w[L.index];
+                        if (L.nseg == 2) { f.ld = EX + W; f.col_off = seg == 0 ? 0 : EX; }      // [gamma(x), h]
+                        else f.ld = W;
+                        break;
+                    case PNR_L_SEM0: f.src = p.sem0_w; f.ld = W; break;
+                    case PNR_L_SEM1: f.src = p.sem1_w; f.ld = H; break;
+                    case PNR_L_INST0: f.src = p.inst0_w; f.ld = W; break;
+                    case PNR_L_INST1: f.src = p.inst1_w; f.ld = H; break;
+                    case PNR_L_FEATURE: f.src = p.feature_w; f.ld = W; break;
+                    case PNR_L_VIEWS: f.src = p.views_w; f.ld = W + ED; f.col_off = seg == 0 ? 0 : W; break;   // [feature, gamma(d)]
+                    case PNR_L_RGBSIGMA:
+                        if (seg == 0) { f.src = p.rgb_w; f.ld = H; f.lo = 0; f.hi = 3; f.off = 0; }             // rows 0..2 <- g
+                        else { f.src = p.alpha_w; f.ld = W; f.lo = 3; f.hi = 4; f.off = 3; }                    // row 3 <- h
+                        break;
+                    }
+                    im.frags.push_back(f);
+                }
+            }
+        }
+        PnrFragDesc b = zero_desc();
+        b.kind = PNR_F_BIAS;
+        b.row0 = ch.fb * 32; b.nblk = ch.nfb;
+        b.lo = 0; b.hi = L.out_dim; b.off = 0;
+        switch (L.kind) {
+        case PNR_L_TRUNK0: case PNR_L_TRUNK: b.src = p.pts_b[L.index]; break;
+        case PNR_L_SEM0: b.src = p.sem0_b; break;
+        case PNR_L_SEM1: b.src = p.sem1_b; break;
+        case PNR_L_INST0: b.src = p.inst0_b; break;
+        case PNR_L_INST1: b.src = p.inst1_b; break;
+        case PNR_L_FEATURE: b.src = p.feature_b; break;
+        case PNR_L_VIEWS: b.src = p.views_b; break;
+        case PNR_L_RGBSIGMA: b.src = p.rgb_b; b.lo = 0; b.hi = 3; b.src2 = p.alpha_b; b.lo2 = 3; b.hi2 = 4; b.off2 = 3; break;
+        }
+        im.frags.push_back(b);
+    }
+}
+
+static void describe_backward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p, Image& im)
+{
+    PnrBPlan plan;
+    pnr_build_bwd_plan(d, plan);
+    fill_header(im, d, 2, plan.chunks.size(), plan.max_chunk_frags, plan.table_off, plan.data_off, plan.total_bytes);
+    const int W = d.W, H = W / 2, EX = 3 + 6 * d.xyz_L, ED = 3 + 6 * d.dir_L;
+    for (const PnrChunk& ch : plan.chunks) {
+        const PnrBLayer& L = plan.layers[ch.layer];
+        im.table.push_back({(uint32_t)ch.off_frag, (uint32_t)ch.nfrag});
+        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
+            for (int seg = 0; seg < L.nseg; ++seg) {
+                for (int ks = 0; ks < L.seg_slots[seg] / 16; ++ks) {
+                    PnrFragDesc f = zero_desc();
+                    f.kind = PNR_F_WEIGHT_T;
+                    f.row0 = (ch.fb + fbl) * 32;        // input-feature rows
+                    f.ks = ks;
+                    switch (L.seg_kind[seg]) {
+                    case PNR_K_RGBS:
+                        if (L.kind == PNR_B_DG) { f.src = p.rgb_w; f.ld = H; f.lo = 0; f.hi = 3; f.off = 0; }      // d g
+                        else { f.src = p.alpha_w; f.ld = W; f.lo = 3; f.hi = 4; f.off = 3; }                        // d h (sigma)
+                        break;
+                    case PNR_K_VIEWS: f.src = p.views_w; f.ld = W + ED; f.lo = 0; f.hi = H; break;                   // feature columns
+                    case PNR_K_SEM1: f.src = d.n_sem ? p.sem1_w : nullptr; f.ld = H; f.lo = 0; f.hi = d.n_sem; break;
+                    case PNR_K_INST1: f.src = d.n_inst ? p.inst1_w : nullptr; f.ld = H; f.lo = 0; f.hi = d.n_inst; break;
+                    case PNR_K_FEATURE: f.src = p.feature_w; f.ld = W; f.lo = 0; f.hi = W; break;
+                    case PNR_K_SEM0: f.src = d.n_sem ? p.sem0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; break;
+                    case PNR_K_INST0: f.src = d.n_inst ? p.inst0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; break;
+                    case PNR_K_TRUNK: {
+                        const bool sk = (L.index - 1 == d.skip);
+                        f.src = p.pts_w[L.index]; f.ld = sk ? EX + W : W; f.col_off = sk ? EX : 0; f.lo = 0; f.hi = W;
+                        break;
+                    }
+                    }
+                    im.frags.push_back(f);
+                }
+            }
+        }
+    }
+}
+
+static void fill_fragment_host(const PnrFragDesc& f, int precision, uint8_t* frag)
+{
+    const int kpl = pnr_kpl(precision);
+    if (f.kind == PNR_F_BIAS) {
+        float* b = (float*)frag;
+        for (int i = 0; i < 256; ++i) b[i] = pnr_bias_value(f, i);
+        return;
+    }
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < kpl; ++j) {
+            const float w = pnr_frag_value(f, kpl, lane, j);
+            if (precision == PNR_PREC_BF16) {
+                const uint16_t h = pnr_f32_to_bf16(w);
+                memcpy(frag + lane * 16 + j * 2, &h, 2);
+            } else {
+                memcpy(frag + lane * 16 + j * 4, &w, 4);
+            }
+        }
+}
+
+static void write_host(const Image& im, int precision, void* out)
+{
+    uint8_t* img = (uint8_t*)out;
+    memset(img, 0, im.total_bytes);
+    memcpy(img, &im.hdr, sizeof(im.hdr));
+    memcpy(img + im.table_off, im.table.data(), im.table.size() * sizeof(pnr_chunk_entry));
+    for (size_t i = 0; i < im.frags.size(); ++i) fill_fragment_host(im.frags[i], precision, img + im.data_off + i * PNR_FRAG_BYTES);
+}
+
+// ------------------------------------------------------------------------------- host API
 PNR_EXPORT int64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc)
 {
     if (pnr_mlp_validate(desc) != PNR_OK) return PNR_EINVAL;
@@ -49,127 +221,11 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(p && packed_host, "pnr_mlp_pack: null pointer");
-    PNR_REQUIRE(p->pts_w && p->pts_b && p->alpha_w && p->alpha_b && p->feature_w && p->feature_b && p->views_w &&
-                    p->views_b && p->rgb_w && p->rgb_b,
-                "pnr_mlp_pack: missing trunk parameter");
-    if (desc->n_sem) PNR_REQUIRE(p->sem0_w && p->sem0_b && p->sem1_w && p->sem1_b, "pnr_mlp_pack: missing semantic head");
-    if (desc->n_inst) PNR_REQUIRE(p->inst0_w && p->inst0_b && p->inst1_w && p->inst1_b, "pnr_mlp_pack: missing instance head");
-
-    PnrPlan plan;
-    pnr_build_plan(*desc, plan);
-    uint8_t* img = (uint8_t*)packed_host;
-    memset(img, 0, plan.total_bytes);
-
-    pnr_pack_header hdr;
-    memset(&hdr, 0, sizeof(hdr));
-    hdr.magic = PNR_PACK_MAGIC;
-    hdr.version = 1;
-    hdr.n_chunks = (uint32_t)plan.chunks.size();
-    hdr.max_chunk_frags = (uint32_t)plan.max_chunk_frags;
-    hdr.table_off = (uint32_t)plan.table_off;
-    hdr.data_off = (uint32_t)plan.data_off;
-    hdr.total_bytes = plan.total_bytes;
-    memcpy(hdr.desc, desc, sizeof(pnr_mlp_desc));
-    memcpy(img, &hdr, sizeof(hdr));
-    pnr_chunk_entry* table = (pnr_chunk_entry*)(img + plan.table_off);
-
-    const int W = desc->W, EX = 3 + 6 * desc->xyz_L, ED = 3 + 6 * desc->dir_L;
-    const int kpl = pnr_kpl(desc->precision);
-    const bool bf16 = desc->precision == PNR_PREC_BF16;
-
-    for (size_t ci = 0; ci < plan.chunks.size(); ++ci) {
-        const PnrChunk& ch = plan.chunks[ci];
-        const PnrLayer& L = plan.layers[ch.layer];
-        table[ci].off_frag = (uint32_t)ch.off_frag;
-        table[ci].nfrag = (uint32_t)ch.nfrag;
-        uint8_t* base = img + plan.data_off + (size_t)ch.off_frag * PNR_FRAG_BYTES;
-        // Resolve (out row, segment, canonical column) -> weight value for this layer.
-        auto weight = [&](int row, int seg, int col) -> float {
-            if (row >= L.out_dim || col < 0) return 0.0f;
-            switch (L.kind) {
-            case PNR_L_TRUNK0:
-            case PNR_L_TRUNK: {
-                const int i = L.index;
-                const float* Wm = p->pts_w[i];
-                if (i == 0) return Wm[(size_t)row * EX + col];                      // [gamma(x)]
-                if (L.nseg == 2)                                                     // [gamma(x), h]
-                    return Wm[(size_t)row * (EX + W) + (seg == 0 ? col : EX + col)];
-                return Wm[(size_t)row * W + col];                                    // [h]
-            }
-            case PNR_L_SEM0: return p->sem0_w[(size_t)row * W + col];
-            case PNR_L_SEM1: return p->sem1_w[(size_t)row * desc->head_W + col];
-            case PNR_L_INST0: return p->inst0_w[(size_t)row * W + col];
-            case PNR_L_INST1: return p->inst1_w[(size_t)row * desc->head_W + col];
-            case PNR_L_FEATURE: return p->feature_w[(size_t)row * W + col];
-            case PNR_L_VIEWS: {
-                if (seg == 1 && col >= ED) return 0.0f;
-                const int c = seg == 0 ? col : W + col;            // [feature, gamma(d)]
-                return p->views_w[(size_t)row * (W + ED) + c];
-            }
-            case PNR_L_RGBSIGMA:
-                if (seg == 0) return row < 3 ? p->rgb_w[(size_t)row * (W / 2) + col] : 0.0f;
-                return row == 3 ? p->alpha_w[col] : 0.0f;
-            }
-            return 0.0f;
-        };
-        auto bias = [&](int row) -> float {
-            if (row >= L.out_dim) return 0.0f;
-            switch (L.kind) {
-            case PNR_L_TRUNK0:
-            case PNR_L_TRUNK: return p->pts_b[L.index][row];
-            case PNR_L_SEM0: return p->sem0_b[row];
-            case PNR_L_SEM1: return p->sem1_b[row];
-            case PNR_L_INST0: return p->inst0_b[row];
-            case PNR_L_INST1: return p->inst1_b[row];
-            case PNR_L_FEATURE: return p->feature_b[row];
-            case PNR_L_VIEWS: return p->views_b[row];
-            case PNR_L_RGBSIGMA: return row < 3 ? p->rgb_b[row] : p->alpha_b[0];
-            }
-            return 0.0f;
-        };
-        int frag_idx = 0;
-        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
-            const int fb = ch.fb + fbl;
-            for (int seg = 0; seg < L.nseg; ++seg) {
-                const int kind = L.seg_kind[seg];
-                const int vl = pnr_seg_vl(kind, L.seg_nfeat[seg]);
-                const int Lf = kind == PNR_SEG_GX ? desc->xyz_L : desc->dir_L;
-                for (int ks = 0; ks < vl / kpl; ++ks, ++frag_idx) {
-                    uint8_t* frag = base + (size_t)frag_idx * PNR_FRAG_BYTES;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int i = lane & 31, hi = lane >> 5;
-                        const int row = fb * 32 + i;
-                        for (int j = 0; j < kpl; ++j) {
-                            const int col = pnr_seg_col(kind, Lf, hi, ks * kpl + j);
-                            const float w = weight(row, seg, col);
-                            if (bf16) {
-                                const uint16_t h = f32_to_bf16_rne(w);
-                                memcpy(frag + lane * 16 + j * 2, &h, 2);
-                            } else {
-                                memcpy(frag + lane * 16 + j * 4, &w, 4);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        float* bfrag = (float*)(base + (size_t)frag_idx * PNR_FRAG_BYTES);
-        for (int fbl = 0; fbl < ch.nfb; ++fbl)
-            for (int r = 0; r < 32; ++r) bfrag[fbl * 32 + r] = bias((ch.fb + fbl) * 32 + r);
-    }
-    return PNR_OK;
-}
-
-// ---- backward image: the transposed weights, same fragment format (rows = input features i of the
-// forward layer, k = its output features o in FEAT slot order).  bf16.
-static int bwd_validate(const pnr_mlp_desc* d)
-{
-    int rc = pnr_mlp_validate(d);
-    if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
-    PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
-                "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
+    PNR_REQUIRE(packed_host, "pnr_mlp_pack: null pointer");
+    if ((rc = check_params(desc, p, true)) != PNR_OK) return rc;
+    Image im;
+    describe_forward(*desc, *p, im);
+    write_host(im, desc->precision, packed_host);
     return PNR_OK;
 }
 
@@ -185,72 +241,72 @@ PNR_EXPORT int pnr_mlp_pack_bwd(const pnr_mlp_desc* desc, const pnr_mlp_params_h
 {
     int rc = bwd_validate(desc);
     if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(p && packed_host, "pnr_mlp_pack_bwd: null pointer");
-    PNR_REQUIRE(p->pts_w && p->alpha_w && p->feature_w && p->views_w && p->rgb_w, "pnr_mlp_pack_bwd: missing trunk parameter");
-    if (desc->n_sem) PNR_REQUIRE(p->sem0_w && p->sem1_w, "pnr_mlp_pack_bwd: missing semantic head");
-    if (desc->n_inst) PNR_REQUIRE(p->inst0_w && p->inst1_w, "pnr_mlp_pack_bwd: missing instance head");
-    PnrBPlan plan;
-    pnr_build_bwd_plan(*desc, plan);
-    uint8_t* img = (uint8_t*)packed_host;
-    memset(img, 0, plan.total_bytes);
-    pnr_pack_header hdr;
-    memset(&hdr, 0, sizeof(hdr));
-    hdr.magic = PNR_PACK_MAGIC;
-    hdr.version = 2;
-    hdr.n_chunks = (uint32_t)plan.chunks.size();
-    hdr.max_chunk_frags = (uint32_t)plan.max_chunk_frags;
-    hdr.table_off = (uint32_t)plan.table_off;
-    hdr.data_off = (uint32_t)plan.data_off;
-    hdr.total_bytes = plan.total_bytes;
-    memcpy(hdr.desc, desc, sizeof(pnr_mlp_desc));
-    memcpy(img, &hdr, sizeof(hdr));
-    pnr_chunk_entry* table = (pnr_chunk_entry*)(img + plan.table_off);
-    const int W = desc->W, H = W / 2, EX = 3 + 6 * desc->xyz_L, ED = 3 + 6 * desc->dir_L;
+    PNR_REQUIRE(packed_host, "pnr_mlp_pack_bwd: null pointer");
+    if ((rc = check_params(desc, p, false)) != PNR_OK) return rc;
+    Image im;
+    describe_backward(*desc, *p, im);
+    write_host(im, PNR_PREC_BF16, packed_host);
+    return PNR_OK;
+}
 
-    for (size_t ci = 0; ci < plan.chunks.size(); ++ci) {
-        const PnrChunk& ch = plan.chunks[ci];
-        const PnrBLayer& L = plan.layers[ch.layer];
-        table[ci].off_frag = (uint32_t)ch.off_frag;
-        table[ci].nfrag = (uint32_t)ch.nfrag;
-        uint8_t* base = img + plan.data_off + (size_t)ch.off_frag * PNR_FRAG_BYTES;
-        // W_forward[o][i] of the k-segment's layer, 0 outside it
-        auto wt = [&](int kseg, int o, int i) -> float {
-            switch (kseg) {
-            case PNR_K_RGBS:
-                if (L.kind == PNR_B_DG) return o < 3 ? p->rgb_w[(size_t)o * H + i] : 0.0f;     // d g
-                return o == 3 ? p->alpha_w[i] : 0.0f;                                          // d h (sigma row)
-            case PNR_K_VIEWS: return o < H ? p->views_w[(size_t)o * (W + ED) + i] : 0.0f;      // feature columns
-            case PNR_K_SEM1: return (desc->n_sem && o < desc->n_sem) ? p->sem1_w[(size_t)o * H + i] : 0.0f;
-            case PNR_K_INST1: return (desc->n_inst && o < desc->n_inst) ? p->inst1_w[(size_t)o * H + i] : 0.0f;
-            case PNR_K_FEATURE: return p->feature_w[(size_t)o * W + i];
-            case PNR_K_SEM0: return desc->n_sem ? p->sem0_w[(size_t)o * W + i] : 0.0f;
-            case PNR_K_INST0: return desc->n_inst ? p->inst0_w[(size_t)o * W + i] : 0.0f;
-            case PNR_K_TRUNK: {
-                const int l = L.index;
-                const bool sk = (l - 1 == desc->skip);
-                return p->pts_w[l][(size_t)o * (sk ? EX + W : W) + (sk ? EX + i : i)];
-            }
-            }
-            return 0.0f;
-        };
-        int frag_idx = 0;
-        for (int fbl = 0; fbl < ch.nfb; ++fbl) {
-            const int fb = ch.fb + fbl;
-            for (int seg = 0; seg < L.nseg; ++seg) {
-                const int vl = L.seg_slots[seg] / 2;
-                for (int ks = 0; ks < vl / 8; ++ks, ++frag_idx) {
-                    uint8_t* frag = base + (size_t)frag_idx * PNR_FRAG_BYTES;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int irow = fb * 32 + (lane & 31), hi = lane >> 5;
-                        for (int j = 0; j < 8; ++j) {
-                            const int o = pnr_seg_col(PNR_SEG_FEAT, 0, hi, ks * 8 + j);
-                            const uint16_t h = f32_to_bf16_rne(wt(L.seg_kind[seg], o, irow));
-                            memcpy(frag + lane * 16 + j * 2, &h, 2);
-                        }
-                    }
-                }
-            }
+// ------------------------------------------------------------------------------- device packer
+// One 64-lane workgroup per fragment; lane l fills its own 16 bytes (the kernel's ds_read_b128 unit).
+__global__ __launch_bounds__(64) void k_pack_fragments(const PnrFragDesc* __restrict__ descs, int n_frags, int precision,
+                                                       uint8_t* __restrict__ data)
+{
+    const int lane = threadIdx.x;
+    for (int fi = blockIdx.x; fi < n_frags; fi += gridDim.x) {
+        const PnrFragDesc f = descs[fi];
+        uint32_t w[4];
+        if (f.kind == PNR_F_BIAS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(pnr_bias_value(f, lane * 4 + j));
+        } else if (precision == PNR_PREC_BF16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = (uint32_t)pnr_f32_to_bf16(pnr_frag_value(f, 8, lane, 2 * j)) |
+                       ((uint32_t)pnr_f32_to_bf16(pnr_frag_value(f, 8, lane, 2 * j + 1)) << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(pnr_frag_value(f, 4, lane, j));
         }
+        *reinterpret_cast<uint4*>(data + (size_t)fi * PNR_FRAG_BYTES + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+static int describe(const pnr_mlp_desc* desc, const pnr_mlp_params_host* p, int backward, Image& im)
+{
+    int rc = backward ? bwd_validate(desc) : pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    if ((rc = check_params(desc, p, !backward)) != PNR_OK) return rc;
+    if (backward) describe_backward(*desc, *p, im); else describe_forward(*desc, *p, im);
+    return PNR_OK;
+}
+
+PNR_EXPORT int64_t pnr_mlp_pack_workspace_bytes(const pnr_mlp_desc* desc, int backward)
+{
+    const int64_t total = backward ? pnr_mlp_bwd_packed_bytes(desc) : pnr_mlp_packed_bytes(desc);
+    if (total < 0) return total;
+    return (total / PNR_FRAG_BYTES + 1) * (int64_t)sizeof(PnrFragDesc);      // >= one descriptor per fragment
+}
+
+PNR_EXPORT int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
+                                   void* workspace, void* packed, void* stream)
+{
+    PNR_REQUIRE(workspace && packed, "pnr_mlp_pack_device: null pointer");
+    Image im;
+    int rc = describe(desc, params_dev, backward, im);
+    if (rc != PNR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // header + chunk table, then the descriptors: small pageable-host copies (staged by the runtime before
+    // they return, so the local vectors may go out of scope); ordered on `st` before the kernel.
+    PNR_HIP(hipMemcpyAsync(packed, &im.hdr, sizeof(im.hdr), hipMemcpyHostToDevice, st));
+    PNR_HIP(hipMemcpyAsync((uint8_t*)packed + im.table_off, im.table.data(), im.table.size() * sizeof(pnr_chunk_entry),
+                           hipMemcpyHostToDevice, st));
+    PNR_HIP(hipMemcpyAsync(workspace, im.frags.data(), im.frags.size() * sizeof(PnrFragDesc), hipMemcpyHostToDevice, st));
+    const int n = (int)im.frags.size();
+    hipLaunchKernelGGL(k_pack_fragments, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, (const PnrFragDesc*)workspace, n,
+                       backward ? PNR_PREC_BF16 : desc->precision, (uint8_t*)packed + im.data_off);
+    PNR_CHECK_LAUNCH("pnr_mlp_pack_device");
     return PNR_OK;
 }

@@ -68,31 +68,32 @@ class Network(nn.Module):
     def _version(self, level):
         return tuple(p._version for p in self.nerf(level).parameters())
 
-    def packed(self, level, device, precision=None):
-        """(desc, packed device image) of level's NeRF; rebuilt when any parameter changed."""
-        precision = precision or self.precision
-        key = (level if self.nerf_1 is not None else 0, str(device), precision)
+    def _pack(self, level, device, precision, backward):
+        """(desc, packed image on `device`) of level's NeRF, rebuilt when any parameter changed.  When the
+        parameters live on that GPU the image is packed there (pnr_mlp_pack_device, buffers reused); otherwise
+        on the host and uploaded."""
+        key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision)
         ver = self._version(level)
         hit = self._packed.get(key)
-        if hit is None or hit[0] != ver:
-            net = self.nerf(level)
-            desc = net.desc(precision)
-            sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-            img = ops.pack_mlp(desc, sd).to(device)
-            self._packed[key] = hit = (ver, desc, img)
-        return hit[1], hit[2]
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        net = self.nerf(level)
+        desc = net.desc(precision)
+        sd = dict(net.named_parameters())
+        on_dev = torch.device(device).type == "cuda" and all(p.device == torch.device(device) for p in sd.values())
+        if on_dev:
+            img, ws = ops.pack_mlp_device(desc, sd, backward, hit[2] if hit else None, hit[3] if hit else None)
+        else:
+            sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+            img, ws = (ops.pack_mlp_bwd if backward else ops.pack_mlp)(desc, sd).to(device), None
+        self._packed[key] = (ver, desc, img, ws)
+        return desc, img
+
+    def packed(self, level, device, precision=None):
+        return self._pack(level, device, precision or self.precision, False)
 
     def packed_bwd(self, level, device):
-        """Transposed-weight image of level's NeRF for the backward kernel (bf16); rebuilt on parameter change."""
-        key = ("bwd", level if self.nerf_1 is not None else 0, str(device))
-        ver = self._version(level)
-        hit = self._packed.get(key)
-        if hit is None or hit[0] != ver:
-            net = self.nerf(level)
-            desc = net.desc("bf16")
-            sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-            self._packed[key] = hit = (ver, desc, ops.pack_mlp_bwd(desc, sd).to(device))
-        return hit[1], hit[2]
+        return self._pack(level, device, "bf16", True)
 
     def forward(self, *a, **k):
         raise RuntimeError("Network is evaluated by Renderer.render() through the fused HIP kernel; "

@@ -73,19 +73,17 @@ def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=N
     return d
 
 
-def pack_mlp(desc, params):
-    """params: dict name -> CPU float32 tensor (canonical NeRF names, see network.py).
-    Returns the packed image as a CPU uint8 tensor (pure host work, no GPU needed)."""
-    lib = _lib.load()
-    nbytes = lib.pnr_mlp_packed_bytes(ctypes.byref(desc))
-    if nbytes < 0:
-        _lib.check(int(nbytes), "pnr_mlp_packed_bytes")
+def _param_struct(desc, params, device):
+    """pnr_mlp_params_host filled with pointers to `params` (dict name -> tensor) moved/kept on `device`.
+    Returns (struct, keep-alive list)."""
     keep = []
 
     def fp(name):
         if name not in params:
             return None
-        t = params[name].detach().to("cpu", torch.float32).contiguous()
+        t = params[name].detach()
+        if t.device != torch.device(device) or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device, torch.float32).contiguous()
         keep.append(t)
         return ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
 
@@ -93,6 +91,7 @@ def pack_mlp(desc, params):
     D = desc.D
     pw = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.weight") for i in range(D)])
     pb = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.bias") for i in range(D)])
+    keep += [pw, pb]
     P.pts_w, P.pts_b = pw, pb
     P.alpha_w, P.alpha_b = fp("alpha_linear.weight"), fp("alpha_linear.bias")
     P.feature_w, P.feature_b = fp("feature_linear.weight"), fp("feature_linear.bias")
@@ -104,6 +103,38 @@ def pack_mlp(desc, params):
     if desc.n_inst:
         P.inst0_w, P.inst0_b = fp("instance_linears.0.weight"), fp("instance_linears.0.bias")
         P.inst1_w, P.inst1_b = fp("instance_linears.1.weight"), fp("instance_linears.1.bias")
+    return P, keep
+
+
+def pack_mlp_device(desc, params, backward=False, out=None, workspace=None):
+    """Pack on the GPU straight from the (CUDA, fp32) parameter tensors: pnr_mlp_pack_device.
+    Returns (image uint8 CUDA tensor, workspace) -- pass both back in to reuse the buffers."""
+    lib = _lib.load()
+    dev = next(iter(params.values())).device
+    if dev.type != "cuda":
+        raise RuntimeError("pack_mlp_device: parameters must be on the GPU")
+    nbytes = (lib.pnr_mlp_bwd_packed_bytes if backward else lib.pnr_mlp_packed_bytes)(ctypes.byref(desc))
+    if nbytes < 0:
+        _lib.check(int(nbytes), "pnr_mlp_packed_bytes")
+    wbytes = lib.pnr_mlp_pack_workspace_bytes(ctypes.byref(desc), int(backward))
+    if out is None or out.numel() != nbytes:
+        out = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)     # zeros: the table->data alignment gap
+    if workspace is None or workspace.numel() < wbytes:
+        workspace = torch.empty(int(wbytes), dtype=torch.uint8, device=dev)
+    P, keep = _param_struct(desc, params, dev)
+    _lib.check(lib.pnr_mlp_pack_device(ctypes.byref(desc), ctypes.byref(P), int(backward), _p(workspace), _p(out),
+                                       _stream()), "pnr_mlp_pack_device")
+    return out, workspace
+
+
+def pack_mlp(desc, params):
+    """params: dict name -> float32 tensor (canonical NeRF names, see network.py).
+    Returns the packed image as a CPU uint8 tensor (pure host work, no GPU needed)."""
+    lib = _lib.load()
+    nbytes = lib.pnr_mlp_packed_bytes(ctypes.byref(desc))
+    if nbytes < 0:
+        _lib.check(int(nbytes), "pnr_mlp_packed_bytes")
+    P, keep = _param_struct(desc, params, "cpu")
     img = torch.empty(int(nbytes), dtype=torch.uint8)
     _lib.check(lib.pnr_mlp_pack(ctypes.byref(desc), ctypes.byref(P), ctypes.c_void_p(img.data_ptr())),
                "pnr_mlp_pack")
@@ -116,28 +147,7 @@ def pack_mlp_bwd(desc, params):
     nbytes = lib.pnr_mlp_bwd_packed_bytes(ctypes.byref(desc))
     if nbytes < 0:
         _lib.check(int(nbytes), "pnr_mlp_bwd_packed_bytes")
-    keep = []
-
-    def fp(name):
-        if name not in params:
-            return None
-        t = params[name].detach().to("cpu", torch.float32).contiguous()
-        keep.append(t)
-        return ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
-
-    P = MlpParamsHost()
-    D = desc.D
-    pw = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.weight") for i in range(D)])
-    pb = (ctypes.POINTER(ctypes.c_float) * D)(*[fp(f"pts_linears.{i}.bias") for i in range(D)])
-    P.pts_w, P.pts_b = pw, pb
-    P.alpha_w, P.alpha_b = fp("alpha_linear.weight"), fp("alpha_linear.bias")
-    P.feature_w, P.feature_b = fp("feature_linear.weight"), fp("feature_linear.bias")
-    P.views_w, P.views_b = fp("views_linears.0.weight"), fp("views_linears.0.bias")
-    P.rgb_w, P.rgb_b = fp("rgb_linear.weight"), fp("rgb_linear.bias")
-    if desc.n_sem:
-        P.sem0_w, P.sem1_w = fp("semantic_linears.0.weight"), fp("semantic_linears.1.weight")
-    if desc.n_inst:
-        P.inst0_w, P.inst1_w = fp("instance_linears.0.weight"), fp("instance_linears.1.weight")
+    P, keep = _param_struct(desc, params, "cpu")
     img = torch.empty(int(nbytes), dtype=torch.uint8)
     _lib.check(lib.pnr_mlp_pack_bwd(ctypes.byref(desc), ctypes.byref(P), ctypes.c_void_p(img.data_ptr())),
                "pnr_mlp_pack_bwd")
