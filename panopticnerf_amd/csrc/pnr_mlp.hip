@@ -21,10 +21,12 @@
 // HBM traffic per sample: 4 B of z (+32 B/ray) in, 4*(4+C+K) B of raw out; the kernel is
 // MFMA-bound (1.19 MFLOP/sample trunk + heads).
 //
-// Measured and rejected on MI355X (round 1, same box A/B; kept out of the code):
-// LDS-counter flow control instead of the barrier (-3 %), DMA two chunks ahead with counted vmcnt
-// (-9 %), staggering or spreading the DMA pieces through the MFMA stream (-2..-13 %), ping-pong
-// unrolling of the layer loop (-3 %, code size), one wave per SIMD with 1 or 2 tiles (-30 %).
+// Measured and rejected on MI355X (round 1, same box A/B; kept out of the code, numbers in profiles/README.md):
+// LDS-counter flow control instead of the barrier (-3 %), DMA two chunks ahead with counted vmcnt (-9 %), staggering
+// or spreading the DMA pieces / only half of the waves refilling (-0.5..-13 %), ping-pong unrolling of the layer loop
+// (-3 %), one wave per SIMD with 1 or 2 tiles (-30 %), two 4-wave workgroups per CU (-10 %), 4 blocks per hidden
+// chunk (-2 %), a phase-split weight stream (half the waves join each chunk's barrier mid-loop, 3 slots: -7..-9 %).
+// Debug: -DPNR_TRACE=1 builds stamp s_memtime per chunk phase into LDS (tools/mlp_trace.py).
 #include <string.h>
 
 #include "pnr_mlp_plan.h"
@@ -32,7 +34,6 @@
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
-
 // Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
 // save != nullptr (training, bf16): the output block is also stored slot-ordered for the backward.
 template <int PREC, int TILES, class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
@@ -58,7 +59,9 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
 #pragma unroll
             for (int t = 1; t < TILES; ++t) acc[b][t] = acc[b][0];
         }
+        c.stamp(2);
         mma_chunk<PREC, TILES, FBC, G, NA, NB>(base + c.lane * 16, inA, inB, acc);
+        c.stamp(3);
 #pragma unroll
         for (int b = 0; b < FBC; ++b) {
             const int fb = cb * FBC + b;
@@ -184,6 +187,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 
     CTX c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
           (int)((threadIdx.x & 63) >> 5), 0, 0, {0, 0}, {0, 0}};
+#if PNR_TRACE
+    c.tr = reinterpret_cast<unsigned long long*>(smem + 2 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.titer = 0;
+#endif
     const int n = c.lane & 31;
     c.start();
 
@@ -277,8 +284,18 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         uint32_t g[TILES][GR];
         layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), samp);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
+#if PNR_TRACE
+        ++c.titer;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the refill issued past the last chunk
+#if PNR_TRACE
+    __syncthreads();
+    if (blockIdx.x == 0 && a.trace) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 2 * a.slot_bytes);
+        for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------- launcher
@@ -286,7 +303,7 @@ template <int PREC, int W, int TILES, int WAVES, int MINW, bool TRAIN = false>
 static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
-    const int lds_bytes = 2 * a.slot_bytes;
+    const int lds_bytes = 2 * a.slot_bytes + (PNR_TRACE ? WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
     PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_forward: weight double buffer of %d bytes exceeds the 160 KiB LDS", lds_bytes);
     PNR_REQUIRE(a.n_chunks >= 3, "pnr_mlp_forward: network too small for the weight stream");
     const int per_group = 32 * TILES * WAVES;
@@ -333,6 +350,9 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.acts = (uint16_t*)acts;
+#if PNR_TRACE
+    if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);

@@ -28,6 +28,7 @@ struct MlpArgs {
     // bf16, one [S][width] slot-ordered region per tensor (pnr_train_layout); d_raw: upstream gradient
     // of raw, (ch, S) channel-major fp32; dys: pre-activation gradients written by the backward.
     uint16_t* acts; const float* d_raw; uint16_t* dys;
+    unsigned long long* trace;      // PNR_TRACE builds: [8 waves][PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
     int64_t acts_off[24], dys_off[24];
 };
 
@@ -88,6 +89,17 @@ __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x1
     }
 }
 
+// PNR_TRACE (debug builds only): per-chunk s_memtime stamps of every wave of workgroup 0, kept in LDS (no
+// vector-memory traffic, so vmcnt waits are not perturbed) and dumped to MlpArgs::trace at kernel end.
+#ifndef PNR_TRACE
+#define PNR_TRACE 0
+#endif
+#ifndef PNR_TRACE_MASK
+#define PNR_TRACE_MASK 0xff
+#endif
+#define PNR_TRACE_CHUNKS 48
+#define PNR_TRACE_STAMPS 8
+
 // ---- weight stream: two LDS slots; chunk c+1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
 template <int WAVES, int GDB_>
 struct Ctx {
@@ -97,6 +109,20 @@ struct Ctx {
     int lane, wave, hi;
     int ci, slot;
     pnr_chunk_entry e1, e2;            // table entries of chunks ci+1, ci+2 (scalar loads, fetched a chunk early)
+#if PNR_TRACE
+    unsigned long long* tr;            // LDS trace area of this wave: [PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
+    int titer;
+    __device__ __forceinline__ void stamp(int k)
+    {
+        if (!((PNR_TRACE_MASK >> k) & 1)) return;       // single-stamp builds: a stamp costs an lgkmcnt(0) wait
+        if (blockIdx.x == 0 && titer == 2 && ci < PNR_TRACE_CHUNKS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) tr[ci * PNR_TRACE_STAMPS + k] = t;
+        }
+    }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+#endif
 
     __device__ __forceinline__ int wrap(int i) const { return i >= a.n_chunks ? i - a.n_chunks : i; }
     __device__ __forceinline__ pnr_chunk_entry entry(int idx) const
@@ -125,13 +151,16 @@ struct Ctx {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    __device__ __forceinline__ void begin() const { issue(e1, slot ^ 1); }
     __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
+    __device__ __forceinline__ void begin() { stamp(0); issue(e1, slot ^ 1); stamp(1); }
     // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
     __device__ __forceinline__ void finish()
     {
+        stamp(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
         __syncthreads();
+        stamp(6);
         slot ^= 1;
         ci = wrap(ci + 1);
         e1 = e2;

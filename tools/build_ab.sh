@@ -8,7 +8,7 @@ for cfg in "$@"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
     -fvisibility=hidden -I$R/include -I$C $flags -shared -o $R/build/ab/libpnr_$name.so \
-    $C/pnr_mlp.hip $C/pnr_sampling.hip $C/pnr_composite.hip -x hip $C/pnr_api.cpp $C/pnr_mlp_pack.cpp 2>&1 | grep -E "error" &
+    $C/*.hip -x hip $C/pnr_api.cpp $C/pnr_mlp_pack.cpp 2>&1 | grep -E "error" &
 done
 wait
 ls -la $R/build/ab/

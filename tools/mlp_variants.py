@@ -15,7 +15,9 @@ from panopticnerf_amd import make_network, ops, synthetic
 from oracle import torch_oracle as to
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-net = make_network(NS(N_importance=128, num_classes=45, num_instances=32)).eval()
+import os
+NOSKIP = os.environ.get("PNR_NET_SKIPS") == "none"     # feasibility experiments on a network without the skip layer
+net = make_network(NS(N_importance=128, num_classes=45, num_instances=32, **({"skips": []} if NOSKIP else {}))).eval()
 synthetic.trained_like_(net)
 rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
@@ -26,7 +28,7 @@ ms = min(ops.time_mlp_forward(desc, img, rays, z, raw, 5) for _ in range(3))
 fl = 65536 * 192 * bench.mlp_flops_per_sample()
 # correctness spot check against the bf16-emulating oracle on 24 rays spread over the launch
 idx = torch.arange(0, 65536, 2731)
-oc = to.mlp_config(n_sem=45, n_inst=32)
+oc = to.mlp_config(n_sem=45, n_inst=32, **({"skips": ()} if NOSKIP else {}))
 ref = to.run_network({k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}, oc, rays[idx].cpu(), z[idx].cpu(), emulate_bf16=True)
 got = raw.reshape(81, 65536, 192)[:, idx].permute(1, 2, 0).cpu()
 err = (got - ref).abs().max().item()
