@@ -34,6 +34,9 @@
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
+#ifndef PNR_OPT_EAGER_EPI
+#define PNR_OPT_EAGER_EPI 1
+#endif
 // Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
 // save != nullptr (training, bf16): the output block is also stored slot-ordered for the backward.
 template <int PREC, int TILES, class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
@@ -74,6 +77,9 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
                         // ReLU after rounding (they commute, bit for bit): a negative bf16 is a negative int16,
                         // so one v_pk_max_i16 against 0 gates both halves -- 8 ops per block instead of 16 v_max_f32.
                         if (MODE == MODE_RELU) v = relu_bf16x2(v);
+#if PNR_OPT_EAGER_EPI
+                        asm volatile("" : "+v"(v));      // materialise here: hipcc otherwise parks all of a layer's pack/ReLU at its end
+#endif
                         out[t][fb * RPB + p] = v;
                     }
                     if (save) store_slots(save, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][fb * RPB]);

@@ -53,12 +53,14 @@ template <int PREC> struct PrecT;
 template <> struct PrecT<PNR_PREC_BF16> { static constexpr int RPB = 8; };    // B regs per 32 input features
 template <> struct PrecT<PNR_PREC_FP32> { static constexpr int RPB = 16; };
 
+// Two fp32 -> packed bf16x2 (RNE), lo in bits [15:0].  Written as ONE 2-vector conversion so that hipcc selects a
+// single v_cvt_pk_bf16_f32; two scalar (__bf16) casts become two half-empty v_cvt_pk_bf16_f32 plus a v_perm_b32.
+// (Not inline asm: asm reading MFMA results bypasses the compiler's MFMA->VALU hazard handling.)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
 {
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(uint32_t, v);
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
 }
 
 typedef __attribute__((ext_vector_type(2))) short i16x2;
