@@ -25,7 +25,7 @@ template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF>
 __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
                                           const uint16_t* mask, uint16_t* store, const int (&samp)[TILES])
 {
-    constexpr int FBC = 2, KS = NA / 4, G = 2;
+    constexpr int FBC = 2, G = 2;
     static_assert(NFB_OUT % FBC == 0 && NOUT >= OFF + NFB_OUT * 8, "bad backward layer geometry");
     uint32_t dummy[TILES][1];
 #pragma unroll
