@@ -130,7 +130,7 @@ def main():
             rc = rays[: args.chunk].contiguous()
             z = ops.stratified(rc, N_C + N_F)
             desc, img = net.packed(1, dev)
-            raw = torch.empty((4 + N_SEM + N_INST, rc.shape[0] * (N_C + N_F)), device=dev)
+            raw = ops.alloc_raw(4 + N_SEM + N_INST, rc.shape[0] * (N_C + N_F), dev)   # as Renderer allocates it
             ops.time_mlp_forward(desc, img, rc, z, raw, 1)
             ms = ops.time_mlp_forward(desc, img, rc, z, raw, 5)
             S = rc.shape[0] * (N_C + N_F)

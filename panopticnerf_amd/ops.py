@@ -192,22 +192,41 @@ def n_channels(desc):
     return 4 + desc.n_sem + desc.n_inst
 
 
+RAW_PAD = 64      # floats between the channel rows of a channel-major raw image (see alloc_raw)
+
+
+def alloc_raw(ch, S, device, pad=RAW_PAD):
+    """Channel-major raw image (ch, S) whose channel rows are S + pad floats apart.  With the dense stride the 81
+    rows of a ray sit exactly S*4 B apart (48 MiB at the fine level) and the 8 row loads of a compositing batch hit
+    the same HBM channel; a 256 B skew per row is worth +3 % compositing bandwidth (tools/stride_probe.py)."""
+    buf = torch.empty(ch * (S + pad), device=device, dtype=torch.float32)
+    return buf.as_strided((ch, S), (S + pad, 1))
+
+
+def _chk_raw(raw, ch, S):
+    """channel-major raw: (ch, S) fp32 on the GPU, unit sample stride, any channel stride >= S"""
+    if not raw.is_cuda or raw.dtype != torch.float32:
+        raise TypeError("raw: expected a float32 GPU tensor")
+    if tuple(raw.shape) != (ch, S) or raw.stride(1) != 1 or raw.stride(0) < S:
+        raise ValueError(f"raw: expected shape {(ch, S)} with unit sample stride, got {tuple(raw.shape)} strides {raw.stride()}")
+    return raw.stride(0)
+
+
 def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
     """Fused gamma() + NeRF MLP + heads on every sample.  SURVEY 8a rows a4+a5.
-    Returns raw as (ch, R*N) when channel_major (fast layout) else (R, N, ch)."""
+    Returns raw as (ch, R*N) when channel_major (fast layout; channel stride padded, see alloc_raw) else (R, N, ch)."""
     rays, z = _chk(rays, "rays"), _chk(z, "z")
     packed = _chk(packed, "packed", torch.uint8)
     R, N = z.shape
     ch = n_channels(desc)
     S = R * N
     if channel_major:
-        raw = out if out is not None else torch.empty((ch, S), device=z.device, dtype=torch.float32)
-        assert tuple(raw.shape) == (ch, S)
-        ss, sc = 1, S
+        raw = out if out is not None else alloc_raw(ch, S, z.device)
+        ss, sc = 1, _chk_raw(raw, ch, S)
     else:
         raw = out if out is not None else torch.empty((R, N, ch), device=z.device, dtype=torch.float32)
         ss, sc = ch, 1
-    _chk(raw, "raw")
+        _chk(raw, "raw")
     _lib.check(_lib.load().pnr_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), ss, sc,
                                            _stream()), "pnr_mlp_forward")
     return raw
@@ -218,7 +237,7 @@ def time_mlp_forward(desc, packed, rays, z, raw, iters):
     R, N = z.shape
     ms = ctypes.c_float(0.0)
     _lib.check(_lib.load().pnr_time_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1,
-                                                R * N, int(iters), ctypes.byref(ms), _stream()),
+                                                _chk_raw(raw, n_channels(desc), R * N), int(iters), ctypes.byref(ms), _stream()),
                "pnr_time_mlp_forward")
     return float(ms.value)
 
@@ -226,16 +245,16 @@ def time_mlp_forward(desc, packed, rays, z, raw, iters):
 def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
               sem_mode=0, white_bkgd=False, want_weights=True):
     """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
-    raw, z, rays = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays")
+    z, rays = _chk(z, "z"), _chk(rays, "rays")
     noise = _chk(noise, "noise")
     label_sem = _chk(label_sem, "label_sem", torch.int32)
     label_inst = _chk(label_inst, "label_inst", torch.int32)
     R, N = z.shape
     ch = 4 + n_sem + n_inst
     if channel_major:
-        assert tuple(raw.shape) == (ch, R * N), f"raw shape {tuple(raw.shape)} != {(ch, R * N)}"
-        ss, sc = 1, R * N
+        ss, sc = 1, _chk_raw(raw, ch, R * N)
     else:
+        _chk(raw, "raw")
         assert tuple(raw.shape) == (R, N, ch)
         ss, sc = ch, 1
     dev = z.device

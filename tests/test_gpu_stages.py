@@ -288,3 +288,31 @@ def test_mlp_many_groups_persistent_loop(dev):
     assert torch.equal(full, sub), "a sample's result must not depend on which workgroup/iteration computed it"
     ref = to.run_network(p, ocfg, rays[idx], z[idx.to(dev)].cpu(), emulate_bf16=True)
     assert (sub.T.reshape(len(idx), 64, -1).cpu() - ref).abs().max() < 1e-2
+
+
+@pytest.mark.gpu
+def test_raw_channel_stride_is_free(dev):
+    """The channel-major raw image may carry any channel stride >= R*N (ops.alloc_raw pads it to skew the channel
+    rows across HBM channels): MLP and compositing results are bit-identical to the dense layout."""
+    C, K = 5, 3
+    ocfg = to.mlp_config(n_sem=C, n_inst=K)
+    p = to.init_params(ocfg, seed=5, sigma_bias=0.05)
+    desc = ops.make_desc(n_sem=C, n_inst=K, precision="bf16")
+    img = ops.pack_mlp(desc, p).to(dev)
+    R, N = 1000, 64
+    rays = synthetic.camera_rays()[::401][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    dense = torch.empty((4 + C + K, R * N), device=dev)
+    ops.mlp_forward(desc, img, rays, z, out=dense)
+    padded = ops.mlp_forward(desc, img, rays, z)                       # default allocation: padded channel stride
+    assert padded.stride(0) == R * N + ops.RAW_PAD and padded.stride(1) == 1
+    odd = ops.alloc_raw(4 + C + K, R * N, dev, pad=6)                  # rows not 16 B aligned: the generic strided path
+    ops.mlp_forward(desc, img, rays, z, out=odd)
+    assert torch.equal(padded, dense) and torch.equal(odd, dense)
+    lab = torch.randint(-1, C, (R, N), device=dev, dtype=torch.int32)
+    a = ops.composite(dense, z, rays, C, K, True, None, lab, None)
+    for other in (padded, odd):
+        b = ops.composite(other, z, rays, C, K, True, None, lab, None)
+        assert all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(ValueError):
+        ops.composite(dense.T.contiguous().T, z, rays, C, K, True)     # sample stride != 1

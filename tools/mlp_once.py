@@ -10,7 +10,7 @@ net = make_network(NS(N_importance=128, num_classes=45, num_instances=32)).eval(
 rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
 desc, img = net.packed(1, dev)
-raw = torch.empty((81, 65536 * 192), device=dev)
+raw = ops.alloc_raw(81, 65536 * 192, dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     ops.mlp_forward(desc, img, rays, z, out=raw)
 torch.cuda.synchronize()

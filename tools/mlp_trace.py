@@ -19,7 +19,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     rays = synthetic.camera_rays()[:65536].to(dev)
     z = ops.stratified(rays, 192)
     desc, img = net.packed(1, dev)
-    raw = torch.empty((81, 65536 * 192), device=dev)
+    raw = ops.alloc_raw(81, 65536 * 192, dev)
     ops.mlp_forward(desc, img, rays, z, out=raw)
     torch.cuda.synchronize()
     print("TRACE " + json.dumps(trace.cpu().tolist()))

@@ -22,7 +22,7 @@ synthetic.trained_like_(net)
 rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
 desc, img = net.packed(1, dev)
-raw = torch.empty((81, 65536 * 192), device=dev)
+raw = ops.alloc_raw(81, 65536 * 192, dev)
 ops.time_mlp_forward(desc, img, rays, z, raw, 2)
 ms = min(ops.time_mlp_forward(desc, img, rays, z, raw, 5) for _ in range(3))
 fl = 65536 * 192 * bench.mlp_flops_per_sample()
@@ -30,7 +30,7 @@ fl = 65536 * 192 * bench.mlp_flops_per_sample()
 idx = torch.arange(0, 65536, 2731)
 oc = to.mlp_config(n_sem=45, n_inst=32, **({"skips": ()} if NOSKIP else {}))
 ref = to.run_network({k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}, oc, rays[idx].cpu(), z[idx].cpu(), emulate_bf16=True)
-got = raw.reshape(81, 65536, 192)[:, idx].permute(1, 2, 0).cpu()
+got = raw.unflatten(1, (65536, 192))[:, idx].permute(1, 2, 0).cpu()
 err = (got - ref).abs().max().item()
 print("%%-14s %%8.3f ms  %%7.1f TFLOP/s  %%6.1f Msamples/s  max|err| vs bf16 oracle %%.2e" %% (
     sys.argv[1], ms, fl / ms / 1e9, 65536 * 192 / ms / 1e3, err), flush=True)
