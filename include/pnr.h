@@ -115,12 +115,13 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
  *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output,
  *          one slot-ordered [S][width] region per tensor (S = n_rays*n_samples);
- *   dys  : bf16, dys_off[D+4] elements -- every layer's pre-activation gradient dY, same layout, written by
+ *   dys  : bf16, dys_off[D+7] elements -- every layer's pre-activation gradient dY, same layout (plus the output
+ *          layers' dY = d_raw in bf16: [rgb,sigma] in 32 slots, semantic and instance logits in 64 slots each), written by
  *          pnr_mlp_backward for the weight-gradient GEMMs dW = dY^T X (plain S-reduction GEMMs, done by the caller);
  *   d_raw: (4+n_sem+n_inst, S) channel-major fp32 (pnr_composite_backward's output).
  * Slot order (csrc/pnr_mlp_layout.h): slot fb*32 + hi*16 + r <-> feature fb*32 + (r&3) + 8*(r>>2) + 4*hi. */
 int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples, int64_t* acts_off_host /* D+7 */,
-                         int64_t* dys_off_host /* D+5 */);
+                         int64_t* dys_off_host /* D+8 */);
 int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                           int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
                           int64_t raw_stride_c, void* acts, void* stream);
@@ -128,6 +129,18 @@ int64_t pnr_mlp_bwd_packed_bytes(const pnr_mlp_desc* desc);
 int pnr_mlp_pack_bwd(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, void* packed_host);
 int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd, const float* d_raw, const void* acts,
                      void* dys, int64_t n_rays, int n_samples, void* stream);
+
+/* Weight gradients (the third K3 kernel): for every Linear of the network
+ *     dW = dY^T X   and   db = sum over samples of dY,
+ * computed from `acts` (pnr_mlp_forward_train) and `dys` (pnr_mlp_backward) of the same n_samples = n_rays * n_samples.
+ * grads_dev: a pnr_mlp_params_host whose pointers are DEVICE pointers to the fp32 GRADIENT buffers, one per parameter,
+ *   nn.Linear layout ((out,in) row-major / (out)); every one of them is fully overwritten (not accumulated).  The struct
+ *   and its pts_w / pts_b arrays live in host memory.
+ * workspace: device scratch of pnr_mlp_wgrad_workspace_bytes bytes (per-slab partial sums; deterministic reduction).
+ * Replaces autograd's per-layer  grad_output.t() @ input  and  grad_output.sum(0)  for nn.Linear. */
+int64_t pnr_mlp_wgrad_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_samples);
+int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const void* dys, int64_t n_samples,
+                  const pnr_mlp_params_host* grads_dev, void* workspace, void* stream);
 
 /* ---- a6: raw2outputs.  raw strides as above.  noise (R,N) or NULL; label_* (R,N) int32 or
  * NULL (fixed bbox-prior field, -1 = none).  sem_mode 0: composite logits; 1: softmax first.

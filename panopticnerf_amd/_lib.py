@@ -53,6 +53,8 @@ SIGNATURES = {
     "pnr_mlp_bwd_packed_bytes": (c_i64, [ctypes.POINTER(MlpDesc)]),
     "pnr_mlp_pack_bwd": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), ctypes.c_void_p]),
     "pnr_mlp_backward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_f, c_i64, c_int, c_f]),
+    "pnr_mlp_wgrad_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
+    "pnr_mlp_wgrad": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, ctypes.POINTER(MlpParamsHost), c_f, c_f]),
     "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,

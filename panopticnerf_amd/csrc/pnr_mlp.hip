@@ -396,7 +396,7 @@ PNR_EXPORT int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples,
     int64_t a[24], d[24];
     pnr_train_layout(*desc, n_samples, a, d);
     memcpy(acts_off_host, a, sizeof(int64_t) * (size_t)(desc->D + 7));
-    memcpy(dys_off_host, d, sizeof(int64_t) * (size_t)(desc->D + 5));
+    memcpy(dys_off_host, d, sizeof(int64_t) * (size_t)(desc->D + 8));
     return PNR_OK;
 }
 

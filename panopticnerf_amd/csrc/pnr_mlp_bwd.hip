@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
         for (int i = 0; i < CATR; ++i) cat[0][i] = 0;
         uint32_t drs[TILES][8];
         load_draw<1>(a, samp[0], c.hi, 0, 4, drs[0]);
+        store_slots(dys + a.dys_off[4 + D], 32, samp[0], 0, c.hi, drs[0]);        // dY of [rgb, sigma] for the wgrad
 #pragma unroll
         for (int i = 0; i < 8; ++i) cat[0][HR + i] = drs[0][i];
 
@@ -134,11 +135,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
         if (a.n_sem) {
             uint32_t ds[TILES][OBR];
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
+#pragma unroll
+            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &ds[0][b * 8]);
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.acts_off[4 + D], dys + a.dys_off[2], samp);
         }
         if (a.n_inst) {
             uint32_t di[TILES][OBR];
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
+#pragma unroll
+            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &di[0][b * 8]);
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.acts_off[5 + D], dys + a.dys_off[3], samp);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D

@@ -114,7 +114,12 @@ static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* a
     dys_off[2] = take(d.W / 2);
     dys_off[3] = take(d.W / 2);
     for (int l = 0; l < d.D; ++l) dys_off[4 + l] = take(d.W);
-    dys_off[4 + d.D] = o;
+    // the output layers' dY = d_raw in bf16, FEAT slot order (k_mlp_bwd stores what it feeds the MFMAs):
+    // [rgb, sigma] in 32 slots, semantic logits and instance logits in PNR_BWD_OUT_SLOTS = 64 slots each
+    dys_off[4 + d.D] = take(32);
+    dys_off[5 + d.D] = take(64);
+    dys_off[6 + d.D] = take(64);
+    dys_off[7 + d.D] = o;
 }
 
 // ---- fragment descriptors: ONE description of where every element of a packed image comes from, consumed by

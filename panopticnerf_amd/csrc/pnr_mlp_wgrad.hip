@@ -1,0 +1,327 @@
+// K3-wgrad: weight gradients of the fused NeRF MLP, bf16 MFMA, fp32 accumulate.
+//   dW_l = dY_l^T X_l   (M = layer outputs, N = layer inputs, reduction over the S samples),   db_l = sum_s dY_l
+// for every Linear of the network, straight from the slot-ordered bf16 buffers the training forward (acts: X) and
+// the data-gradient pass (dys: dY) leave in HBM (pnr_train_layout).  No reference file exists in the mount
+// (SURVEY.md 0); the arithmetic is what autograd does for nn.Linear.
+//
+// Both MFMA operands are needed k-major per lane (8 consecutive SAMPLES of one feature) while memory is
+// feature-major ([sample][feature]), so both go through LDS and come back through gfx950's transpose read:
+//   * a workgroup owns one job (a (dY region, X region) pair) and one slab of samples; it streams KT = 64-sample
+//     tiles of both regions into LDS by LDS-DMA (1 KiB per wave instruction, double buffered, one barrier per tile);
+//   * ds_read_b64_tr_b16 hands a lane 4 consecutive samples of its feature; a 16-lane group addresses a
+//     [4 samples][16 features] block (lane a: sample a>>2, features 4(a&3)..), two reads make one MFMA operand;
+//   * those reads touch 4 rows x 64 B per half-wave, which is conflict-free only if the 4 rows sit in different
+//     64 B bank groups: the 16 B chunks of a row are XOR-swizzled with the row index.  LDS-DMA writes LDS
+//     linearly, so the swizzle is applied on the SOURCE side (each lane fetches the chunk its LDS position holds);
+//   * 8 waves x (2 x 4) 32x32 tiles cover a 256 x 256 gradient; db comes from one more MFMA per row block against
+//     an all-ones operand (the kernel is HBM-bound: ~13.7 KB per sample over all jobs, ~1.3 MFLOP);
+//   * every (job, slab) writes its partial sums; k_wgrad_reduce adds the slabs in a fixed order (deterministic)
+//     and un-permutes slots into the nn.Linear layout, so no atomics and no host-side index maps are needed.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "pnr_common.h"
+#include "pnr_mlp_layout.h"
+#include "pnr_mlp_plan.h"
+
+int pnr_mlp_validate(const pnr_mlp_desc* d);
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(8))) short i16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+
+#define WG_KT 64                    /* samples per LDS tile */
+#define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
+#define WG_MAX_JOBS 24
+#define WG_BIAS_COLS 32             /* partial block: [ma][nb + 32], column nb = row sum (bias gradient) */
+
+struct WgJob {
+    int64_t a_off, b_off;           // element offsets of the dY region (in dys) and the X region (in acts)
+    int64_t p_off;                  // float offset of this job's partials: [n_slabs][ma][nb + WG_BIAS_COLS]
+    int ma, nb;                     // region widths in slots: 32, 64, 128 or 256
+};
+struct WgArgs {
+    const uint16_t* acts; const uint16_t* dys; const uint16_t* zeros;   // zeros: >= 512 B of zeros (tile rows past the slab)
+    float* partial;
+    int S, slab, n_slabs, n_jobs;
+    WgJob job[WG_MAX_JOBS];
+};
+
+// 16 B chunk swizzle of a tile row with `cpr` chunks: bits 2..3 (bit 2) of the chunk index are XORed with the row
+__device__ __forceinline__ int wg_swz(int row, int cpr) { return cpr >= 16 ? ((row & 3) << 2) : cpr == 8 ? (((row >> 1) & 1) << 2) : 0; }
+
+__global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][A tile | B tile]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int jb = blockIdx.x / a.n_slabs, slab = blockIdx.x - jb * a.n_slabs;
+    const int ma = a.job[jb].ma, nb = a.job[jb].nb;
+    const uint16_t* const Ag = a.dys + a.job[jb].a_off;
+    const uint16_t* const Bg = a.acts + a.job[jb].b_off;
+    const int s_begin = slab * a.slab;
+    const int s_end = a.S < s_begin + a.slab ? a.S : s_begin + a.slab;
+    const int ntiles = (s_end - s_begin + WG_KT - 1) / WG_KT;
+    const int cprA = ma >> 3, cprB = nb >> 3;                       // 16 B chunks per tile row
+    const int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64;
+
+    // ---- LDS-DMA of tile t into buffer buf: piece p of an operand covers 64 consecutive chunk positions
+    auto issue = [&](int t, int buf) {
+        const int s0 = s_begin + t * WG_KT;
+        char* const dA = smem + buf * 2 * WG_TILE_BYTES;
+        for (int p = wave; p < piecesA + piecesB; p += 8) {
+            const bool isA = p < piecesA;
+            const int pp = isA ? p : p - piecesA;
+            const int cpr = isA ? cprA : cprB;
+            const int lg = 31 - __builtin_clz(cpr);                 // cpr is a power of two
+            const int r = pp * (64 >> lg) + (lane >> lg);           // tile row of this lane's chunk position
+            const int c = (lane & (cpr - 1)) ^ wg_swz(r, cpr);      // global chunk that lives at this position
+            const int srow = s0 + r;
+            const char* src = srow < s_end ? reinterpret_cast<const char*>((isA ? Ag : Bg) + (int64_t)srow * (cpr * 8)) + c * 16
+                                           : reinterpret_cast<const char*>(a.zeros) + c * 16;
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dA + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- this wave's 32x32 tiles: row blocks 2*wm + {0,1}, column blocks 4*wn + {0..3}
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nMb = ma >> 5, nNb = nb >> 5;
+    const int al = lane & 15, gq = lane >> 4, hi = gq >> 1;
+    const int rsub = 8 * hi + (al >> 2);                            // row within a 16-sample k-step (first half-read)
+    const int sxA = cprA >= 16 ? (rsub & 3) : cprA == 8 ? ((rsub >> 1) & 1) : 0;
+    const int sxB = cprB >= 16 ? (rsub & 3) : cprB == 8 ? ((rsub >> 1) & 1) : 0;
+    const int inblk = (2 * (gq & 1) + ((al & 3) >> 1)) * 16 + (al & 1) * 8;    // byte offset inside the 64 B block row
+    const int rbA = cprA * 16, rbB = cprB * 16;                     // row bytes
+    int offA[2], offB[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offA[i] = rsub * rbA + (((2 * wm + i) ^ sxA) << 6) + inblk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offB[j] = WG_TILE_BYTES + rsub * rbB + (((4 * wn + j) ^ sxB) << 6) + inblk;
+
+    f32x16 acc[2][4], bacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    auto frag = [&](const char* tile, int off, int ks, int rb) -> bf16x8 {
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + off + (ks * 16) * rb));
+        const i16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + off + (ks * 16 + 4) * rb));
+        const i16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    if (ntiles > 0) issue(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                            // tile t landed; everybody is done with tile t-1
+        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+        const char* tile = smem + (t & 1) * 2 * WG_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < WG_KT / 16; ++ks) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (2 * wm + i < nMb) fa[i] = frag(tile, offA[i], ks, rbA);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * wn + j < nNb) fb[j] = frag(tile, offB[j], ks, rbB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (2 * wm + i >= nMb) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * wn + j < nNb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (wn == 0) bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- partial sums of this (job, slab): [ma][nb + 32] fp32, slot order on both axes
+    const int ldp = nb + WG_BIAS_COLS;
+    float* const P = a.partial + a.job[jb].p_off + (int64_t)slab * ma * ldp;
+    const int n = lane & 31, hl = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (2 * wm + i >= nMb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (2 * wm + i) * 32 + pnr_row_of(r, hl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * wn + j < nNb) P[(int64_t)row * ldp + (4 * wn + j) * 32 + n] = acc[i][j][r];
+            if (wn == 0 && n == 0) P[(int64_t)row * ldp + nb] = bacc[i][r];
+        }
+    }
+}
+
+// ---- reduction over slabs + un-permutation into the nn.Linear layout
+struct WgRed {
+    int64_t p_off;                  // partial block of the job
+    int ma, nb;
+    int row0, n_rows;               // canonical dY features [row0, row0 + n_rows) -> rows 0.. of `out`
+    int col_kind, col_L, n_cols;    // canonical X columns: PNR_SEG_FEAT (n_cols features) / PNR_SEG_GX / PNR_SEG_GD (encoding of L bands)
+    float* out; int ld, col_off;    // out[row * ld + col_off + col]
+    float* out_b;                   // bias gradient (n_rows) or null
+};
+struct WgRedArgs { const float* partial; int n_slabs, n_items; WgRed item[WG_MAX_JOBS]; };
+
+__device__ __forceinline__ int wg_feat_slot(int f)
+{
+    const int w = f & 31;
+    return (f & ~31) + ((w >> 2) & 1) * 16 + (w & 3) + 4 * (w >> 3);
+}
+__device__ __forceinline__ int wg_embed_slot(int kind, int L, int col)
+{
+    const int nv = kind == PNR_SEG_GX ? 32 : 16;
+    for (int h = 0; h < 2; ++h)
+        for (int v = 0; v < nv; ++v)
+            if (pnr_seg_col(kind, L, h, v) == col) return h * nv + v;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgRedArgs a)
+{
+    const WgRed& it = a.item[blockIdx.y];
+    const int ncol = it.n_cols + (it.out_b ? 1 : 0);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= it.n_rows * ncol) return;
+    const int o = idx / ncol, i = idx - o * ncol;
+    const int srow = wg_feat_slot(it.row0 + o);
+    const bool bias = i == it.n_cols;
+    const int scol = bias ? it.nb : it.col_kind == PNR_SEG_FEAT ? wg_feat_slot(i) : wg_embed_slot(it.col_kind, it.col_L, i);
+    const int ldp = it.nb + WG_BIAS_COLS;
+    const float* p = a.partial + it.p_off + (int64_t)srow * ldp + scol;
+    const int64_t stride = (int64_t)it.ma * ldp;
+    float s = 0.0f;
+    for (int k = 0; k < a.n_slabs; ++k) s += p[k * stride];
+    if (bias) it.out_b[o] = s;
+    else it.out[(int64_t)o * it.ld + it.col_off + i] = s;
+}
+
+// ------------------------------------------------------------------------------- host side
+static int wg_slab(int64_t S)
+{
+    // samples per slab: enough slabs to fill the GPU a few times over, few enough to keep the partials small
+    int slab = 16384;
+    while (slab > 1024 && S / slab < 24) slab >>= 1;
+    return slab;
+}
+
+struct WgPlan { int n; WgJob job[WG_MAX_JOBS]; WgRed red[WG_MAX_JOBS]; int64_t partial_floats; int slab, n_slabs; };
+
+// grads: pnr_mlp_params_host whose pointers are DEVICE pointers to the gradients (null for a plan used for sizes only)
+static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host* g, WgPlan& pl)
+{
+    int64_t ao[24], dof[24];
+    pnr_train_layout(d, S, ao, dof);
+    const int D = d.D, W = d.W, H = d.W / 2;
+    const int EXn = 3 + 6 * d.xyz_L, EDn = 3 + 6 * d.dir_L;
+    pl.slab = wg_slab(S);
+    pl.n_slabs = (int)((S + pl.slab - 1) / pl.slab);
+    pl.n = 0;
+    int64_t po = 0;
+    auto F = [](const float* p) { return const_cast<float*>(p); };
+    auto add = [&](int64_t a_off, int ma, int64_t b_off, int nb, int row0, int n_rows, int ck, int cL, int n_cols,
+                   float* out, int ld, int col_off, float* out_b) {
+        WgJob& j = pl.job[pl.n];
+        j.a_off = a_off; j.b_off = b_off; j.ma = ma; j.nb = nb; j.p_off = po;
+        WgRed& r = pl.red[pl.n];
+        r.p_off = po; r.ma = ma; r.nb = nb; r.row0 = row0; r.n_rows = n_rows; r.col_kind = ck; r.col_L = cL; r.n_cols = n_cols;
+        r.out = out; r.ld = ld; r.col_off = col_off; r.out_b = out_b;
+        po += (int64_t)pl.n_slabs * ma * (nb + WG_BIAS_COLS);
+        ++pl.n;
+    };
+    const bool have = g != nullptr;
+    // trunk
+    for (int l = 0; l < D; ++l) {
+        const int64_t dy = dof[4 + l];
+        float* w = have ? F(g->pts_w[l]) : nullptr;
+        float* b = have ? F(g->pts_b[l]) : nullptr;
+        if (l == 0) add(dy, W, ao[0], 64, 0, W, PNR_SEG_GX, d.xyz_L, EXn, w, EXn, 0, b);
+        else if (l - 1 == d.skip) {
+            add(dy, W, ao[1 + l], W, 0, W, PNR_SEG_FEAT, 0, W, w, EXn + W, EXn, b);
+            add(dy, W, ao[0], 64, 0, W, PNR_SEG_GX, d.xyz_L, EXn, w, EXn + W, 0, nullptr);
+        } else add(dy, W, ao[1 + l], W, 0, W, PNR_SEG_FEAT, 0, W, w, W, 0, b);
+    }
+    const int64_t Xh = ao[1 + D];
+    add(dof[1], W, Xh, W, 0, W, PNR_SEG_FEAT, 0, W, have ? F(g->feature_w) : nullptr, W, 0, have ? F(g->feature_b) : nullptr);
+    add(dof[0], H, ao[2 + D], W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->views_w) : nullptr, W + EDn, 0, have ? F(g->views_b) : nullptr);
+    add(dof[0], H, ao[1], 32, 0, H, PNR_SEG_GD, d.dir_L, EDn, have ? F(g->views_w) : nullptr, W + EDn, W, nullptr);
+    add(dof[4 + D], 32, ao[3 + D], H, 0, 3, PNR_SEG_FEAT, 0, H, have ? F(g->rgb_w) : nullptr, H, 0, have ? F(g->rgb_b) : nullptr);
+    add(dof[4 + D], 32, Xh, W, 3, 1, PNR_SEG_FEAT, 0, W, have ? F(g->alpha_w) : nullptr, W, 0, have ? F(g->alpha_b) : nullptr);
+    if (d.n_sem) {
+        add(dof[2], H, Xh, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
+        add(dof[5 + D], 64, ao[4 + D], H, 0, d.n_sem, PNR_SEG_FEAT, 0, H, have ? F(g->sem1_w) : nullptr, H, 0, have ? F(g->sem1_b) : nullptr);
+    }
+    if (d.n_inst) {
+        add(dof[3], H, Xh, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
+        add(dof[6 + D], 64, ao[5 + D], H, 0, d.n_inst, PNR_SEG_FEAT, 0, H, have ? F(g->inst1_w) : nullptr, H, 0, have ? F(g->inst1_b) : nullptr);
+    }
+    pl.partial_floats = po;
+}
+
+#define WG_ZERO_BYTES 1024
+
+PNR_EXPORT int64_t pnr_mlp_wgrad_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_samples)
+{
+    if (pnr_mlp_validate(desc) != PNR_OK || n_samples < 0 || desc->precision != PNR_PREC_BF16) return -1;
+    WgPlan pl;
+    wg_plan(*desc, n_samples, nullptr, pl);
+    return WG_ZERO_BYTES + pl.partial_floats * (int64_t)sizeof(float);
+}
+
+PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const void* dys, int64_t n_samples,
+                             const pnr_mlp_params_host* grads_dev, void* workspace, void* stream)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_wgrad: the training path is bf16 only");
+    PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS, "pnr_mlp_wgrad: n_sem, n_inst <= %d", PNR_BWD_OUT_SLOTS);
+    PNR_REQUIRE(n_samples >= 1 && n_samples < ((int64_t)1 << 31) - 65536, "pnr_mlp_wgrad: bad sample count");
+    PNR_REQUIRE(acts && dys && grads_dev && workspace, "pnr_mlp_wgrad: null pointer");
+    PNR_REQUIRE((((uintptr_t)acts | (uintptr_t)dys | (uintptr_t)workspace) & 15) == 0, "pnr_mlp_wgrad: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    WgPlan pl;
+    wg_plan(*desc, n_samples, grads_dev, pl);
+    PNR_REQUIRE(pl.n <= WG_MAX_JOBS, "pnr_mlp_wgrad: too many jobs");
+    for (int i = 0; i < pl.n; ++i)
+        PNR_REQUIRE(pl.red[i].out && (pl.red[i].out_b || true), "pnr_mlp_wgrad: a gradient pointer is null");
+    PNR_HIP(hipMemsetAsync(workspace, 0, WG_ZERO_BYTES, st));
+    WgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.acts = (const uint16_t*)acts; a.dys = (const uint16_t*)dys; a.zeros = (const uint16_t*)workspace;
+    a.partial = (float*)((char*)workspace + WG_ZERO_BYTES);
+    a.S = (int)n_samples; a.slab = pl.slab; a.n_slabs = pl.n_slabs; a.n_jobs = pl.n;
+    for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 4 * WG_TILE_BYTES, st, a);
+    PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
+    WgRedArgs r;
+    memset(&r, 0, sizeof(r));
+    r.partial = a.partial; r.n_slabs = pl.n_slabs; r.n_items = pl.n;
+    int maxel = 0;
+    for (int i = 0; i < pl.n; ++i) {
+        r.item[i] = pl.red[i];
+        const int el = pl.red[i].n_rows * (pl.red[i].n_cols + 1);
+        if (el > maxel) maxel = el;
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((maxel + 255) / 256, pl.n), dim3(256), 0, st, r);
+    PNR_CHECK_LAUNCH("pnr_mlp_wgrad (reduce)");
+    return PNR_OK;
+}

@@ -157,7 +157,7 @@ def pack_mlp_bwd(desc, params):
 def train_layout(desc, n_samples):
     """(acts_off, dys_off): element offsets (bf16 units) of the saved-activation / dY regions; last = total."""
     a = (ctypes.c_int64 * (desc.D + 7))()
-    d = (ctypes.c_int64 * (desc.D + 5))()
+    d = (ctypes.c_int64 * (desc.D + 8))()
     _lib.check(_lib.load().pnr_mlp_train_layout(ctypes.byref(desc), int(n_samples), a, d), "pnr_mlp_train_layout")
     return list(a), list(d)
 
@@ -186,6 +186,31 @@ def mlp_backward(desc, packed_bwd, d_raw, acts, n_rays, n_samples):
     _lib.check(_lib.load().pnr_mlp_backward(ctypes.byref(desc), _p(packed_bwd), _p(d_raw), _p(acts), _p(dys), n_rays,
                                             n_samples, _stream()), "pnr_mlp_backward")
     return dys
+
+
+_WG_WS = {}
+
+
+def mlp_wgrad(desc, acts, dys, n_samples, shapes):
+    """Weight gradients of every Linear from the training forward's `acts` and the data-gradient pass's `dys`
+    (pnr_mlp_wgrad: hand-written MFMA kernel + deterministic slab reduction).  shapes: dict name -> shape of the
+    parameters (state_dict names).  Returns dict name -> fp32 gradient tensor.  SURVEY 8a row a9."""
+    acts, dys = _chk(acts, "acts", torch.bfloat16), _chk(dys, "dys", torch.bfloat16)
+    lib = _lib.load()
+    dev = acts.device
+    nbytes = lib.pnr_mlp_wgrad_workspace_bytes(ctypes.byref(desc), int(n_samples))
+    if nbytes < 0:
+        raise RuntimeError("pnr_mlp_wgrad_workspace_bytes: " + lib.pnr_last_error().decode(errors="replace"))
+    key = (str(dev), int(nbytes))
+    ws = _WG_WS.get(key)
+    if ws is None:
+        _WG_WS.clear()                       # one workspace per device / size: the partial sums are scratch
+        ws = _WG_WS[key] = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+    grads = {k: torch.empty(tuple(shp), device=dev, dtype=torch.float32) for k, shp in shapes.items()}
+    G, keep = _param_struct(desc, grads, dev)
+    _lib.check(lib.pnr_mlp_wgrad(ctypes.byref(desc), _p(acts), _p(dys), int(n_samples), ctypes.byref(G), _p(ws), _stream()),
+               "pnr_mlp_wgrad")
+    return grads
 
 
 def n_channels(desc):

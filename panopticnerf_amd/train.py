@@ -1,13 +1,13 @@
 """Training-side glue of the render path: the autograd Function that
-puts the HIP forward / backward kernels behind `Renderer.render`, the weight-gradient assembly,
-and the flat-bucket gradient all-reduce.
+puts the HIP forward / backward kernels behind `Renderer.render`, and the flat-bucket gradient
+all-reduce.
 
 What runs where: forward (pnr_mlp_forward_train + pnr_composite), compositing backward
-(pnr_composite_backward) and the MLP data-gradient pass (pnr_mlp_backward) are hand-written HIP.
-The weight gradients dW_l = dY_l^T X_l are plain GEMMs with a (S x 256)-deep reduction over
-samples; round 1 hands those (and the bias sums) to the library GEMM through torch.mm on the
-kernels' slot-ordered bf16 buffers, then un-permutes the small (<= 256 x 320) results.  A
-hand-written split-K kernel for them is listed in DESIGN.md section 7.
+(pnr_composite_backward), the MLP data-gradient pass (pnr_mlp_backward) and the weight gradients
+(pnr_mlp_wgrad: dW_l = dY_l^T X_l and the bias sums, MFMA over LDS transpose reads) are hand-written
+HIP.  `weight_grads()` below is the same computation with library GEMMs (torch.bmm over sample slabs)
+on the kernels' slot-ordered bf16 buffers; it is kept as the cross-check the GPU tests compare
+pnr_mlp_wgrad against (tests/test_gpu_backward.py) and is not on the training path.
 """
 import functools
 
@@ -200,7 +200,8 @@ class LevelFn(torch.autograd.Function):
         d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None)
         desc, img_b = net.packed_bwd(lv, rays.device)
         dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
-        wg = weight_grads(nerf, desc, acts, dys, d_raw, R * N)
+        shapes = {n: p.shape for n, p in nerf.named_parameters()}
+        wg = ops.mlp_wgrad(desc, acts, dys, R * N, shapes)          # pnr_mlp_wgrad (weight_grads() below = torch cross-check)
         return (None,) * 8 + tuple(wg[n].to(p_dtype) for n, p_dtype in ctx.names)
 
 
