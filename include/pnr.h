@@ -162,6 +162,49 @@ int pnr_composite_backward(const float* raw, int64_t raw_stride_c, const float* 
                            const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
                            const float* g_inst, const float* g_weights, float* d_raw, void* stream);
 
+/* pnr_composite_backward plus the two gradient sources the trainer's loss wrapper adds:
+ *   g_fix_sem (R,n_sem) / g_fix_inst (R,n_inst): gradients of the FIXED (bbox-prior) maps; since
+ *     fix_x[c] = sum_i w_i [label_i == c], they reach the densities through the weights: dL/dw_i += g_fix_x[label_i];
+ *   ce_sem / ce_inst: DEVICE scalars s; adds s * (softmax_c(raw logits of sample) - [c == label]) to d_raw for every
+ *     sample with a label >= 0 -- the gradient of the per-sample 3D cross-entropy whose value pnr_ce3d computes
+ *     (s = upstream gradient * loss weight / number of labelled samples).
+ * label_sem / label_inst (R,N) int32 are the labels pnr_sample_labels produced for this level. */
+int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                            const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                            const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                            const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                            const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                            const float* ce_sem, const float* ce_inst, float* d_raw, void* stream);
+
+/* ---- 8f-1: the trainer's loss wrapper (the reference's NetworkWrapper) on the maps of
+ * one level, fused with the gradient of the weighted total w.r.t. every map.  All reductions are means:
+ *   [0] rgb      mean over rays and channels of (rgb - rgb_gt)^2
+ *   [1] depth    mean over rays with depth_gt > 0 of |depth - depth_gt|  (depth_l2: squared error)
+ *   [2] sem      mean over rays with 0 <= sem_gt < n_sem of CE(softmax(sem), sem_gt)      (learned field, 2D pseudo label)
+ *   [3] fix_sem  mean over the same rays of -log(fix_sem[sem_gt] + fix_eps)                (fixed bbox-prior field)
+ *   [4] inst, [5] fix_inst: the same two terms for the instance field
+ *   [6] total = sum of w_x * term_x;  losses_out is 8 floats on the DEVICE.
+ * Any map / target / gradient pointer may be NULL (its term is skipped / its gradient not written).  g_x has the
+ * shape of map x and receives d total / d x.  workspace: pnr_losses_workspace_bytes(n_rays) device bytes.
+ * Replaces ~30 eager torch launches per level (mse_loss, l1_loss, cross_entropy, nll_loss and their backwards). */
+typedef struct pnr_loss_cfg {
+    float w_rgb, w_depth, w_sem, w_fix_sem, w_inst, w_fix_inst;
+    int32_t depth_l2;
+    float fix_eps;
+} pnr_loss_cfg;
+int64_t pnr_losses_workspace_bytes(int64_t n_rays);
+int pnr_losses(const pnr_loss_cfg* cfg, int64_t n_rays, int n_sem, int n_inst, const float* rgb, const float* depth,
+               const float* sem, const float* fix_sem, const float* inst, const float* fix_inst, const float* rgb_gt,
+               const float* depth_gt, const int32_t* sem_gt, const int32_t* inst_gt, float* losses_out, float* g_rgb,
+               float* g_depth, float* g_sem, float* g_fix_sem, float* g_inst, float* g_fix_inst, void* workspace, void* stream);
+
+/* Per-sample 3D cross-entropy (forward value) of the learned logits raw[first_channel .. +n_classes) (channel-major,
+ * sample stride 1) against label (n_samples) int32, -1 = unlabelled: out2 (device) = {mean CE over labelled samples,
+ * their count}.  Gradient: pnr_composite_backward2's ce_sem / ce_inst. */
+int64_t pnr_ce3d_workspace_bytes(int64_t n_samples);
+int pnr_ce3d(const float* raw, int64_t raw_stride_c, int first_channel, int n_classes, const int32_t* label,
+             int64_t n_samples, float* out2, void* workspace, void* stream);
+
 /* ---- a7: sample_pdf + merge.  z (R,Nc), weights (R,Nc) coarse; u (R,Nf) or NULL (det).
  * z_samples (R,Nf) and inds (R,Nf) int32 may be NULL; z_fine (R,Nc+Nf) sorted union or NULL.
  * Indices / z_samples bit-exact with pnro_sample_pdf.  Nc <= 256, Nc+Nf <= 512. */

@@ -278,3 +278,43 @@ def render_rays(params, cfg, rays, n_samples, n_importance=0, lindisp=False, t_r
         ret["z_samples"], ret["inds"] = zs, inds
         level(1, params["fine"], z_fine, noise1)
     return ret
+
+
+# ---- loss wrapper.  PARITY UNPINNED like everything above: the reference's NetworkWrapper is
+# not in the mount; the terms follow SURVEY.md section 2 row 8 (RGB MSE, stereo-depth L1/L2, 2D pseudo-label CE on the
+# learned and on the fixed field, 3D bbox CE).
+def losses(maps, targets, weights, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5):
+    """maps: rgb (R,3), depth (R), semantic/fix_semantic (R,C), instance/fix_instance (R,K) (any subset);
+    targets: rgb, depth, semantic (R) int, instance (R) int.  Returns (dict of the six means, weighted total)."""
+    import torch.nn.functional as F
+    out = {}
+    z = lambda: torch.zeros((), dtype=torch.float32)
+    if "rgb" in maps and targets.get("rgb") is not None:
+        out["rgb"] = ((maps["rgb"] - targets["rgb"]) ** 2).mean()
+    if "depth" in maps and targets.get("depth") is not None:
+        v = targets["depth"] > 0
+        d = (maps["depth"] - targets["depth"])[v]
+        out["depth"] = ((d ** 2) if depth_l2 else d.abs()).sum() / max(int(v.sum()), 1)
+    for key, fkey, tkey, n in (("semantic", "fix_semantic", "semantic", n_sem), ("instance", "fix_instance", "instance", n_inst)):
+        t = targets.get(tkey)
+        if t is None or n == 0:
+            continue
+        v = (t >= 0) & (t < n)
+        cnt = max(int(v.sum()), 1)
+        tl = t[v].long()
+        if key in maps:
+            out[key] = F.cross_entropy(maps[key][v], tl, reduction="sum") / cnt if v.any() else z()
+        if fkey in maps:
+            out[fkey] = (-(maps[fkey][v].gather(1, tl[:, None])[:, 0] + fix_eps).log()).sum() / cnt if v.any() else z()
+    total = sum(float(weights.get(k, 0.0)) * v for k, v in out.items())
+    return out, total
+
+
+def ce3d(logits, label):
+    """logits (S,n_cls), label (S) int, -1 = unlabelled -> (mean CE over labelled samples, count)."""
+    import torch.nn.functional as F
+    v = (label >= 0) & (label < logits.shape[1])
+    cnt = int(v.sum())
+    if cnt == 0:
+        return torch.zeros(()), 0
+    return F.cross_entropy(logits[v], label[v].long(), reduction="sum") / cnt, cnt

@@ -8,4 +8,6 @@ does, and raises if it is missing (no CPU fallback)."""
 from .network import NeRF, Network, make_network  # noqa: F401
 from .renderer import Renderer, make_renderer  # noqa: F401
 
-__all__ = ["NeRF", "Network", "make_network", "Renderer", "make_renderer"]
+from .losses import NetworkWrapper  # noqa: F401,E402
+
+__all__ = ["NeRF", "Network", "make_network", "Renderer", "make_renderer", "NetworkWrapper"]

@@ -14,6 +14,13 @@ c_int = ctypes.c_int
 PREC_BF16, PREC_FP32 = 0, 1
 
 
+class LossCfg(ctypes.Structure):
+    """pnr_loss_cfg (include/pnr.h)."""
+    _fields_ = [("w_rgb", ctypes.c_float), ("w_depth", ctypes.c_float), ("w_sem", ctypes.c_float),
+                ("w_fix_sem", ctypes.c_float), ("w_inst", ctypes.c_float), ("w_fix_inst", ctypes.c_float),
+                ("depth_l2", ctypes.c_int32), ("fix_eps", ctypes.c_float)]
+
+
 class MlpDesc(ctypes.Structure):
     """pnr_mlp_desc (include/pnr.h)."""
     _fields_ = [("D", ctypes.c_int32), ("W", ctypes.c_int32), ("skip", ctypes.c_int32),
@@ -59,6 +66,12 @@ SIGNATURES = {
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_composite_backward2": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
+                                        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_losses_workspace_bytes": (c_i64, [c_i64]),
+    "pnr_losses": (c_int, [ctypes.POINTER(LossCfg), c_i64, c_int, c_int] + [c_f] * 19),
+    "pnr_ce3d_workspace_bytes": (c_i64, [c_i64]),
+    "pnr_ce3d": (c_int, [c_f, c_i64, c_int, c_int, c_f, c_i64, c_f, c_f, c_f]),
     "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),

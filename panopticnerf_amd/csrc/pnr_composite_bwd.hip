@@ -19,6 +19,12 @@ struct CompositeBwdArgs {
     int64_t R; int N, C, K;
     const float *g_rgb, *g_depth, *g_acc, *g_sem, *g_inst, *g_w;   // upstream grads (any may be null)
     float* d_raw;                          // (4+C+K, R*N) channel-major
+    // fixed (bbox-prior) fields: fix_x[c] = sum_i w_i [label_i == c]  =>  dL/dw_i += g_fix_x[label_i]
+    const int32_t *label_sem, *label_inst; // (R,N), -1 = none; needed by g_fix_* and ce_*
+    const float *g_fix_sem, *g_fix_inst;   // (R,C), (R,K) or null
+    // per-sample 3D cross-entropy of the learned logits against the bbox labels (pnr_ce3d is its forward):
+    // d_raw[c][s] += *ce_x * (softmax_c(raw_x[:, s]) - [c == label_s])  for label_s >= 0
+    const float *ce_sem, *ce_inst;         // device scalars (upstream gradient * weight / count) or null
 };
 
 struct f4 { float v[4]; };
@@ -94,6 +100,32 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) G.v[k] = fmaf(gd, zz.v[k], ga) + gw.v[k];
         }
+        int ls[4] = {-1, -1, -1, -1}, li[4] = {-1, -1, -1, -1};
+        if (a.label_sem && active) { const int4 t = *reinterpret_cast<const int4*>(a.label_sem + s0); ls[0] = t.x; ls[1] = t.y; ls[2] = t.z; ls[3] = t.w; }
+        if (a.label_inst && active) { const int4 t = *reinterpret_cast<const int4*>(a.label_inst + s0); li[0] = t.x; li[1] = t.y; li[2] = t.z; li[3] = t.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (a.g_fix_sem && ls[k] >= 0 && ls[k] < a.C) G.v[k] += a.g_fix_sem[rayc * a.C + ls[k]];
+            if (a.g_fix_inst && li[k] >= 0 && li[k] < a.K) G.v[k] += a.g_fix_inst[rayc * a.K + li[k]];
+        }
+        // 3D cross-entropy: per-sample log-sum-exp of each learned field (one extra pass over its channel rows)
+        const float ces = (a.ce_sem && a.label_sem) ? *a.ce_sem : 0.0f, cei = (a.ce_inst && a.label_inst) ? *a.ce_inst : 0.0f;
+        f4 mx_s, den_s, mx_i, den_i;
+        auto lse = [&](int nch, int ch0, f4& mx, f4& den) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mx.v[k] = -INFINITY; den.v[k] = 0.0f; }
+            for (int c = 0; c < nch; ++c) {
+                const f4 v = ld4(a.raw + (int64_t)(ch0 + c) * a.sc + s0, active);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float m2 = fmaxf(mx.v[k], v.v[k]);
+                    den.v[k] = den.v[k] * expf(mx.v[k] - m2) + expf(v.v[k] - m2);
+                    mx.v[k] = m2;
+                }
+            }
+        };
+        if (ces != 0.0f) lse(a.C, 4, mx_s, den_s);
+        if (cei != 0.0f) lse(a.K, 4 + a.C, mx_i, den_i);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float gc = a.g_rgb ? a.g_rgb[rayc * 3 + c] : 0.0f;
@@ -117,6 +149,17 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             f4 dr;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { G.v[k] = fmaf(gc, r.v[k], G.v[k]); dr.v[k] = w.v[k] * gc; }
+            const float ce = is_s ? ces : cei;
+            if (ce != 0.0f) {
+                const int cc = is_s ? c : c - a.C;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lab = is_s ? ls[k] : li[k];
+                    if (lab < 0 || lab >= (is_s ? a.C : a.K)) continue;
+                    const float pc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
+                    dr.v[k] += ce * (pc - (lab == cc ? 1.0f : 0.0f));
+                }
+            }
             st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
         }
 
@@ -149,22 +192,44 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
     }
 }
 
+PNR_EXPORT int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                       const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                                       const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                       const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                                       const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                                       const float* ce_sem, const float* ce_inst, float* d_raw, void* stream);
+
 PNR_EXPORT int pnr_composite_backward(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
                                       const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
                                       const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
                                       const float* g_inst, const float* g_weights, float* d_raw, void* stream)
+{
+    return pnr_composite_backward2(raw, raw_stride_c, z, rays, noise, n_rays, n_samples, n_sem, n_inst, g_rgb, g_depth, g_acc,
+                                   g_sem, g_inst, g_weights, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, stream);
+}
+
+PNR_EXPORT int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                       const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
+                                       const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                       const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                                       const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                                       const float* ce_sem, const float* ce_inst, float* d_raw, void* stream)
 {
     PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0,
                 "pnr_composite_backward: n_samples=%d must be a multiple of 4 in [4,256]", n_samples);
     if (n_rays <= 0) return PNR_OK;
     PNR_REQUIRE(raw && z && rays && d_raw, "pnr_composite_backward: null pointer");
     PNR_REQUIRE((raw_stride_c % 4) == 0 && (((uintptr_t)raw | (uintptr_t)d_raw | (uintptr_t)z | (uintptr_t)noise |
-                                            (uintptr_t)g_weights) & 15) == 0,
+                                            (uintptr_t)g_weights | (uintptr_t)label_sem | (uintptr_t)label_inst) & 15) == 0,
                 "pnr_composite_backward: channel-major, 16-byte aligned images required");
+    PNR_REQUIRE((!g_fix_sem && !ce_sem) || label_sem, "pnr_composite_backward: g_fix_sem / ce_sem need label_sem");
+    PNR_REQUIRE((!g_fix_inst && !ce_inst) || label_inst, "pnr_composite_backward: g_fix_inst / ce_inst need label_inst");
     CompositeBwdArgs a;
     a.raw = raw; a.sc = raw_stride_c; a.z = z; a.rays = rays; a.noise = noise; a.R = n_rays; a.N = n_samples;
     a.C = n_sem; a.K = n_inst; a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_sem = g_sem; a.g_inst = g_inst;
     a.g_w = g_weights; a.d_raw = d_raw;
+    a.label_sem = label_sem; a.label_inst = label_inst; a.g_fix_sem = g_fix_sem; a.g_fix_inst = g_fix_inst;
+    a.ce_sem = ce_sem; a.ce_inst = ce_inst;
     int sub = 1;
     while (sub < n_samples / 4) sub <<= 1;
     const int rpw = 64 / sub;

@@ -304,19 +304,72 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
     return out
 
 
-def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None):
+def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem=None, label_inst=None,
+                       ce_sem=None, ce_inst=None):
     """Backward of composite() for channel-major raw.  grads: dict with any of rgb, depth, acc, semantic,
-    instance, weights (upstream gradients, contiguous fp32).  Returns d_raw (ch, R*N).  SURVEY 8a row a9."""
+    instance, weights, fix_semantic, fix_instance (upstream gradients, contiguous fp32); the fixed-field
+    gradients need the per-sample labels.  ce_sem / ce_inst: 1-element device tensors, the scale of the per-sample
+    3D cross-entropy gradient (see ce3d).  Returns d_raw (ch, R*N).  SURVEY 8a row a9, 8f-1."""
     raw, z, rays = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays")
     noise = _chk(noise, "noise")
+    label_sem = _chk(label_sem, "label_sem", torch.int32)
+    label_inst = _chk(label_inst, "label_inst", torch.int32)
     R, N = z.shape
     g = {k: _chk(v.contiguous().float(), "g_" + k) for k, v in grads.items() if v is not None}
+    ce_sem = None if ce_sem is None else _chk(ce_sem.reshape(1).float().contiguous(), "ce_sem")
+    ce_inst = None if ce_inst is None else _chk(ce_inst.reshape(1).float().contiguous(), "ce_inst")
     d_raw = torch.empty_like(raw)
-    _lib.check(_lib.load().pnr_composite_backward(_p(raw), R * N, _p(z), _p(rays), _p(noise), R, N, n_sem, n_inst,
-                                                  _p(g.get("rgb")), _p(g.get("depth")), _p(g.get("acc")),
-                                                  _p(g.get("semantic")), _p(g.get("instance")), _p(g.get("weights")),
-                                                  _p(d_raw), _stream()), "pnr_composite_backward")
+    _lib.check(_lib.load().pnr_composite_backward2(_p(raw), R * N, _p(z), _p(rays), _p(noise), R, N, n_sem, n_inst,
+                                                   _p(g.get("rgb")), _p(g.get("depth")), _p(g.get("acc")),
+                                                   _p(g.get("semantic")), _p(g.get("instance")), _p(g.get("weights")),
+                                                   _p(label_sem), _p(label_inst), _p(g.get("fix_semantic")),
+                                                   _p(g.get("fix_instance")), _p(ce_sem), _p(ce_inst),
+                                                   _p(d_raw), _stream()), "pnr_composite_backward")
     return d_raw
+
+
+_LOSS_KEYS = ("rgb", "depth", "semantic", "fix_semantic", "instance", "fix_instance")
+
+
+def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5, want_grads=True):
+    """The trainer's per-ray loss terms of one level and the gradient of their weighted total w.r.t. every map
+    (pnr_losses; SURVEY 8f-1).  weights: dict over rgb/depth/semantic/fix_semantic/instance/fix_instance;
+    maps: dict of (R,·) fp32 GPU tensors (any subset); targets: rgb (R,3), depth (R), semantic (R) int32,
+    instance (R) int32.  Returns (losses (8,) device tensor: the six means, total, 0; dict of gradients)."""
+    lib = _lib.load()
+    m = {k: _chk(v.detach().contiguous(), k) for k, v in maps.items() if k in _LOSS_KEYS and v is not None and v.numel()}
+    any_map = next(iter(m.values()))
+    dev, R = any_map.device, any_map.shape[0]
+    t_rgb, t_depth = _chk(targets.get("rgb"), "rgb_gt"), _chk(targets.get("depth"), "depth_gt")
+    t_sem = _chk(targets.get("semantic"), "sem_gt", torch.int32)
+    t_inst = _chk(targets.get("instance"), "inst_gt", torch.int32)
+    cfg = _lib.LossCfg(*(float(weights.get(k, 0.0)) for k in _LOSS_KEYS), int(bool(depth_l2)), float(fix_eps))
+    use = {"rgb": t_rgb is not None, "depth": t_depth is not None, "semantic": t_sem is not None, "fix_semantic": t_sem is not None,
+           "instance": t_inst is not None, "fix_instance": t_inst is not None}
+    m = {k: v for k, v in m.items() if use[k]}
+    grads = {k: torch.empty_like(v) for k, v in m.items()} if want_grads else {}
+    out = torch.empty(8, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(lib.pnr_losses_workspace_bytes(R)), device=dev, dtype=torch.uint8)
+    g = grads.get
+    _lib.check(lib.pnr_losses(ctypes.byref(cfg), R, int(n_sem), int(n_inst), _p(m.get("rgb")), _p(m.get("depth")),
+                              _p(m.get("semantic")), _p(m.get("fix_semantic")), _p(m.get("instance")), _p(m.get("fix_instance")),
+                              _p(t_rgb), _p(t_depth), _p(t_sem), _p(t_inst), _p(out), _p(g("rgb")), _p(g("depth")),
+                              _p(g("semantic")), _p(g("fix_semantic")), _p(g("instance")), _p(g("fix_instance")), _p(ws),
+                              _stream()), "pnr_losses")
+    return out, grads
+
+
+def ce3d(raw, first_channel, n_classes, label):
+    """Per-sample 3D cross-entropy of the learned logits raw[first_channel:+n_classes] (channel-major (ch,S)) against
+    label (S or (R,N)) int32, -1 = unlabelled.  Returns a 2-element device tensor (mean CE, labelled count)."""
+    lib = _lib.load()
+    label = _chk(label, "label", torch.int32)
+    S = label.numel()
+    sc = _chk_raw(raw, raw.shape[0], S)
+    out = torch.empty(2, device=raw.device, dtype=torch.float32)
+    ws = torch.empty(int(lib.pnr_ce3d_workspace_bytes(S)), device=raw.device, dtype=torch.uint8)
+    _lib.check(lib.pnr_ce3d(_p(raw), sc, int(first_channel), int(n_classes), _p(label), S, _p(out), _p(ws), _stream()), "pnr_ce3d")
+    return out
 
 
 def sample_pdf(z, weights, n_importance, u=None, want_samples=True):

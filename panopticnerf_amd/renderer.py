@@ -115,6 +115,9 @@ class Renderer:
                                          None if u is None else u[s:e], train, grad))
         ret = {}
         for k in outs[0]:
+            if outs[0][k].dim() == 0:       # per-level scalars of the training path (ce3d_*): mean over the chunks
+                ret[k] = outs[0][k] if len(outs) == 1 else torch.stack([o[k] for o in outs]).mean()
+                continue
             v = outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)
             ret[k] = v.reshape(*lead, *v.shape[1:])
         return ret

@@ -161,9 +161,12 @@ def weight_grads(nerf, desc, acts, dys, d_raw, S):
 
 class LevelFn(torch.autograd.Function):
     """One level (coarse or fine) of render_rays: NeRF MLP on every sample + raw2outputs.
-    Differentiable w.r.t. the NeRF's parameters only (z comes from the detached sampler)."""
+    Differentiable w.r.t. the NeRF's parameters only (z comes from the detached sampler).  Besides the maps it
+    returns, when the bbox-prior labels are present, the fixed-field maps (differentiable through the weights) and the
+    per-sample 3D cross-entropies of the learned fields against those labels."""
 
-    OUT = ("rgb", "depth", "acc", "weights", "semantic", "instance")
+    OUT = ("rgb", "depth", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance",
+           "ce3d_semantic", "ce3d_instance")
 
     @staticmethod
     def forward(ctx, rend, lv, rays, z, ls, li, noise, names, *params):
@@ -174,34 +177,43 @@ class LevelFn(torch.autograd.Function):
         C, K = nerf.n_sem, nerf.n_inst
         raw, acts = ops.mlp_forward_train(desc, img, rays, z)
         out = ops.composite(raw, z, rays, C, K, True, noise, ls, li, 0, rend.white_bkgd, True)
+        empty = torch.zeros(0, device=dev)
+        ce_s = ops.ce3d(raw, 4, C, ls) if (C and ls is not None) else None
+        ce_i = ops.ce3d(raw, 4 + C, K, li) if (K and li is not None) else None
         ctx.rend, ctx.lv, ctx.names = rend, lv, names
-        ctx.save_for_backward(raw, acts, z, rays, noise if noise is not None else torch.empty(0, device=dev))
-        ctx.has_noise = noise is not None
+        ctx.set_materialize_grads(False)            # unused outputs arrive as None, not as zero tensors
+        ctx.save_for_backward(raw, acts, z, rays, noise if noise is not None else empty,
+                              ls if ls is not None else empty, li if li is not None else empty,
+                              ce_s if ce_s is not None else empty, ce_i if ce_i is not None else empty)
+        ctx.has_noise, ctx.has_ls, ctx.has_li = noise is not None, ls is not None, li is not None
+        out["ce3d_semantic"] = ce_s[0].clone() if ce_s is not None else None
+        out["ce3d_instance"] = ce_i[0].clone() if ce_i is not None else None
         res = [out.get(k) for k in LevelFn.OUT]
-        res = [r if r is not None else torch.zeros(0, device=dev) for r in res]
-        fix = [out.get("fix_semantic"), out.get("fix_instance")]
-        fix = [f if f is not None else torch.zeros(0, device=dev) for f in fix]
-        ctx.mark_non_differentiable(*fix)
-        return tuple(res) + tuple(fix)
+        return tuple(r if r is not None else empty for r in res)
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_acc, g_w, g_sem, g_inst, *_):
-        raw, acts, z, rays, noise = ctx.saved_tensors
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w, g_sem, g_inst, g_fs, g_fi, g_ces, g_cei):
+        raw, acts, z, rays, noise, ls, li, ce_s, ce_i = ctx.saved_tensors
         rend, lv = ctx.rend, ctx.lv
         net = rend.net
         nerf = net.nerf(lv)
         C, K = nerf.n_sem, nerf.n_inst
         R, N = z.shape
         grads = {"rgb": g_rgb, "depth": g_depth, "acc": g_acc, "weights": g_w,
-                 "semantic": g_sem if C else None, "instance": g_inst if K else None}
+                 "semantic": g_sem if C else None, "instance": g_inst if K else None,
+                 "fix_semantic": g_fs if (C and ctx.has_ls) else None, "fix_instance": g_fi if (K and ctx.has_li) else None}
         if rend.white_bkgd and g_rgb is not None:       # rgb += 1 - acc
             grads["acc"] = (g_acc if g_acc is not None else 0) - g_rgb.sum(-1)
         grads = {k: v for k, v in grads.items() if v is not None and v.numel()}
-        d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None)
+        # d(mean CE)/d logits = (softmax - onehot) / count, times the upstream gradient of the scalar
+        sc_s = (g_ces / ce_s[1].clamp(min=1.0)) if (g_ces is not None and ce_s.numel()) else None
+        sc_i = (g_cei / ce_i[1].clamp(min=1.0)) if (g_cei is not None and ce_i.numel()) else None
+        d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None,
+                                       ls if ctx.has_ls else None, li if ctx.has_li else None, sc_s, sc_i)
         desc, img_b = net.packed_bwd(lv, rays.device)
         dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
         shapes = {n: p.shape for n, p in nerf.named_parameters()}
-        wg = ops.mlp_wgrad(desc, acts, dys, R * N, shapes)          # pnr_mlp_wgrad (weight_grads() below = torch cross-check)
+        wg = ops.mlp_wgrad(desc, acts, dys, R * N, shapes)          # pnr_mlp_wgrad (weight_grads() above = torch cross-check)
         return (None,) * 8 + tuple(wg[n].to(p_dtype) for n, p_dtype in ctx.names)
 
 
@@ -211,7 +223,7 @@ def level_train(rend, lv, rays, z, ls, li, noise):
     named = list(nerf.named_parameters())
     names = tuple((n, p.dtype) for n, p in named)
     res = LevelFn.apply(rend, lv, rays, z, ls, li, noise, names, *[p for _, p in named])
-    out = {k: v for k, v in zip(LevelFn.OUT + ("fix_semantic", "fix_instance"), res) if v.numel()}
+    out = {k: v for k, v in zip(LevelFn.OUT, res) if v.numel()}
     return out
 
 
