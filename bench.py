@@ -162,29 +162,28 @@ def main():
                                            "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray}
 
     # secondary measurement (never the headline value): one training step on a 4096-ray batch per rank --
-    # render with autograd, MSE / CE-style losses on the maps, backward through the HIP kernels, flat-bucket
+    # render with autograd, the loss wrapper (RGB / depth / 2D CE on learned and fixed fields / 3D CE; fused HIP),
+    # backward through the HIP kernels (compositing, dgrad, wgrad), flat-bucket
     # gradient all-reduce over RCCL, Adam.  Guarded: a failure here must not lose the headline line.
     train_info = None
     if args.train_steps > 0:
         try:
-            from panopticnerf_amd import train as pnr_train
+            from panopticnerf_amd import NetworkWrapper, train as pnr_train
             tnet = make_network(cfg).to(dev).train()
             synthetic.trained_like_(tnet)
-            trend = make_renderer(cfg, tnet)
+            wrap = NetworkWrapper(tnet, cfg)       # the trainer's loss wrapper: render + fused losses
             opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
             g = torch.Generator(device=dev).manual_seed(rank)
             idx = torch.randint(0, n_rays, (args.train_rays,), generator=g, device=dev)
-            tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
-            tgt_rgb = torch.rand((args.train_rays, 3), generator=g, device=dev)
-            tgt_sem = torch.randint(0, N_SEM, (args.train_rays,), generator=g, device=dev)
+            tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
+                  "rgb": torch.rand((1, args.train_rays, 3), generator=g, device=dev),
+                  "depth": torch.rand((1, args.train_rays), generator=g, device=dev) * 60.0 - 10.0,     # <= 0: no stereo depth
+                  "pseudo_label": torch.randint(-1, N_SEM, (1, args.train_rays), generator=g, device=dev),
+                  "instance_label": torch.randint(-1, N_INST, (1, args.train_rays), generator=g, device=dev)}
 
             def step():
                 opt.zero_grad(set_to_none=True)
-                o = trend.render(tb)
-                loss = 0
-                for lv in (0, 1):
-                    loss = loss + ((o[f"rgb_{lv}"][0] - tgt_rgb) ** 2).mean()
-                    loss = loss + 0.1 * torch.nn.functional.cross_entropy(o[f"semantic_{lv}"][0], tgt_sem)
+                _, loss, _, _ = wrap(tb)
                 loss.backward()
                 pnr_train.allreduce_grads(tnet, world)
                 opt.step()
@@ -204,7 +203,8 @@ def main():
             train_info = {"ms_per_step": round(tdt * 1e3, 3), "rays_per_rank": args.train_rays,
                           "Msamples_per_s_fwd_bwd": round(args.train_rays * world * (N_C + N_C + N_F) / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
-                          "grad_allreduce": "flat bucket, %s" % ("RCCL (nccl)" if world > 1 else "single rank: skipped")}
+                          "grad_allreduce": "flat bucket, %s" % ("RCCL (nccl)" if world > 1 else "single rank: skipped"),
+                          "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE"}
         except Exception as e:      # noqa: BLE001
             train_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
