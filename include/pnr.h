@@ -205,6 +205,27 @@ int64_t pnr_ce3d_workspace_bytes(int64_t n_samples);
 int pnr_ce3d(const float* raw, int64_t raw_stride_c, int first_channel, int n_classes, const int32_t* label,
              int64_t n_samples, float* out2, void* workspace, void* stream);
 
+/* ---- 8f-2: ray generation, the dataset-side producer of batch['rays'] (the reference builds rays from the KITTI-360
+ * intrinsics and poses in lib/datasets/kitti360/, not in the mount).  intr4_host = {fx, fy, cx, cy} and c2w12_host =
+ * 3x4 row-major camera-to-world [R | t] (x right, y down, z forward) are HOST arrays (copied into the launch).
+ * Pixel (i = column, j = row): d = R * ((i - cx)/fx, (j - cy)/fy, 1), o = t; d is not normalised.
+ * pix (n_rays) int32 linear pixel indices j*width + i on the device, or NULL = the whole frame (n_rays = width*height).
+ * rays (n_rays, 8) = o d near far.  Bit-exact with pnro_gen_rays. */
+int pnr_gen_rays(const float* intr4_host, const float* c2w12_host, int width, int height, float near_, float far_,
+                 const int32_t* pix, int64_t n_rays, float* rays, void* stream);
+
+/* ---- 8f-4: label-map post-processing and evaluator counters (what follows the path in the reference's evaluate loop;
+ * its evaluator is not in the mount, conventions are this build's -- DESIGN.md 8).
+ * pnr_panoptic_labels: sem_label = argmax_c sem (lowest index on ties); inst_label = argmax_k inst where is_thing[sem_label]
+ *   != 0 (is_thing NULL: every class), else -1; panoptic = class*1000 + instance on things, class on stuff.  Any output
+ *   may be NULL.  sem (R,n_sem), inst (R,n_inst) or NULL, is_thing (n_sem) int32 device or NULL.
+ * pnr_confusion: conf[gt*n_classes + pred] += 1 over pixels with both labels in [0, n_classes) (gt < 0 = ignore); conf is a
+ *   device (n_classes^2) int64 array the caller zeroes once and accumulates into over frames.  Integer atomics: exact.
+ *   mIoU / accuracy are a handful of flops on that matrix (host side); PSNR = -10 log10 of pnr_losses' rgb term. */
+int pnr_panoptic_labels(const float* sem, const float* inst, const int32_t* is_thing, int64_t n_rays, int n_sem, int n_inst,
+                        int32_t* sem_label, int32_t* inst_label, int32_t* panoptic, void* stream);
+int pnr_confusion(const int32_t* pred, const int32_t* gt, int64_t n, int n_classes, int64_t* conf, void* stream);
+
 /* ---- a7: sample_pdf + merge.  z (R,Nc), weights (R,Nc) coarse; u (R,Nf) or NULL (det).
  * z_samples (R,Nf) and inds (R,Nf) int32 may be NULL; z_fine (R,Nc+Nf) sorted union or NULL.
  * Indices / z_samples bit-exact with pnro_sample_pdf.  Nc <= 256, Nc+Nf <= 512. */

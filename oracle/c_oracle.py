@@ -52,6 +52,19 @@ def _i32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
 
 
+def gen_rays(intr, c2w, width, height, near, far, pix=None):
+    """intr (4) fx fy cx cy, c2w (3,4) -> rays (R,8); pix: int32 linear pixel indices or None (whole frame)."""
+    intr = np.ascontiguousarray(intr, np.float32).reshape(4)
+    c2w = np.ascontiguousarray(c2w, np.float32).reshape(12)
+    if pix is not None:
+        pix = np.ascontiguousarray(pix, np.int32)
+    R = int(pix.shape[0]) if pix is not None else int(width) * int(height)
+    rays = np.empty((R, 8), np.float32)
+    lib().pnro_gen_rays(_fp(intr), _fp(c2w), int(width), int(height), ctypes.c_float(near), ctypes.c_float(far),
+                        pix.ctypes.data_as(ctypes.c_void_p) if pix is not None else None, ctypes.c_int64(R), _fp(rays))
+    return rays
+
+
 def stratified(rays, n_samples, lindisp=False, t_rand=None):
     rays = _f32(rays).reshape(-1, 8)
     t_rand = _f32(t_rand)

@@ -27,6 +27,30 @@
 
 #define PNRO_API __attribute__((visibility("default")))
 
+/* Ray generation (the dataset-side producer of batch['rays']).  Pinhole camera:
+ * intr = {fx, fy, cx, cy};  c2w = 3x4 row-major camera-to-world [R | t], camera axes x right, y down, z forward;
+ * pixel (i = column, j = row):  x = (i - cx)/fx,  y = (j - cy)/fy,  d_k = (R_k0*x + R_k1*y) + R_k2,  o = t.
+ * pix: n_rays linear pixel indices j*width + i, or NULL = the whole frame in row-major order.
+ * rays: (n_rays, 8) = o(3) d(3) near far.  d is NOT normalised (raw2outputs multiplies by |d|). */
+PNRO_API void pnro_gen_rays(const float* intr, const float* c2w, int width, int height, float near_, float far_,
+                            const int32_t* pix, int64_t n_rays, float* rays)
+{
+    (void)height;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const int64_t p = pix ? (int64_t)pix[r] : r;
+        const int j = (int)(p / width), i = (int)(p - (int64_t)j * width);
+        const float x = ((float)i - intr[2]) / intr[0];
+        const float y = ((float)j - intr[3]) / intr[1];
+        for (int k = 0; k < 3; ++k) {
+            const float a = c2w[k * 4 + 0] * x, b = c2w[k * 4 + 1] * y;
+            rays[r * 8 + 3 + k] = (a + b) + c2w[k * 4 + 2];
+            rays[r * 8 + k] = c2w[k * 4 + 3];
+        }
+        rays[r * 8 + 6] = near_;
+        rays[r * 8 + 7] = far_;
+    }
+}
+
 /* ---------------------------------------------------------------- a3: stratified sampler
  * SURVEY 8a row a3.  t_i = i/(N-1) (one correctly rounded division; torch.linspace's
  * bits depend on the host SIMD width, so the strict spec uses the division form);

@@ -318,3 +318,18 @@ def ce3d(logits, label):
     if cnt == 0:
         return torch.zeros(()), 0
     return F.cross_entropy(logits[v], label[v].long(), reduction="sum") / cnt, cnt
+
+
+def gen_rays(intr, c2w, width, height, near, far, pix=None):
+    """Pinhole ray generation, vectorised: same op order as pnro_gen_rays."""
+    intr = torch.as_tensor(intr, dtype=torch.float32).reshape(4)
+    c2w = torch.as_tensor(c2w, dtype=torch.float32).reshape(3, 4)
+    p = torch.arange(width * height) if pix is None else torch.as_tensor(pix).long()
+    j = torch.div(p, width, rounding_mode="floor")
+    i = p - j * width
+    x = (i.float() - intr[2]) / intr[0]
+    y = (j.float() - intr[3]) / intr[1]
+    d = torch.stack([(c2w[k, 0] * x + c2w[k, 1] * y) + c2w[k, 2] for k in range(3)], -1)
+    o = c2w[:, 3].expand_as(d)
+    nf = torch.tensor([near, far], dtype=torch.float32).expand(d.shape[0], 2)
+    return torch.cat([o, d, nf], -1).contiguous()

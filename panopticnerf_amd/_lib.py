@@ -72,6 +72,10 @@ SIGNATURES = {
     "pnr_losses": (c_int, [ctypes.POINTER(LossCfg), c_i64, c_int, c_int] + [c_f] * 19),
     "pnr_ce3d_workspace_bytes": (c_i64, [c_i64]),
     "pnr_ce3d": (c_int, [c_f, c_i64, c_int, c_int, c_f, c_i64, c_f, c_f, c_f]),
+    "pnr_gen_rays": (c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_int, c_int, ctypes.c_float,
+                             ctypes.c_float, c_f, c_i64, c_f, c_f]),
+    "pnr_panoptic_labels": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_confusion": (c_int, [c_f, c_f, c_i64, c_int, c_f, c_f]),
     "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),

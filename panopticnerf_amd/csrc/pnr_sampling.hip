@@ -22,6 +22,27 @@ __device__ __forceinline__ float strat_z(float nr, float fr, int i, int N, int l
     return 1.0f / (a + b);
 }
 
+// Ray generation: one thread per ray, two float4 stores; write-bound (32 B/ray).
+struct GenRaysArgs { float fx, fy, cx, cy; float c2w[12]; int width; float near_, far_; const int32_t* pix; int64_t R; float* rays; };
+__global__ __launch_bounds__(256) void k_gen_rays(const GenRaysArgs a)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.R; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = a.pix ? (int64_t)a.pix[r] : r;
+        const int j = (int)(p / a.width), i = (int)(p - (int64_t)j * a.width);
+        const float x = ((float)i - a.cx) / a.fx;
+        const float y = ((float)j - a.cy) / a.fy;
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float u = a.c2w[k * 4 + 0] * x, v = a.c2w[k * 4 + 1] * y;
+            d[k] = (u + v) + a.c2w[k * 4 + 2];
+        }
+        float4* o = reinterpret_cast<float4*>(a.rays + r * 8);
+        o[0] = make_float4(a.c2w[3], a.c2w[7], a.c2w[11], d[0]);
+        o[1] = make_float4(d[1], d[2], a.near_, a.far_);
+    }
+}
+
 // One thread per sample; HBM-bound: reads 8 B/ray amortised (+4 B t_rand), writes 4 B.
 __global__ __launch_bounds__(256) void k_stratified(const float* __restrict__ rays, int64_t R, int N,
                                                      int lindisp, const float* __restrict__ t_rand,
@@ -265,6 +286,24 @@ PNR_EXPORT int pnr_stratified(const float* rays, int64_t n_rays, int n_samples, 
     hipLaunchKernelGGL(k_stratified, dim3(pnr_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rays, n_rays, n_samples, lindisp, t_rand, z_out);
     PNR_CHECK_LAUNCH("pnr_stratified");
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_gen_rays(const float* intr4_host, const float* c2w12_host, int width, int height, float near_, float far_,
+                            const int32_t* pix, int64_t n_rays, float* rays, void* stream)
+{
+    PNR_REQUIRE(intr4_host && c2w12_host, "pnr_gen_rays: null camera");
+    PNR_REQUIRE(width >= 1 && height >= 1 && n_rays >= 0, "pnr_gen_rays: bad size");
+    if (n_rays == 0) return PNR_OK;             // before the pointer checks: an empty pixel list has a null pointer
+    PNR_REQUIRE(pix || n_rays == (int64_t)width * height, "pnr_gen_rays: without pixel indices n_rays must be width*height");
+    PNR_REQUIRE(intr4_host[0] != 0.0f && intr4_host[1] != 0.0f, "pnr_gen_rays: zero focal length");
+    PNR_REQUIRE(rays && (((uintptr_t)rays) & 15) == 0, "pnr_gen_rays: rays must be a 16-byte aligned device buffer");
+    GenRaysArgs a;
+    a.fx = intr4_host[0]; a.fy = intr4_host[1]; a.cx = intr4_host[2]; a.cy = intr4_host[3];
+    for (int k = 0; k < 12; ++k) a.c2w[k] = c2w12_host[k];
+    a.width = width; a.near_ = near_; a.far_ = far_; a.pix = pix; a.R = n_rays; a.rays = rays;
+    hipLaunchKernelGGL(k_gen_rays, dim3(pnr_grid_cap((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    PNR_CHECK_LAUNCH("pnr_gen_rays");
     return PNR_OK;
 }
 

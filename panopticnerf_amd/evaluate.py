@@ -1,0 +1,62 @@
+"""Evaluator -- host-side mirror of the reference's evaluator (lib/evaluators/*; not in the mount,
+SURVEY.md 0): `evaluate(output, batch)` per frame, `summarize()` at the end.
+
+Per frame, on the GPU: semantic / instance / panoptic label maps from the fine-level composited maps
+(pnr_panoptic_labels), the semantic confusion matrix against batch['pseudo_label' | 'semantic_gt'] (pnr_confusion,
+accumulated over frames in a device int64 matrix) and the colour MSE (pnr_losses' rgb term).  `summarize()` turns those
+counters into PSNR (mean over frames), mIoU / per-class IoU and pixel accuracy.  Nothing is copied to the host before
+summarize()."""
+import math
+
+import torch
+
+from . import ops
+
+
+class Evaluator:
+    def __init__(self, cfg=None, n_classes=None, is_thing=None):
+        g = lambda k, d: getattr(cfg, k, d) if cfg is not None else d
+        self.n_classes = n_classes if n_classes is not None else g("num_classes", 0)
+        self.is_thing = is_thing
+        self.level = 1
+        self.conf = None
+        self.mse = []
+
+    def evaluate(self, output, batch):
+        lv = self.level if f"rgb_{self.level}" in output else 0
+        rgb = output[f"rgb_{lv}"].reshape(-1, 3).float().contiguous()
+        dev = rgb.device
+        res = {}
+        if batch.get("rgb") is not None:
+            gt = batch["rgb"].reshape(-1, 3).to(dev, torch.float32).contiguous()
+            out, _ = ops.losses({"rgb": 1.0}, {"rgb": rgb}, {"rgb": gt}, want_grads=False)
+            self.mse.append(out[0])
+        if self.n_classes and f"semantic_{lv}" in output:
+            sem = output[f"semantic_{lv}"].reshape(-1, self.n_classes).float().contiguous()
+            inst = output.get(f"instance_{lv}")
+            inst = None if inst is None else inst.reshape(-1, inst.shape[-1]).float().contiguous()
+            th = None if self.is_thing is None else torch.as_tensor(self.is_thing, dtype=torch.int32, device=dev)
+            res["semantic_label"], res["instance_label"], res["panoptic_id"] = ops.panoptic_labels(sem, inst, th)
+            gt = batch.get("semantic_gt", batch.get("pseudo_label"))
+            if gt is not None:
+                self.conf = ops.confusion(res["semantic_label"], gt.reshape(-1).to(dev, torch.int32).contiguous(),
+                                          self.n_classes, self.conf)
+        return res
+
+    def summarize(self):
+        out = {}
+        if self.mse:
+            mse = torch.stack(self.mse).double().cpu()
+            out["psnr"] = float((-10.0 * torch.log10(mse.clamp(min=1e-12))).mean())
+            out["mse"] = float(mse.mean())
+        if self.conf is not None:
+            c = self.conf.double().cpu()
+            tp = c.diag()
+            union = c.sum(0) + c.sum(1) - tp
+            seen = union > 0
+            iou = torch.where(seen, tp / union.clamp(min=1), torch.full_like(tp, float("nan")))
+            out["iou"] = iou.tolist()
+            out["miou"] = float(iou[seen].mean()) if seen.any() else math.nan
+            out["pixel_acc"] = float(tp.sum() / c.sum().clamp(min=1))
+        self.mse, self.conf = [], None
+        return out

@@ -32,6 +32,23 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def gen_rays(intr, c2w, width, height, near, far, pix=None, device=None):
+    """Pinhole ray generation on the GPU (pnr_gen_rays).  intr: fx, fy, cx, cy; c2w: 3x4 camera-to-world
+    (host values); pix: int32 GPU tensor of linear pixel indices or None (whole frame).  Returns rays (R,8)."""
+    intr_h = (ctypes.c_float * 4)(*[float(v) for v in torch.as_tensor(intr, dtype=torch.float32).reshape(4).tolist()])
+    c2w_h = (ctypes.c_float * 12)(*[float(v) for v in torch.as_tensor(c2w, dtype=torch.float32).reshape(12).tolist()])
+    pix = _chk(pix, "pix", torch.int32)
+    dev = pix.device if pix is not None else torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("gen_rays: expected a GPU device (the HIP path has no CPU fallback)")
+    R = pix.numel() if pix is not None else int(width) * int(height)
+    rays = torch.empty((R, 8), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().pnr_gen_rays(intr_h, c2w_h, int(width), int(height), float(near), float(far), _p(pix), R,
+                                            _p(rays), _stream()), "pnr_gen_rays")
+    return rays
+
+
 def stratified(rays, n_samples, lindisp=False, t_rand=None):
     """rays (R,8) -> z (R,N).  SURVEY 8a row a3."""
     rays = _chk(rays, "rays")
@@ -411,3 +428,25 @@ def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     _lib.check(_lib.load().pnr_sample_labels(_p(z), R, N, _p(hit_t), _p(hit_box), _p(hit_count), hit_box.shape[1],
                                              _p(box_ids), _p(ls), _p(li), _stream()), "pnr_sample_labels")
     return ls, li
+
+
+def panoptic_labels(sem, inst=None, is_thing=None):
+    """Composited maps -> (semantic label, instance label, panoptic id), each (R) int32 (pnr_panoptic_labels)."""
+    sem, inst = _chk(sem, "sem"), _chk(inst, "inst")
+    is_thing = _chk(is_thing, "is_thing", torch.int32)
+    R, C = sem.shape
+    K = inst.shape[1] if inst is not None else 0
+    out = [torch.empty(R, device=sem.device, dtype=torch.int32) for _ in range(3)]
+    _lib.check(_lib.load().pnr_panoptic_labels(_p(sem), _p(inst), _p(is_thing), R, C, K, _p(out[0]), _p(out[1]), _p(out[2]),
+                                               _stream()), "pnr_panoptic_labels")
+    return tuple(out)
+
+
+def confusion(pred, gt, n_classes, conf=None):
+    """Accumulate the (n_classes, n_classes) int64 confusion matrix conf[gt, pred] (pnr_confusion).  gt < 0 = ignore."""
+    pred, gt = _chk(pred, "pred", torch.int32), _chk(gt, "gt", torch.int32)
+    if conf is None:
+        conf = torch.zeros((n_classes, n_classes), device=pred.device, dtype=torch.int64)
+    _chk(conf, "conf", torch.int64)
+    _lib.check(_lib.load().pnr_confusion(_p(pred), _p(gt), pred.numel(), int(n_classes), _p(conf), _stream()), "pnr_confusion")
+    return conf

@@ -1,0 +1,61 @@
+"""GPU tests of SURVEY.md 8f rank 4: label post-processing and the evaluator counters, bit-exact with oracle/np_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as no
+from panopticnerf_amd import ops
+from panopticnerf_amd.evaluate import Evaluator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R,C,K", [(1, 2, 0), (1000, 45, 32), (70001, 19, 7)])
+def test_panoptic_labels_bit_exact(dev, R, C, K):
+    g = torch.Generator().manual_seed(R)
+    sem = torch.randn(R, C, generator=g)
+    sem[::7] = sem[::7].round()                       # ties: lowest index wins
+    inst = torch.randn(R, K, generator=g).round() if K else None
+    thing = (torch.arange(C) % 3 == 0).int()
+    sl, il, pan = ops.panoptic_labels(sem.to(dev), None if inst is None else inst.to(dev), thing.to(dev))
+    rs, ri, rp = no.panoptic_labels(sem.numpy(), None if inst is None else inst.numpy(), thing.numpy())
+    assert np.array_equal(sl.cpu().numpy(), rs) and np.array_equal(il.cpu().numpy(), ri) and np.array_equal(pan.cpu().numpy(), rp)
+    sl2, il2, _ = ops.panoptic_labels(sem.to(dev), None if inst is None else inst.to(dev), None)      # every class a thing
+    assert torch.equal(sl2, sl) and (K == 0 or (il2 >= 0).all())
+
+
+def test_confusion_exact_and_accumulates(dev):
+    g = torch.Generator().manual_seed(1)
+    C, n = 45, 529408
+    pred = torch.randint(0, C, (n,), generator=g, dtype=torch.int32)
+    gt = torch.randint(-1, C + 1, (n,), generator=g, dtype=torch.int32)      # -1 and C are ignored
+    conf = ops.confusion(pred.to(dev), gt.to(dev), C)
+    ref = no.confusion(pred.numpy(), gt.numpy(), C)
+    assert np.array_equal(conf.cpu().numpy(), ref)
+    conf = ops.confusion(pred.to(dev), gt.to(dev), C, conf)                  # second frame accumulates
+    assert np.array_equal(conf.cpu().numpy(), 2 * ref)
+    assert ops.confusion(pred[:0].to(dev), gt[:0].to(dev), C).sum().item() == 0
+
+
+def test_evaluator_psnr_miou(dev):
+    g = torch.Generator().manual_seed(3)
+    R, C, K = 5000, 6, 3
+    ev = Evaluator(n_classes=C, is_thing=[1, 0, 0, 1, 0, 0])
+    ref_conf = np.zeros((C, C), np.int64)
+    psnr = []
+    for f in range(3):
+        rgb, gt_rgb = torch.rand(1, R, 3, generator=g), torch.rand(1, R, 3, generator=g)
+        sem, inst = torch.randn(1, R, C, generator=g), torch.randn(1, R, K, generator=g)
+        lab = torch.randint(-1, C, (1, R), generator=g)
+        out = {"rgb_1": rgb.to(dev), "semantic_1": sem.to(dev), "instance_1": inst.to(dev)}
+        res = ev.evaluate(out, {"rgb": gt_rgb.to(dev), "pseudo_label": lab.to(dev)})
+        sl, il, pan = no.panoptic_labels(sem[0].numpy(), inst[0].numpy(), np.array([1, 0, 0, 1, 0, 0]))
+        assert np.array_equal(res["panoptic_id"].cpu().numpy(), pan)
+        ref_conf += no.confusion(sl, lab[0].numpy(), C)
+        psnr.append(-10 * np.log10(((rgb - gt_rgb).double() ** 2).mean().item()))
+    s = ev.summarize()
+    tp = np.diag(ref_conf).astype(float)
+    union = ref_conf.sum(0) + ref_conf.sum(1) - tp
+    assert abs(s["psnr"] - np.mean(psnr)) < 1e-4
+    assert abs(s["miou"] - np.mean(tp / union)) < 1e-12 and abs(s["pixel_acc"] - tp.sum() / ref_conf.sum()) < 1e-12
+    assert ev.summarize() == {}                       # counters reset

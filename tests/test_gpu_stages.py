@@ -316,3 +316,20 @@ def test_raw_channel_stride_is_free(dev):
         assert all(torch.equal(a[k], b[k]) for k in a)
     with pytest.raises(ValueError):
         ops.composite(dense.T.contiguous().T, z, rays, C, K, True)     # sample stride != 1
+
+
+@pytest.mark.gpu
+def test_gen_rays_bit_exact_with_c_oracle(dev):
+    """pnr_gen_rays: whole frame and pixel subsets, bit-exact with pnro_gen_rays; empty input is a no-op."""
+    import math
+    intr = [552.554261, 560.25, 682.049453, 238.769549]
+    c, s = math.cos(-0.7), math.sin(-0.7)
+    c2w = np.array([[c, 0.02, s, 12.5], [-0.01, 1, 0.03, 1.55], [-s, 0.01, c, -3.25]], np.float32)
+    full = ops.gen_rays(intr, c2w, 1408, 376, 0.5, 100.0, device=dev)
+    assert np.array_equal(N_(full), co.gen_rays(intr, c2w, 1408, 376, 0.5, 100.0))
+    g = torch.Generator().manual_seed(0)
+    pix = torch.randint(0, 1408 * 376, (4099,), generator=g, dtype=torch.int32)
+    sub = ops.gen_rays(intr, c2w, 1408, 376, 0.25, 80.0, pix=pix.to(dev))
+    assert np.array_equal(N_(sub), co.gen_rays(intr, c2w, 1408, 376, 0.25, 80.0, pix.numpy()))
+    assert torch.equal(sub, full[pix.long().to(dev)] * torch.tensor([1, 1, 1, 1, 1, 1, 0, 0], device=dev) + torch.tensor([0, 0, 0, 0, 0, 0, 0.25, 80.0], device=dev))
+    assert ops.gen_rays(intr, c2w, 1408, 376, 0.5, 100.0, pix=torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 8)

@@ -211,3 +211,25 @@ def test_stratified_endpoints(N):
     rays = np.array([[0, 0, 0, 0, 0, 1, 2.0, 6.0]], np.float32)
     z = co.stratified(rays, N)
     assert z[0, 0] == 2.0 and (N == 1 or z[0, -1] == 6.0)
+
+
+def test_gen_rays_c_oracle_matches_torch_oracle_and_synthetic():
+    """the two restatements of the ray generator agree bit for bit, reproduce the synthetic KITTI-360-shaped
+    camera the benches use, and honour pixel subsets and a rotated / translated pose."""
+    import math
+    from panopticnerf_amd import synthetic as syn
+    intr = [syn.KITTI_F, syn.KITTI_F, syn.KITTI_CX, syn.KITTI_CY]
+    c2w0 = np.array([[1, 0, 0, 0.0], [0, 1, 0, 1.55], [0, 0, 1, 0.0]], np.float32)
+    full = co.gen_rays(intr, c2w0, syn.KITTI_W, syn.KITTI_H, 0.5, 100.0)
+    assert np.array_equal(full, to.gen_rays(intr, c2w0, syn.KITTI_W, syn.KITTI_H, 0.5, 100.0).numpy())
+    assert np.array_equal(full, syn.camera_rays().numpy())
+    yaw = 0.3
+    c, s = math.cos(yaw), math.sin(yaw)
+    c2w = np.array([[c, 0, s, 3.0], [0, 1, 0, 1.5], [-s, 0, c, -7.0]], np.float32)
+    pix = np.array([0, 1407, 1408, 376 * 1408 - 1, 12345], np.int32)
+    sub = co.gen_rays([500.0, 510.0, 700.0, 200.0], c2w, 1408, 376, 1.0, 50.0, pix)
+    assert np.array_equal(sub, to.gen_rays([500.0, 510.0, 700.0, 200.0], c2w, 1408, 376, 1.0, 50.0, pix).numpy())
+    assert np.allclose(sub[:, :3], [3.0, 1.5, -7.0]) and np.all(sub[:, 6] == 1.0) and np.all(sub[:, 7] == 50.0)
+    # pixel (i=1407, j=0): x = (1407-700)/500, y = (0-200)/510 rotated by the yaw
+    x, y = (1407 - 700.0) / 500.0, (0 - 200.0) / 510.0
+    assert np.allclose(sub[1, 3:6], [c * x + s, y, -s * x + c], atol=1e-6)
