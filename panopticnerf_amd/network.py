@@ -95,6 +95,43 @@ class Network(nn.Module):
     def packed_bwd(self, level, device):
         return self._pack(level, device, "bf16", True)
 
+    # --- checkpoint interop: reference-trained weights -> this module
+    DEFAULT_KEY_MAP = (
+        (r"^(module\.|net\.|network\.)+", ""),                       # DataParallel / wrapper prefixes
+        (r"^(coarse|nerf_coarse|model_coarse|cascade\.0)\.", "nerf_0."),
+        (r"^(fine|nerf_fine|model_fine|cascade\.1)\.", "nerf_1."),
+        (r"\.sigma_linear\.", ".alpha_linear."),
+        (r"\.(semantic_linear|semantic_head)\.(\d+)\.", r".semantic_linears.\2."),
+        (r"\.(instance_linear|instance_head)\.(\d+)\.", r".instance_linears.\2."),
+    )
+
+    def load_reference_state_dict(self, sd, key_map=None, strict=True):
+        """Load a reference checkpoint's network state_dict.  key_map: sequence of (regex, replacement) applied in order
+        to every key (default: DEFAULT_KEY_MAP -- guesses at the reference's naming; the real names
+        cannot be checked here, pass the right table once they can).  Shapes must match exactly: a (out,in) weight of
+        the wrong size is an error, never a silent reshape.  Returns {'loaded': [...], 'missing': [...],
+        'unexpected': [...]}; with strict=True anything missing or unexpected raises."""
+        import re
+        own = self.state_dict()
+        mapped, unexpected = {}, []
+        for k, v in sd.items():
+            nk = k
+            for pat, rep in (key_map if key_map is not None else self.DEFAULT_KEY_MAP):
+                nk = re.sub(pat, rep, nk)
+            if nk in own:
+                if tuple(v.shape) != tuple(own[nk].shape):
+                    raise ValueError(f"{k} -> {nk}: shape {tuple(v.shape)} != {tuple(own[nk].shape)}")
+                mapped[nk] = v
+            else:
+                unexpected.append(k)
+        missing = [k for k in own if k not in mapped]
+        if strict and (missing or unexpected):
+            raise KeyError(f"load_reference_state_dict: missing {missing[:6]}{'...' if len(missing) > 6 else ''}, "
+                           f"unexpected {unexpected[:6]}{'...' if len(unexpected) > 6 else ''}")
+        self.load_state_dict(mapped, strict=False)
+        self._packed.clear()                 # the packed images are rebuilt from the new parameters
+        return {"loaded": sorted(mapped), "missing": missing, "unexpected": unexpected}
+
     def forward(self, *a, **k):
         raise RuntimeError("Network is evaluated by Renderer.render() through the fused HIP kernel; "
                            "there is no torch forward (and no CPU fallback).")

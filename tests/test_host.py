@@ -170,3 +170,27 @@ def test_sharded_render_world2_gloo(n_rays):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)
+
+
+def test_reference_checkpoint_key_map():
+    """a checkpoint with wrapper prefixes / alternative names loads through the key map; wrong shapes and
+    unknown keys are loud."""
+    cfg = NS(D=2, W=128, skips=[], num_classes=3, N_importance=8)
+    src, dst = make_network(cfg), make_network(cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.normal_()
+    ren = lambda k: "module.net." + k.replace("nerf_0.", "coarse.").replace("nerf_1.", "fine.").replace("alpha_linear", "sigma_linear")
+    sd = {ren(k): v.clone() for k, v in src.state_dict().items()}
+    rep = dst.load_reference_state_dict(sd)
+    assert not rep["missing"] and not rep["unexpected"] and len(rep["loaded"]) == len(sd)
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    with pytest.raises(KeyError):
+        dst.load_reference_state_dict({**sd, "module.net.coarse.extra.weight": torch.zeros(1)})
+    bad = dict(sd)
+    k0 = next(k for k in bad if k.endswith("rgb_linear.weight"))
+    bad[k0] = torch.zeros(3, 7)
+    with pytest.raises(ValueError):
+        dst.load_reference_state_dict(bad)
+    rep = dst.load_reference_state_dict({k: v for k, v in sd.items() if "fine." not in k}, strict=False)
+    assert rep["missing"] and all(m.startswith("nerf_1.") for m in rep["missing"])
