@@ -233,3 +233,36 @@ def test_gen_rays_c_oracle_matches_torch_oracle_and_synthetic():
     # pixel (i=1407, j=0): x = (1407-700)/500, y = (0-200)/510 rotated by the yaw
     x, y = (1407 - 700.0) / 500.0, (0 - 200.0) / 510.0
     assert np.allclose(sub[1, 3:6], [c * x + s, y, -s * x + c], atol=1e-6)
+
+
+def test_loss_oracle_known_answers():
+    """SURVEY 8f-1 oracle (torch_oracle.losses / ce3d) against closed forms, so the GPU tests' checker is itself pinned."""
+    import math
+    R, C = 4, 3
+    maps = {"rgb": torch.zeros(R, 3), "depth": torch.tensor([1.0, 2.0, 3.0, 4.0]),
+            "semantic": torch.zeros(R, C),                                   # uniform logits: CE = log C
+            "fix_semantic": torch.tensor([[0.5, 0.0, 0.0], [0.0, 0.25, 0.0], [0.0, 0.0, 1.0], [0.2, 0.2, 0.2]])}
+    tg = {"rgb": torch.full((R, 3), 0.5), "depth": torch.tensor([2.0, 0.0, 1.0, -1.0]),          # two valid depths
+          "semantic": torch.tensor([0, 1, 2, -1], dtype=torch.int32)}
+    w = {"rgb": 2.0, "depth": 0.5, "semantic": 1.0, "fix_semantic": 3.0}
+    terms, total = to.losses(maps, tg, w, n_sem=C, fix_eps=0.0)
+    assert abs(terms["rgb"].item() - 0.25) < 1e-7
+    assert abs(terms["depth"].item() - (1.0 + 2.0) / 2) < 1e-7                                    # |1-2|, |3-1| over 2 valid rays
+    assert abs(terms["semantic"].item() - math.log(3)) < 1e-6
+    assert abs(terms["fix_semantic"].item() - (-(math.log(0.5) + math.log(0.25) + math.log(1.0)) / 3)) < 1e-6
+    assert abs(total.item() - (2 * 0.25 + 0.5 * 1.5 + math.log(3) + 3 * (math.log(2) + math.log(4)) / 3)) < 1e-5
+    terms2, _ = to.losses(maps, tg, w, n_sem=C, depth_l2=True)
+    assert abs(terms2["depth"].item() - (1.0 + 4.0) / 2) < 1e-7
+    ce, n = to.ce3d(torch.tensor([[0.0, 0.0], [10.0, -10.0], [3.0, 3.0]]), torch.tensor([1, 0, -1]))
+    assert n == 2 and abs(ce.item() - (math.log(2) + math.log1p(math.exp(-20.0))) / 2) < 1e-6
+    assert to.ce3d(torch.zeros(2, 2), torch.tensor([-1, -1]))[1] == 0
+
+
+def test_postprocessing_oracle_known_answers():
+    """SURVEY 8f-4 oracle (np_oracle.panoptic_labels / confusion): ties, stuff vs thing, ignore labels."""
+    sem = np.array([[0.1, 0.9, 0.9], [2.0, 1.0, 0.0], [0.0, 0.0, 0.0]], np.float32)
+    inst = np.array([[0.0, 5.0], [7.0, 1.0], [1.0, 1.0]], np.float32)
+    sl, il, pan = no.panoptic_labels(sem, inst, is_thing=np.array([0, 1, 1]))
+    assert sl.tolist() == [1, 0, 0] and il.tolist() == [1, -1, -1] and pan.tolist() == [1001, 0, 0]
+    conf = no.confusion(np.array([0, 1, 1, 2, 5]), np.array([0, 1, 2, -1, 1]), 3)
+    assert conf.tolist() == [[1, 0, 0], [0, 1, 0], [0, 1, 0]]
