@@ -175,6 +175,15 @@ int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, const float*
                             const float* g_inst, const float* g_weights, const int32_t* label_sem,
                             const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
                             const float* ce_sem, const float* ce_inst, float* d_raw, void* stream);
+/* ... and with pnr_composite's sem_mode: 1 = the semantic / instance maps composite softmax(logits) per sample
+ * (g_sem / g_inst are then gradients of probability maps):  d x_{i,c} = w_i s_c (g_c - sum_k g_k s_k),
+ * dL/dw_i += sum_k g_k s_k. */
+int pnr_composite_backward3(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                            const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst, int sem_mode,
+                            const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                            const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                            const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                            const float* ce_sem, const float* ce_inst, float* d_raw, void* stream);
 
 /* ---- 8f-1: the trainer's loss wrapper (the reference's NetworkWrapper) on the maps of
  * one level, fused with the gradient of the weighted total w.r.t. every map.  All reductions are means:
@@ -191,6 +200,8 @@ typedef struct pnr_loss_cfg {
     float w_rgb, w_depth, w_sem, w_fix_sem, w_inst, w_fix_inst;
     int32_t depth_l2;
     float fix_eps;
+    int32_t maps_are_prob;   /* 1: sem / inst are composited PROBABILITIES (pnr_composite sem_mode 1): their 2D term is
+                                -log(map[label] + fix_eps) like the fixed field's, not a softmax cross-entropy */
 } pnr_loss_cfg;
 int64_t pnr_losses_workspace_bytes(int64_t n_rays);
 int pnr_losses(const pnr_loss_cfg* cfg, int64_t n_rays, int n_sem, int n_inst, const float* rgb, const float* depth,

@@ -283,7 +283,7 @@ def render_rays(params, cfg, rays, n_samples, n_importance=0, lindisp=False, t_r
 # ---- loss wrapper.  PARITY UNPINNED like everything above: the reference's NetworkWrapper is
 # not in the mount; the terms follow SURVEY.md section 2 row 8 (RGB MSE, stereo-depth L1/L2, 2D pseudo-label CE on the
 # learned and on the fixed field, 3D bbox CE).
-def losses(maps, targets, weights, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5):
+def losses(maps, targets, weights, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5, maps_are_prob=False):
     """maps: rgb (R,3), depth (R), semantic/fix_semantic (R,C), instance/fix_instance (R,K) (any subset);
     targets: rgb, depth, semantic (R) int, instance (R) int.  Returns (dict of the six means, weighted total)."""
     import torch.nn.functional as F
@@ -302,7 +302,9 @@ def losses(maps, targets, weights, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e
         v = (t >= 0) & (t < n)
         cnt = max(int(v.sum()), 1)
         tl = t[v].long()
-        if key in maps:
+        if key in maps and maps_are_prob:
+            out[key] = (-(maps[key][v].gather(1, tl[:, None])[:, 0] + fix_eps).log()).sum() / cnt if v.any() else z()
+        elif key in maps:
             out[key] = F.cross_entropy(maps[key][v], tl, reduction="sum") / cnt if v.any() else z()
         if fkey in maps:
             out[fkey] = (-(maps[fkey][v].gather(1, tl[:, None])[:, 0] + fix_eps).log()).sum() / cnt if v.any() else z()

@@ -18,7 +18,7 @@ class LossCfg(ctypes.Structure):
     """pnr_loss_cfg (include/pnr.h)."""
     _fields_ = [("w_rgb", ctypes.c_float), ("w_depth", ctypes.c_float), ("w_sem", ctypes.c_float),
                 ("w_fix_sem", ctypes.c_float), ("w_inst", ctypes.c_float), ("w_fix_inst", ctypes.c_float),
-                ("depth_l2", ctypes.c_int32), ("fix_eps", ctypes.c_float)]
+                ("depth_l2", ctypes.c_int32), ("fix_eps", ctypes.c_float), ("maps_are_prob", ctypes.c_int32)]
 
 
 class MlpDesc(ctypes.Structure):
@@ -67,6 +67,8 @@ SIGNATURES = {
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
                                        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward2": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
+                                        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_composite_backward3": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                                         c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_losses_workspace_bytes": (c_i64, [c_i64]),
     "pnr_losses": (c_int, [ctypes.POINTER(LossCfg), c_i64, c_int, c_int] + [c_f] * 19),

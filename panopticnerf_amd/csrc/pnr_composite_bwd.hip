@@ -25,6 +25,7 @@ struct CompositeBwdArgs {
     // per-sample 3D cross-entropy of the learned logits against the bbox labels (pnr_ce3d is its forward):
     // d_raw[c][s] += *ce_x * (softmax_c(raw_x[:, s]) - [c == label_s])  for label_s >= 0
     const float *ce_sem, *ce_inst;         // device scalars (upstream gradient * weight / count) or null
+    int sem_mode;                          // 0: logits are composited; 1: softmax(logits) per sample is composited
 };
 
 struct f4 { float v[4]; };
@@ -124,8 +125,21 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
                 }
             }
         };
-        if (ces != 0.0f) lse(a.C, 4, mx_s, den_s);
-        if (cei != 0.0f) lse(a.K, 4 + a.C, mx_i, den_i);
+        if (ces != 0.0f || (a.sem_mode && a.g_sem)) lse(a.C, 4, mx_s, den_s);
+        if (cei != 0.0f || (a.sem_mode && a.g_inst)) lse(a.K, 4 + a.C, mx_i, den_i);
+        // softmax compositing: map_c = sum_i w_i s_{i,c}, s = softmax(x_i).  Needs dot_i = sum_c g_c s_{i,c}:
+        //   dL/dw_i += dot_i,   d x_{i,c} = w_i s_{i,c} (g_c - dot_i)
+        f4 dot_s = {{0, 0, 0, 0}}, dot_i = {{0, 0, 0, 0}};
+        auto gdot = [&](int nch, int ch0, const float* gp, const f4& mx, const f4& den, f4& dot) {
+            for (int c = 0; c < nch; ++c) {
+                const float gc = gp[rayc * nch + c];
+                const f4 v = ld4(a.raw + (int64_t)(ch0 + c) * a.sc + s0, active);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dot.v[k] = fmaf(gc, expf(v.v[k] - mx.v[k]) / den.v[k], dot.v[k]);
+            }
+        };
+        if (a.sem_mode && a.g_sem) gdot(a.C, 4, a.g_sem, mx_s, den_s, dot_s);
+        if (a.sem_mode && a.g_inst) gdot(a.K, 4 + a.C, a.g_inst, mx_i, den_i, dot_i);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float gc = a.g_rgb ? a.g_rgb[rayc * 3 + c] : 0.0f;
@@ -148,7 +162,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             const f4 r = ld4(a.raw + (int64_t)(4 + c) * a.sc + s0, active);
             f4 dr;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { G.v[k] = fmaf(gc, r.v[k], G.v[k]); dr.v[k] = w.v[k] * gc; }
+            for (int k = 0; k < 4; ++k) {
+                if (a.sem_mode && gp) {
+                    const float sc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
+                    dr.v[k] = w.v[k] * sc * (gc - (is_s ? dot_s.v[k] : dot_i.v[k]));
+                } else {
+                    G.v[k] = fmaf(gc, r.v[k], G.v[k]);
+                    dr.v[k] = w.v[k] * gc;
+                }
+            }
             const float ce = is_s ? ces : cei;
             if (ce != 0.0f) {
                 const int cc = is_s ? c : c - a.C;
@@ -163,6 +185,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
         }
 
+        if (a.sem_mode) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) G.v[k] += dot_s.v[k] + dot_i.v[k];
+        }
         // ---- S_i = sum_{k>i} G_k w_k : lane-local suffix, then a segmented reverse (suffix) scan over lanes
         f4 gwk;
 #pragma unroll
@@ -208,12 +234,42 @@ PNR_EXPORT int pnr_composite_backward(const float* raw, int64_t raw_stride_c, co
                                    g_sem, g_inst, g_weights, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, stream);
 }
 
+static int composite_backward_impl(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                   const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst, int sem_mode,
+                                   const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                   const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                                   const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                                   const float* ce_sem, const float* ce_inst, float* d_raw, void* stream);
+
 PNR_EXPORT int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
                                        const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst,
                                        const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
                                        const float* g_inst, const float* g_weights, const int32_t* label_sem,
                                        const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
                                        const float* ce_sem, const float* ce_inst, float* d_raw, void* stream)
+{
+    return composite_backward_impl(raw, raw_stride_c, z, rays, noise, n_rays, n_samples, n_sem, n_inst, 0, g_rgb, g_depth, g_acc, g_sem,
+                                   g_inst, g_weights, label_sem, label_inst, g_fix_sem, g_fix_inst, ce_sem, ce_inst, d_raw, stream);
+}
+
+PNR_EXPORT int pnr_composite_backward3(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                       const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst, int sem_mode,
+                                       const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                       const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                                       const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                                       const float* ce_sem, const float* ce_inst, float* d_raw, void* stream)
+{
+    PNR_REQUIRE(sem_mode == 0 || sem_mode == 1, "pnr_composite_backward: sem_mode must be 0 (logits) or 1 (softmax)");
+    return composite_backward_impl(raw, raw_stride_c, z, rays, noise, n_rays, n_samples, n_sem, n_inst, sem_mode, g_rgb, g_depth, g_acc,
+                                   g_sem, g_inst, g_weights, label_sem, label_inst, g_fix_sem, g_fix_inst, ce_sem, ce_inst, d_raw, stream);
+}
+
+static int composite_backward_impl(const float* raw, int64_t raw_stride_c, const float* z, const float* rays,
+                                   const float* noise, int64_t n_rays, int n_samples, int n_sem, int n_inst, int sem_mode,
+                                   const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_sem,
+                                   const float* g_inst, const float* g_weights, const int32_t* label_sem,
+                                   const int32_t* label_inst, const float* g_fix_sem, const float* g_fix_inst,
+                                   const float* ce_sem, const float* ce_inst, float* d_raw, void* stream)
 {
     PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0,
                 "pnr_composite_backward: n_samples=%d must be a multiple of 4 in [4,256]", n_samples);
@@ -229,7 +285,7 @@ PNR_EXPORT int pnr_composite_backward2(const float* raw, int64_t raw_stride_c, c
     a.C = n_sem; a.K = n_inst; a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_sem = g_sem; a.g_inst = g_inst;
     a.g_w = g_weights; a.d_raw = d_raw;
     a.label_sem = label_sem; a.label_inst = label_inst; a.g_fix_sem = g_fix_sem; a.g_fix_inst = g_fix_inst;
-    a.ce_sem = ce_sem; a.ce_inst = ce_inst;
+    a.ce_sem = ce_sem; a.ce_inst = ce_inst; a.sem_mode = sem_mode;
     int sub = 1;
     while (sub < n_samples / 4) sub <<= 1;
     const int rpw = 64 / sub;

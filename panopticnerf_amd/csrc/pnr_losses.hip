@@ -92,7 +92,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_loss_maps(LossArgs a)
             const bool valid = lab >= 0 && lab < n_cls;
             if (logit) {
                 float* g = g_logit ? g_logit + r * n_cls : nullptr;
-                if (valid) t_ce = ce_row(logit + r * n_cls, n_cls, lab, w_ce / n, g);
+                if (a.cfg.maps_are_prob) {              // probability map: NLL of the labelled class
+                    if (g) for (int c = 0; c < n_cls; ++c) g[c] = 0.0f;
+                    if (valid) {
+                        const float p = logit[r * n_cls + lab] + a.cfg.fix_eps;
+                        t_ce = -logf(p);
+                        if (g) g[lab] = -w_ce / (p * n);
+                    }
+                } else if (valid) t_ce = ce_row(logit + r * n_cls, n_cls, lab, w_ce / n, g);
                 else if (g) for (int c = 0; c < n_cls; ++c) g[c] = 0.0f;
             }
             if (fix) {

@@ -28,9 +28,9 @@ class PanopticLossFn(torch.autograd.Function):
     """(total, stats) of one level; differentiable w.r.t. the maps through the gradients pnr_losses wrote."""
 
     @staticmethod
-    def forward(ctx, weights, n_sem, n_inst, depth_l2, fix_eps, targets, keys, *maps):
+    def forward(ctx, weights, n_sem, n_inst, depth_l2, fix_eps, prob, targets, keys, *maps):
         m = dict(zip(keys, maps))
-        out, grads = ops.losses(weights, m, targets, n_sem, n_inst, depth_l2, fix_eps, True)
+        out, grads = ops.losses(weights, m, targets, n_sem, n_inst, depth_l2, fix_eps, True, prob)
         ctx.keys = keys
         ctx.save_for_backward(*[grads.get(k, torch.zeros(0, device=out.device)) for k in keys])
         ctx.mark_non_differentiable(out)
@@ -39,7 +39,7 @@ class PanopticLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_stats):
         gs = ctx.saved_tensors
-        return (None,) * 7 + tuple((g * g_total if g.numel() else None) for g in gs)
+        return (None,) * 8 + tuple((g * g_total if g.numel() else None) for g in gs)
 
 
 class NetworkWrapper(nn.Module):
@@ -70,7 +70,8 @@ class NetworkWrapper(nn.Module):
                 continue
             keys = tuple(k for k in _TERMS if f"{k}_{lv}" in ret)
             maps = [ret[f"{k}_{lv}"].reshape(-1, *ret[f"{k}_{lv}"].shape[2:]) for k in keys]
-            total, st = PanopticLossFn.apply(self.weights, C, K, self.depth_l2, self.fix_eps, targets, keys, *maps)
+            total, st = PanopticLossFn.apply(self.weights, C, K, self.depth_l2, self.fix_eps, self.renderer.sem_mode == 1,
+                                             targets, keys, *maps)
             loss = loss + total
             for i, k in enumerate(_TERMS):
                 stats[f"{k}_loss_{lv}"] = st[i]

@@ -322,11 +322,11 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
 
 
 def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem=None, label_inst=None,
-                       ce_sem=None, ce_inst=None):
+                       ce_sem=None, ce_inst=None, sem_mode=0):
     """Backward of composite() for channel-major raw.  grads: dict with any of rgb, depth, acc, semantic,
     instance, weights, fix_semantic, fix_instance (upstream gradients, contiguous fp32); the fixed-field
     gradients need the per-sample labels.  ce_sem / ce_inst: 1-element device tensors, the scale of the per-sample
-    3D cross-entropy gradient (see ce3d).  Returns d_raw (ch, R*N).  SURVEY 8a row a9, 8f-1."""
+    3D cross-entropy gradient (see ce3d).  sem_mode as in composite().  Returns d_raw (ch, R*N).  SURVEY 8a row a9, 8f-1."""
     raw, z, rays = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays")
     noise = _chk(noise, "noise")
     label_sem = _chk(label_sem, "label_sem", torch.int32)
@@ -336,7 +336,7 @@ def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem
     ce_sem = None if ce_sem is None else _chk(ce_sem.reshape(1).float().contiguous(), "ce_sem")
     ce_inst = None if ce_inst is None else _chk(ce_inst.reshape(1).float().contiguous(), "ce_inst")
     d_raw = torch.empty_like(raw)
-    _lib.check(_lib.load().pnr_composite_backward2(_p(raw), R * N, _p(z), _p(rays), _p(noise), R, N, n_sem, n_inst,
+    _lib.check(_lib.load().pnr_composite_backward3(_p(raw), R * N, _p(z), _p(rays), _p(noise), R, N, n_sem, n_inst, int(sem_mode),
                                                    _p(g.get("rgb")), _p(g.get("depth")), _p(g.get("acc")),
                                                    _p(g.get("semantic")), _p(g.get("instance")), _p(g.get("weights")),
                                                    _p(label_sem), _p(label_inst), _p(g.get("fix_semantic")),
@@ -348,7 +348,7 @@ def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem
 _LOSS_KEYS = ("rgb", "depth", "semantic", "fix_semantic", "instance", "fix_instance")
 
 
-def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5, want_grads=True):
+def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5, want_grads=True, maps_are_prob=False):
     """The trainer's per-ray loss terms of one level and the gradient of their weighted total w.r.t. every map
     (pnr_losses; SURVEY 8f-1).  weights: dict over rgb/depth/semantic/fix_semantic/instance/fix_instance;
     maps: dict of (R,·) fp32 GPU tensors (any subset); targets: rgb (R,3), depth (R), semantic (R) int32,
@@ -360,7 +360,7 @@ def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e
     t_rgb, t_depth = _chk(targets.get("rgb"), "rgb_gt"), _chk(targets.get("depth"), "depth_gt")
     t_sem = _chk(targets.get("semantic"), "sem_gt", torch.int32)
     t_inst = _chk(targets.get("instance"), "inst_gt", torch.int32)
-    cfg = _lib.LossCfg(*(float(weights.get(k, 0.0)) for k in _LOSS_KEYS), int(bool(depth_l2)), float(fix_eps))
+    cfg = _lib.LossCfg(*(float(weights.get(k, 0.0)) for k in _LOSS_KEYS), int(bool(depth_l2)), float(fix_eps), int(bool(maps_are_prob)))
     use = {"rgb": t_rgb is not None, "depth": t_depth is not None, "semantic": t_sem is not None, "fix_semantic": t_sem is not None,
            "instance": t_inst is not None, "fix_instance": t_inst is not None}
     m = {k: v for k, v in m.items() if use[k]}

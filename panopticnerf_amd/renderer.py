@@ -88,9 +88,6 @@ class Renderer:
         if not rays.is_cuda:
             raise RuntimeError("Renderer.render: batch['rays'] must be on the GPU (no CPU fallback)")
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
-        if grad and self.sem_mode != 0:
-            raise NotImplementedError("Renderer.render: gradients are implemented for logit compositing "
-                                      "(semantic_activation='none') only")
         if grad and self.net.precision != "bf16":
             raise NotImplementedError("Renderer.render: the backward kernels are bf16; set precision='bf16' to train")
         lead = rays.shape[:-1]

@@ -176,7 +176,7 @@ class LevelFn(torch.autograd.Function):
         desc, img = net.packed(lv, dev, "bf16")
         C, K = nerf.n_sem, nerf.n_inst
         raw, acts = ops.mlp_forward_train(desc, img, rays, z)
-        out = ops.composite(raw, z, rays, C, K, True, noise, ls, li, 0, rend.white_bkgd, True)
+        out = ops.composite(raw, z, rays, C, K, True, noise, ls, li, rend.sem_mode, rend.white_bkgd, True)
         empty = torch.zeros(0, device=dev)
         ce_s = ops.ce3d(raw, 4, C, ls) if (C and ls is not None) else None
         ce_i = ops.ce3d(raw, 4 + C, K, li) if (K and li is not None) else None
@@ -209,7 +209,7 @@ class LevelFn(torch.autograd.Function):
         sc_s = (g_ces / ce_s[1].clamp(min=1.0)) if (g_ces is not None and ce_s.numel()) else None
         sc_i = (g_cei / ce_i[1].clamp(min=1.0)) if (g_cei is not None and ce_i.numel()) else None
         d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None,
-                                       ls if ctx.has_ls else None, li if ctx.has_li else None, sc_s, sc_i)
+                                       ls if ctx.has_ls else None, li if ctx.has_li else None, sc_s, sc_i, rend.sem_mode)
         desc, img_b = net.packed_bwd(lv, rays.device)
         dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
         shapes = {n: p.shape for n, p in nerf.named_parameters()}

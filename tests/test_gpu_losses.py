@@ -151,3 +151,37 @@ def test_network_wrapper_end_to_end(dev):
             r = _rel(p.grad.cpu(), ref_params[lv][name].grad)
             assert r < 6e-2, (lv, name, r)
     assert set(stats) >= {"loss", "rgb_loss_0", "fix_semantic_loss_1", "ce3d_semantic_loss_1"}
+
+
+@pytest.mark.parametrize("N", [16, 192])
+def test_softmax_compositing_backward(dev, N):
+    """sem_mode 1 (softmax(logits) composited per sample): d_raw of pnr_composite_backward3 vs torch autograd of the
+    oracle's raw2outputs(sem_mode=1), together with every other gradient source; and the probability-map loss terms."""
+    R, C, K = 29, 7, 5
+    raw, z, rays, ls, li = _level_inputs(R, N, C, K, 100 + N)
+    g = torch.Generator().manual_seed(4)
+    up = {"rgb": torch.randn(R, 3, generator=g), "depth": torch.randn(R, generator=g), "acc": torch.randn(R, generator=g),
+          "semantic": torch.randn(R, C, generator=g), "instance": torch.randn(R, K, generator=g),
+          "fix_semantic": torch.randn(R, C, generator=g), "weights": torch.randn(R, N, generator=g)}
+    leaf = raw.clone().requires_grad_(True)
+    o = to.raw2outputs(leaf, z, rays[:, 3:6], C, K, label_sem=ls, label_inst=li, sem_mode=1)
+    sum((o[k] * v).sum() for k, v in up.items()).backward()
+    raw_cm = raw.reshape(R * N, -1).T.contiguous().to(dev)
+    fwd = ops.composite(raw_cm, z.to(dev), rays.to(dev), C, K, True, None, ls.to(dev), li.to(dev), 1)
+    assert (fwd["semantic"].cpu() - o["semantic"].detach()).abs().max() < 2e-5
+    d = ops.composite_backward(raw_cm, z.to(dev), rays.to(dev), C, K, {k: v.to(dev) for k, v in up.items()}, None, ls.to(dev),
+                               li.to(dev), None, None, 1)
+    ref = leaf.grad.reshape(R * N, -1).T
+    assert _rel(d.cpu(), ref) < 2e-4, _rel(d.cpu(), ref)
+    # probability maps: NLL terms
+    maps = {"semantic": fwd["semantic"].cpu(), "fix_semantic": fwd["fix_semantic"].cpu()}
+    tg = {"semantic": torch.randint(-1, C, (R,), generator=g, dtype=torch.int32)}
+    w = {"semantic": 0.7, "fix_semantic": 0.3}
+    leafm = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+    terms, total = to.losses(leafm, tg, w, C, 0, maps_are_prob=True)
+    total.backward()
+    out, grads = ops.losses(w, {k: v.to(dev) for k, v in maps.items()}, {k: v.to(dev) for k, v in tg.items()}, C, 0, maps_are_prob=True)
+    assert abs(out[2].item() - terms["semantic"].item()) < 2e-5 * max(1, abs(terms["semantic"].item()))
+    assert abs(out[6].item() - total.item()) < 2e-5 * max(1, abs(total.item()))
+    for k in maps:
+        assert (grads[k].cpu() - leafm[k].grad).abs().max() <= 1e-6 + 2e-5 * leafm[k].grad.abs().max(), k
