@@ -29,7 +29,9 @@ struct CompositeArgs {
 };
 
 struct f4 { float v[4]; };
+#ifndef CMP_UB
 #define CMP_UB 8        // channel rows per batch
+#endif
 #define CMP_FIX_SCALE 1073741824.0f   // 2^30
 
 template <bool CH_MAJOR>
