@@ -296,8 +296,10 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     WgPlan pl;
     wg_plan(*desc, n_samples, grads_dev, pl);
     PNR_REQUIRE(pl.n <= WG_MAX_JOBS, "pnr_mlp_wgrad: too many jobs");
-    for (int i = 0; i < pl.n; ++i)
-        PNR_REQUIRE(pl.red[i].out && (pl.red[i].out_b || true), "pnr_mlp_wgrad: a gradient pointer is null");
+    for (int i = 0; i < pl.n; ++i)      // out_b is null by design for the second job of a concatenated weight
+        PNR_REQUIRE(pl.red[i].out, "pnr_mlp_wgrad: a weight-gradient pointer of grads_dev is null");
+    PNR_REQUIRE(grads_dev->alpha_b && grads_dev->rgb_b && grads_dev->feature_b && grads_dev->views_b,
+                "pnr_mlp_wgrad: a bias-gradient pointer of grads_dev is null");
     PNR_HIP(hipMemsetAsync(workspace, 0, WG_ZERO_BYTES, st));
     WgArgs a;
     memset(&a, 0, sizeof(a));

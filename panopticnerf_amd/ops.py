@@ -218,11 +218,9 @@ def mlp_wgrad(desc, acts, dys, n_samples, shapes):
     nbytes = lib.pnr_mlp_wgrad_workspace_bytes(ctypes.byref(desc), int(n_samples))
     if nbytes < 0:
         raise RuntimeError("pnr_mlp_wgrad_workspace_bytes: " + lib.pnr_last_error().decode(errors="replace"))
-    key = (str(dev), int(nbytes))
-    ws = _WG_WS.get(key)
-    if ws is None:
-        _WG_WS.clear()                       # one workspace per device / size: the partial sums are scratch
-        ws = _WG_WS[key] = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+    ws = _WG_WS.get(str(dev))                # one scratch buffer per device, grown to the largest size seen
+    if ws is None or ws.numel() < nbytes:
+        ws = _WG_WS[str(dev)] = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
     grads = {k: torch.empty(tuple(shp), device=dev, dtype=torch.float32) for k, shp in shapes.items()}
     G, keep = _param_struct(desc, grads, dev)
     _lib.check(lib.pnr_mlp_wgrad(ctypes.byref(desc), _p(acts), _p(dys), int(n_samples), ctypes.byref(G), _p(ws), _stream()),
