@@ -9,14 +9,19 @@
 // gamma(x), gamma(d) (the inputs are not learnable), so layer 0 and the view-direction columns have
 // no data-gradient step.
 //
-// 4 waves x 1 tile per workgroup, one wave per SIMD (the concatenated dH input needs 136 B registers):
-// correctness-first geometry; the forward kernel's tuning has not been carried over yet.
+// 8 waves x 1 tile per workgroup (two waves per SIMD), like the forward kernel.
 #include <string.h>
 
 #include "pnr_mlp_plan.h"
 #include "pnr_mlp_core.h"
 
 int pnr_mlp_validate(const pnr_mlp_desc* d);
+
+// 8 waves (two per SIMD) measured 7 % faster than 4 (one per SIMD) although the concatenated dH input (136 B registers)
+// makes hipcc spill ~160 dwords at the 256-register cap: the pass is HBM/latency-bound (masks in, dY out: ~9 KB/sample).
+#ifndef PNR_BWD_WAVES
+#define PNR_BWD_WAVES 8
+#endif
 
 // One backward layer.  in: NA B registers (k-segments concatenated).  out[t][OFF + fb*8 + p].
 // mask  : slot-ordered [S][NFB_OUT*32] activations whose ReLU gates this gradient (nullptr: linear)
@@ -33,7 +38,7 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
         c.begin();
         const char* base = c.base();
         u32x4 mk[FBC][TILES][2];
-        if (mask) {
+        auto load_mask = [&]() {
 #pragma unroll
             for (int b = 0; b < FBC; ++b)
 #pragma unroll
@@ -43,7 +48,8 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
                     mk[b][t][0] = mp[0];
                     mk[b][t][1] = mp[1];
                 }
-        }
+        };
+        if (mask) load_mask();
         f32x16 acc[FBC][TILES];
 #pragma unroll
         for (int b = 0; b < FBC; ++b)
@@ -207,5 +213,5 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
     pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
     hipStream_t st = (hipStream_t)stream;
-    return desc->W == 256 ? launch_bwd<256, 4>(a, st) : launch_bwd<128, 4>(a, st);
+    return desc->W == 256 ? launch_bwd<256, PNR_BWD_WAVES>(a, st) : launch_bwd<128, PNR_BWD_WAVES>(a, st);
 }
