@@ -143,6 +143,11 @@ def _worker(rank, world, port, n_rays, q):
         return {k: o[k] for k in ("rgb_1", "depth_1", "semantic_1", "z_vals_1")}
 
     full = shard.render_sharded(render, rays, rank, world, gather=True)
+    # reduce before the gather (here: a CPU argmax standing in for pnr_panoptic_labels) and gather selected keys only
+    red = lambda o: {"rgb_1": o["rgb_1"], "semantic_label": o["semantic_1"].argmax(-1).int()}
+    lab = shard.render_sharded(render, rays, rank, world, gather=True, keys=("semantic_label",), reduce_fn=red)
+    assert set(lab) == {"semantic_label"} and lab["semantic_label"].dtype == torch.int32
+    assert torch.equal(lab["semantic_label"], full["semantic_1"].argmax(-1).int())
     local = shard.render_sharded(render, rays, rank, world, gather=False)
     assert local["rgb_1"].shape[0] == len(range(rank, n_rays, world))
     ref = render(rays)
