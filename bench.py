@@ -132,7 +132,11 @@ def main():
             desc, img = net.packed(1, dev)
             raw = ops.alloc_raw(4 + N_SEM + N_INST, rc.shape[0] * (N_C + N_F), dev)   # as Renderer allocates it
             ops.time_mlp_forward(desc, img, rc, z, raw, 1)
-            ms = ops.time_mlp_forward(desc, img, rc, z, raw, 5)
+            ms, kernel_mhz = ops.time_mlp_forward_clk(desc, img, rc, z, raw, 5)
+            # what the matrix pipe of THIS device sustains (register-only MFMA loop): with constant operands, and with
+            # random operands that change from MFMA to MFMA (the toggle rate of real data: the chip lowers its clock)
+            pk_const, mhz_const = ops.probe_mfma_peak(False, 12000, dev)
+            pk_rand, mhz_rand = ops.probe_mfma_peak(True, 12000, dev)
             S = rc.shape[0] * (N_C + N_F)
             flops = S * mlp_flops_per_sample()
             ach = flops / (ms * 1e-3) / 1e12
@@ -140,7 +144,12 @@ def main():
             roofline = {"kernel": "k_mlp_fused (fine level, %d rays x %d samples)" % (rc.shape[0], N_C + N_F),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", rc.shape[0]),
-                        "ms_per_launch": round(ms, 4), "flop_per_launch": flops}
+                        "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
+                        "shader_mhz_during_kernel": round(kernel_mhz, 0),
+                        "mfma_sustained": {"note": "register-only bf16 MFMA loop on every SIMD of this device, measured in this run",
+                                           "constant_operands_tflops": round(pk_const, 1), "constant_operands_mhz": round(mhz_const, 0),
+                                           "random_operands_tflops": round(pk_rand, 1), "random_operands_mhz": round(mhz_rand, 0)},
+                        "frac_of_sustained_random_operand_peak": round(ach / pk_rand, 4) if pk_rand > 0 else None}
             # secondary: compositing scan (HBM-bound), algorithmic bytes per SURVEY.md 8d
             lab = torch.zeros((rc.shape[0], N_C + N_F), device=dev, dtype=torch.int32)
             for _ in range(2):

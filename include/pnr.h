@@ -260,6 +260,17 @@ int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float
 int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                          int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
                          int64_t raw_stride_c, int iters, float* ms_out_host, void* stream);
+/* The same, plus the mean SHADER CLOCK during the last launch (s_memtime / s_memrealtime of workgroup 0's first wave);
+ * scratch: >= 16 bytes of device memory.  Bench only. */
+int pnr_time_mlp_forward_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                             int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c,
+                             int iters, void* scratch, float* ms_out_host, float* mhz_out_host, void* stream);
+/* What the matrix pipe of this device SUSTAINS (bench only; synchronises): a register-only bf16 MFMA loop on every SIMD with
+ * constant operands (random_operands = 0) or with pseudo-random operands that change from MFMA to MFMA (1: the toggle
+ * rate of real data -- on MI355X the clock then drops from ~2.37 to ~1.83 GHz and the rate from ~2.46 to ~1.83 PFLOP/s).
+ * scratch: >= 32 device bytes; tflops / mhz: host floats. */
+int pnr_probe_mfma_peak(int random_operands, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -199,6 +199,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #endif
     const int n = c.lane & 31;
     c.start();
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (a.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     uint32_t dummy[TILES][1];
 #pragma unroll
@@ -294,7 +296,11 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         ++c.titer;
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the refill issued past the last chunk
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }   // the refill issued past the last chunk
 #if PNR_TRACE
     __syncthreads();
     if (blockIdx.x == 0 && a.trace) {
@@ -330,6 +336,8 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
     return PNR_OK;
 }
 
+static thread_local unsigned long long* g_clk_buf = nullptr;     // set by pnr_time_mlp_forward_clk around its launches
+
 static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                             int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c,
                             void* acts, void* stream)
@@ -359,6 +367,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
+    a.clk = g_clk_buf;
     if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
@@ -397,6 +406,28 @@ PNR_EXPORT int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples,
     pnr_train_layout(*desc, n_samples, a, d);
     memcpy(acts_off_host, a, sizeof(int64_t) * (size_t)(desc->D + 7));
     memcpy(dys_off_host, d, sizeof(int64_t) * (size_t)(desc->D + 8));
+    return PNR_OK;
+}
+
+PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                    int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                                    int64_t raw_stride_c, int iters, float* ms_out_host, void* stream);
+
+// pnr_time_mlp_forward plus the mean shader clock DURING the last launch (scratch: >= 16 device bytes)
+PNR_EXPORT int pnr_time_mlp_forward_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                        int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                                        int64_t raw_stride_c, int iters, void* scratch, float* ms_out_host,
+                                        float* mhz_out_host, void* stream)
+{
+    PNR_REQUIRE(scratch && mhz_out_host, "pnr_time_mlp_forward_clk: bad arguments");
+    g_clk_buf = (unsigned long long*)scratch;
+    const int rc = pnr_time_mlp_forward(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, iters,
+                                        ms_out_host, stream);
+    g_clk_buf = nullptr;
+    if (rc != PNR_OK) return rc;
+    unsigned long long h[2] = {0, 1};
+    PNR_HIP(hipMemcpy(h, scratch, sizeof(h), hipMemcpyDeviceToHost));
+    *mhz_out_host = h[1] ? (float)(100.0 * (double)h[0] / (double)h[1]) : 0.0f;
     return PNR_OK;
 }
 

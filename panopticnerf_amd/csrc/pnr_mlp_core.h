@@ -29,6 +29,7 @@ struct MlpArgs {
     // of raw, (ch, S) channel-major fp32; dys: pre-activation gradients written by the backward.
     uint16_t* acts; const float* d_raw; uint16_t* dys;
     unsigned long long* trace;      // PNR_TRACE builds: [8 waves][PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
+    unsigned long long* clk;        // optional (bench): {shader cycles, 100 MHz ticks} of workgroup 0's first wave
     int64_t acts_off[24], dys_off[24];
 };
 

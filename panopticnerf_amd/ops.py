@@ -282,6 +282,28 @@ def time_mlp_forward(desc, packed, rays, z, raw, iters):
     return float(ms.value)
 
 
+def time_mlp_forward_clk(desc, packed, rays, z, raw, iters):
+    """(mean ms per launch, mean shader MHz during the last launch) -- bench only."""
+    R, N = z.shape
+    ms, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    scratch = torch.zeros(4, device=z.device, dtype=torch.int64)
+    _lib.check(_lib.load().pnr_time_mlp_forward_clk(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1,
+                                                    _chk_raw(raw, n_channels(desc), R * N), int(iters), _p(scratch),
+                                                    ctypes.byref(ms), ctypes.byref(mhz), _stream()), "pnr_time_mlp_forward_clk")
+    return float(ms.value), float(mhz.value)
+
+
+def probe_mfma_peak(random_operands, iters=20000, device=None):
+    """(TFLOP/s, shader MHz) a register-only bf16 MFMA loop sustains on this device (pnr_probe_mfma_peak) -- bench only."""
+    dev = torch.device(device if device is not None else "cuda")
+    tf, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    scratch = torch.zeros(4, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().pnr_probe_mfma_peak(int(bool(random_operands)), int(iters), _p(scratch), ctypes.byref(tf),
+                                                   ctypes.byref(mhz), _stream()), "pnr_probe_mfma_peak")
+    return float(tf.value), float(mhz.value)
+
+
 def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
               sem_mode=0, white_bkgd=False, want_weights=True):
     """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
