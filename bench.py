@@ -165,10 +165,13 @@ def main():
             ch = 4 + N_SEM + N_INST
             bytes_ray = 4 * N * (ch + 1) + 2 * 4 * N + 4 * N + 4 * (5 + 2 * (N_SEM + N_INST)) + 32
             gbs = rc.shape[0] * bytes_ray / (cms * 1e-3) / 1e9
+            read_gbs = ops.probe_raw_read(raw, rc.shape[0], N, 5)     # same image, same order, no arithmetic
             extra["roofline_composite"] = {"kernel": "k_composite<channel-major>", "bound": "hbm",
                                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k_composite", rc.shape[0]),
-                                           "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray}
+                                           "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray,
+                                           "pure_read_same_pattern_gbs": round(read_gbs, 1),
+                                           "frac_of_pure_read": round(gbs / read_gbs, 4) if read_gbs > 0 else None}
 
     # secondary measurement (never the headline value): one training step on a 4096-ray batch per rank --
     # render with autograd, the loss wrapper (RGB / depth / 2D CE on learned and fixed fields / 3D CE; fused HIP),

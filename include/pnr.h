@@ -271,6 +271,10 @@ int pnr_time_mlp_forward_clk(const pnr_mlp_desc* desc, const void* packed, const
  * scratch: >= 32 device bytes; tflops / mhz: host floats. */
 int pnr_probe_mfma_peak(int random_operands, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host,
                         void* stream);
+/* What HBM delivers for k_composite's own access pattern with no arithmetic (bench only; synchronises): a pure read of the
+ * channel-major raw image, per wave the 8 channel rows of a batch of one ray, 8 loads in flight.  scratch: >= 1 KiB. */
+int pnr_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,
+                       void* scratch, float* gbs_out_host, void* stream);
 
 #ifdef __cplusplus
 }

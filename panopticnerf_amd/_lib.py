@@ -86,6 +86,7 @@ SIGNATURES = {
     "pnr_time_mlp_forward_clk": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64,
                                          c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_probe_mfma_peak": (c_int, [c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
+    "pnr_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), c_f]),
 }
 
 _lib = None

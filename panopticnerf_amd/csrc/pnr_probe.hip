@@ -73,3 +73,52 @@ PNR_EXPORT int pnr_probe_mfma_peak(int random_operands, int iters, void* scratch
     (void)hipEventDestroy(e1);
     return PNR_OK;
 }
+
+// pnr_probe_raw_read: a pure read of a channel-major raw image in k_composite's own order (per wave: the 8 channel rows of
+// a batch of one ray, N/4 lanes x 16 B each, 8 loads in flight, 8 waves per SIMD) -- what HBM delivers for this access
+// pattern with no arithmetic at all.  bench.py quotes k_composite against it next to the 8 TB/s datasheet peak.
+__global__ __launch_bounds__(256) void k_raw_read(const float* raw, int64_t sc, int64_t R, int N, int CH, float* sink)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool active = lane * 4 < N;
+    float acc = 0.0f;
+    for (int64_t ray = wave; ray < R; ray += n_waves) {
+        const float* p = raw + ray * N + lane * 4;
+        for (int c0 = 0; c0 < CH; c0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (active && c0 + j < CH) ? *reinterpret_cast<const float4*>(p + (int64_t)(c0 + j) * sc) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+    if (acc == 12345.678f) sink[threadIdx.x] = acc;
+}
+
+// raw (n_channels, R*N) channel-major with channel stride raw_stride_c, N % 4 == 0, N <= 256.  gbs_out: host float.
+PNR_EXPORT int pnr_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels,
+                                  int iters, void* scratch, float* gbs_out_host, void* stream)
+{
+    PNR_REQUIRE(raw && scratch && gbs_out_host && iters >= 1 && n_rays >= 1, "pnr_probe_raw_read: bad arguments");
+    PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0 && (raw_stride_c % 4) == 0, "pnr_probe_raw_read: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    PNR_HIP(hipEventCreate(&e0));
+    PNR_HIP(hipEventCreate(&e1));
+    const int grid = pnr_grid_cap((n_rays + 3) / 4, 8);
+    hipLaunchKernelGGL(k_raw_read, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
+    PNR_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_raw_read, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
+    PNR_CHECK_LAUNCH("pnr_probe_raw_read");
+    PNR_HIP(hipEventRecord(e1, st));
+    PNR_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gbs_out_host = (float)((double)n_rays * n_samples * 4.0 * n_channels * iters / (ms * 1e-3) / 1e9);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PNR_OK;
+}

@@ -304,6 +304,16 @@ def probe_mfma_peak(random_operands, iters=20000, device=None):
     return float(tf.value), float(mhz.value)
 
 
+def probe_raw_read(raw, n_rays, n_samples, iters=5):
+    """GB/s of a pure read of the channel-major raw image in k_composite's access order (pnr_probe_raw_read) -- bench only."""
+    gbs = ctypes.c_float(0.0)
+    scratch = torch.zeros(256, device=raw.device, dtype=torch.float32)
+    _lib.check(_lib.load().pnr_probe_raw_read(_p(raw), _chk_raw(raw, raw.shape[0], n_rays * n_samples), int(n_rays), int(n_samples),
+                                              int(raw.shape[0]), int(iters), _p(scratch), ctypes.byref(gbs), _stream()),
+               "pnr_probe_raw_read")
+    return float(gbs.value)
+
+
 def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
               sem_mode=0, white_bkgd=False, want_weights=True):
     """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
