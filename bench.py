@@ -59,6 +59,55 @@ def traffic(kernel, n_rays_launch):
         return None
 
 
+def graph_step_child(args):
+    """Child process of the training-step measurement: the same step (NetworkWrapper render + fused losses, backward through
+    the HIP kernels, Adam(capturable), in-place repack of both weight images) captured into ONE HIP graph; prints
+    {"graph_ms": ms per replayed step}.  Separate process: see the call site."""
+    from panopticnerf_amd import NetworkWrapper, make_network, synthetic
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = NS(N_samples=N_C, N_importance=N_F, num_classes=N_SEM, num_instances=N_INST, precision=args.precision)
+    torch.manual_seed(0)
+    tnet = make_network(cfg).to(dev).train()
+    synthetic.trained_like_(tnet)
+    wrap = NetworkWrapper(tnet, cfg)
+    opt = torch.optim.Adam(tnet.parameters(), lr=5e-4, capturable=True)
+    g = torch.Generator(device=dev).manual_seed(0)
+    rays = synthetic.camera_rays().to(dev)
+    box, ids = synthetic.random_boxes(64, N_SEM, N_INST)
+    idx = torch.randint(0, rays.shape[0], (args.train_rays,), generator=g, device=dev)
+    tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
+          "rgb": torch.rand((1, args.train_rays, 3), generator=g, device=dev),
+          "depth": torch.rand((1, args.train_rays), generator=g, device=dev) * 60.0 - 10.0,
+          "pseudo_label": torch.randint(-1, N_SEM, (1, args.train_rays), generator=g, device=dev),
+          "instance_label": torch.randint(-1, N_INST, (1, args.train_rays), generator=g, device=dev)}
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        _, loss, _, _ = wrap(tb)
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    print(json.dumps({"graph_ms": round((time.perf_counter() - t0) / args.train_steps * 1e3, 3)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +119,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3, help="secondary training-step measurement (0 = skip)")
     ap.add_argument("--train-rays", type=int, default=4096)
+    ap.add_argument("--graph-step-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.graph_step_child:
+        return graph_step_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,7 +264,20 @@ def main():
                 tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tdt = float(tt.item())
-            train_info = {"ms_per_step": round(tdt * 1e3, 3), "rays_per_rank": args.train_rays,
+            graph_ms = None
+            if world == 1:
+                # the same step captured into ONE HIP graph (fresh process: torch's capture wants a network whose autograd
+                # nodes were created under the capture-side stream, and a crash there must not lose the headline line)
+                import subprocess
+                try:
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-step-child", "--train-rays", str(args.train_rays),
+                                         "--train-steps", str(max(args.train_steps, 5)), "--precision", args.precision],
+                                        capture_output=True, text=True, timeout=180)
+                    line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                    graph_ms = json.loads(line[-1])["graph_ms"] if line else "failed: rc %d" % cp.returncode
+                except Exception as e:      # noqa: BLE001
+                    graph_ms = "failed: %s" % type(e).__name__
+            train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms, "rays_per_rank": args.train_rays,
                           "Msamples_per_s_fwd_bwd": round(args.train_rays * world * (N_C + N_C + N_F) / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
                           "grad_allreduce": "flat bucket, %s" % ("RCCL (nccl)" if world > 1 else "single rank: skipped"),

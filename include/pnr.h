@@ -100,6 +100,10 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, vo
 int64_t pnr_mlp_pack_workspace_bytes(const pnr_mlp_desc* desc, int backward);
 int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
                         void* workspace, void* packed, void* stream);
+/* The packing kernel alone, for parameters that CHANGED IN PLACE since a pnr_mlp_pack_device call with the same desc,
+ * parameter pointers, workspace and packed buffer (an optimiser step): no host-to-device copy, graph-capture safe. */
+int pnr_mlp_repack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
+                          void* workspace, void* packed, void* stream);
 
 /* Evaluate the network on every sample of every ray:
  *   pts = o + d*z, viewdir = d/||d||, raw = MLP(gamma(pts), gamma(viewdir)).

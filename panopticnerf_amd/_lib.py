@@ -54,6 +54,7 @@ SIGNATURES = {
     "pnr_mlp_pack": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), ctypes.c_void_p]),
     "pnr_mlp_pack_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_int]),
     "pnr_mlp_pack_device": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), c_int, c_f, c_f, c_f]),
+    "pnr_mlp_repack_device": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), c_int, c_f, c_f, c_f]),
     "pnr_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_f]),
     "pnr_mlp_train_layout": (c_int, [ctypes.POINTER(MlpDesc), c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "pnr_mlp_forward_train": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_f, c_f]),

@@ -310,3 +310,21 @@ PNR_EXPORT int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_param
     PNR_CHECK_LAUNCH("pnr_mlp_pack_device");
     return PNR_OK;
 }
+
+// Re-run ONLY the packing kernel: the descriptors in `workspace` and the header / chunk table in `packed` are those a
+// previous pnr_mlp_pack_device call with the SAME desc, parameter pointers and buffers left there.  No host-to-device
+// copy, so this form is graph-capture safe -- it is what lets a whole training step (render, losses, backward,
+// optimiser, repack) be captured into one HIP graph and replayed.
+PNR_EXPORT int pnr_mlp_repack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
+                                     void* workspace, void* packed, void* stream)
+{
+    PNR_REQUIRE(workspace && packed, "pnr_mlp_repack_device: null pointer");
+    Image im;
+    int rc = describe(desc, params_dev, backward, im);
+    if (rc != PNR_OK) return rc;
+    const int n = (int)im.frags.size();
+    hipLaunchKernelGGL(k_pack_fragments, dim3(n < 2048 ? n : 2048), dim3(64), 0, (hipStream_t)stream, (const PnrFragDesc*)workspace, n,
+                       backward ? PNR_PREC_BF16 : desc->precision, (uint8_t*)packed + im.data_off);
+    PNR_CHECK_LAUNCH("pnr_mlp_repack_device");
+    return PNR_OK;
+}

@@ -81,12 +81,16 @@ class Network(nn.Module):
         desc = net.desc(precision)
         sd = dict(net.named_parameters())
         on_dev = torch.device(device).type == "cuda" and all(p.device == torch.device(device) for p in sd.values())
+        ptrs = tuple(p.data_ptr() for p in sd.values())
         if on_dev:
-            img, ws = ops.pack_mlp_device(desc, sd, backward, hit[2] if hit else None, hit[3] if hit else None)
+            # same parameter storage as last time (an in-place optimiser step): the descriptors already on the device
+            # are still right, only the packing kernel has to run again -- no host copies, graph-capture safe
+            same = hit is not None and hit[3] is not None and len(hit) > 4 and hit[4] == ptrs
+            img, ws = ops.pack_mlp_device(desc, sd, backward, hit[2] if hit else None, hit[3] if hit else None, repack=same)
         else:
             sd = {k: v.detach().float().cpu() for k, v in sd.items()}
             img, ws = (ops.pack_mlp_bwd if backward else ops.pack_mlp)(desc, sd).to(device), None
-        self._packed[key] = (ver, desc, img, ws)
+        self._packed[key] = (ver, desc, img, ws, ptrs)
         return desc, img
 
     def packed(self, level, device, precision=None):

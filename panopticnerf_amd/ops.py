@@ -123,9 +123,11 @@ def _param_struct(desc, params, device):
     return P, keep
 
 
-def pack_mlp_device(desc, params, backward=False, out=None, workspace=None):
+def pack_mlp_device(desc, params, backward=False, out=None, workspace=None, repack=False):
     """Pack on the GPU straight from the (CUDA, fp32) parameter tensors: pnr_mlp_pack_device.
-    Returns (image uint8 CUDA tensor, workspace) -- pass both back in to reuse the buffers."""
+    Returns (image uint8 CUDA tensor, workspace) -- pass both back in to reuse the buffers.
+    repack=True: `out` / `workspace` come from an earlier call with the SAME parameter tensors (same data pointers) whose
+    values changed in place: only the packing kernel runs (pnr_mlp_repack_device; no host copies, graph-capture safe)."""
     lib = _lib.load()
     dev = next(iter(params.values())).device
     if dev.type != "cuda":
@@ -139,8 +141,8 @@ def pack_mlp_device(desc, params, backward=False, out=None, workspace=None):
     if workspace is None or workspace.numel() < wbytes:
         workspace = torch.empty(int(wbytes), dtype=torch.uint8, device=dev)
     P, keep = _param_struct(desc, params, dev)
-    _lib.check(lib.pnr_mlp_pack_device(ctypes.byref(desc), ctypes.byref(P), int(backward), _p(workspace), _p(out),
-                                       _stream()), "pnr_mlp_pack_device")
+    fn = lib.pnr_mlp_repack_device if repack else lib.pnr_mlp_pack_device
+    _lib.check(fn(ctypes.byref(desc), ctypes.byref(P), int(backward), _p(workspace), _p(out), _stream()), "pnr_mlp_pack_device")
     return out, workspace
 
 
