@@ -133,22 +133,25 @@ __global__ __launch_bounds__(LS_THREADS) void k_loss_maps(LossArgs a)
 
 __global__ __launch_bounds__(64) void k_loss_final(LossArgs a)
 {
+    // per term: lane i adds blocks i, i + 64, ... in that order, then a fixed butterfly (deterministic; a full frame has
+    // ~2000 partials, one lane walking them all costs >100 us)
     const int i = threadIdx.x;
-    float v = 0.0f;
-    if (i < 6) {
-        for (int b = 0; b < a.n_blocks; ++b) v += a.partial[(int64_t)b * LS_TERMS + i];
-        const float n = i == 0 ? 3.0f * (float)a.R : i == 1 ? (float)(a.counts[0] > 0 ? a.counts[0] : 1)
-                      : i <= 3 ? (float)(a.counts[1] > 0 ? a.counts[1] : 1) : (float)(a.counts[2] > 0 ? a.counts[2] : 1);
+    float total = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        float v = 0.0f;
+        for (int b = i; b < a.n_blocks; b += 64) v += a.partial[(int64_t)b * LS_TERMS + t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        const float n = t == 0 ? 3.0f * (float)a.R : t == 1 ? (float)(a.counts[0] > 0 ? a.counts[0] : 1)
+                      : t <= 3 ? (float)(a.counts[1] > 0 ? a.counts[1] : 1) : (float)(a.counts[2] > 0 ? a.counts[2] : 1);
         v /= n;
-        a.losses[i] = v;
+        const float w = t == 0 ? a.cfg.w_rgb : t == 1 ? a.cfg.w_depth : t == 2 ? a.cfg.w_sem : t == 3 ? a.cfg.w_fix_sem
+                      : t == 4 ? a.cfg.w_inst : a.cfg.w_fix_inst;
+        if (i == 0) a.losses[t] = v;
+        total += w * v;                         // fixed order t = 0..5
     }
-    const float w = i == 0 ? a.cfg.w_rgb : i == 1 ? a.cfg.w_depth : i == 2 ? a.cfg.w_sem : i == 3 ? a.cfg.w_fix_sem
-                  : i == 4 ? a.cfg.w_inst : i == 5 ? a.cfg.w_fix_inst : 0.0f;
-    float tot = i < 6 ? w * v : 0.0f;
-    // fixed-order sum of the six weighted terms
-    float s = 0.0f;
-    for (int k = 0; k < 6; ++k) s += __shfl(tot, k, 64);
-    if (i == 0) { a.losses[6] = s; a.losses[7] = 0.0f; }
+    if (i == 0) { a.losses[6] = total; a.losses[7] = 0.0f; }
 }
 
 PNR_EXPORT int64_t pnr_losses_workspace_bytes(int64_t n_rays)
@@ -228,12 +231,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_ce3d(Ce3dArgs a)
 
 __global__ __launch_bounds__(64) void k_ce3d_final(Ce3dArgs a)
 {
-    // two lanes, each a fixed-order sum over the blocks (double: counts up to 2^31 stay exact)
+    // lane i adds blocks i, i + 64, ... in that order, then a fixed butterfly: deterministic, and not one lane walking
+    // thousands of partials (that cost 170 us).  double: counts up to 2^31 stay exact.
     const int i = threadIdx.x;
-    double v = 0.0;
-    if (i < 2)
-        for (int b = 0; b < a.n_blocks; ++b) v += (double)a.partial[(int64_t)b * 2 + i];
-    const double cnt = __shfl(v, 1, 64), sum = __shfl(v, 0, 64);
+    double sum = 0.0, cnt = 0.0;
+    for (int b = i; b < a.n_blocks; b += 64) {
+        sum += (double)a.partial[(int64_t)b * 2];
+        cnt += (double)a.partial[(int64_t)b * 2 + 1];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64); }
     if (i == 0) { a.out[0] = (float)(sum / (cnt > 0.0 ? cnt : 1.0)); a.out[1] = (float)cnt; }
 }
 
