@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, int6
 // One 64-lane workgroup (= one wavefront) per ray.  The CDF is accumulated by lane 0 in the
 // oracle's sequential fp32 order (the bit-exact index requirement, SURVEY.md section 7 "hard
 // parts"); everything else is lane-parallel: bins, pdf, one upper_bound per u, and a bitonic
-// sort of the Nc+Nf union in LDS.  LDS per workgroup: 5 KiB.
+// sort of the Nc+Nf union in LDS (a rank-based merge when the new samples are already ascending).  LDS: 7 KiB.
 #define PDF_MAXC 256
 #define PDF_MAXT 512
 __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, const float* __restrict__ weights,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
                                                     float* __restrict__ zfine_out)
 {
     __shared__ float s_z[PDF_MAXC], s_w[PDF_MAXC], s_pdf[PDF_MAXC], s_cdf[PDF_MAXC], s_bins[PDF_MAXC];
-    __shared__ float s_sort[PDF_MAXT];
+    __shared__ float s_sort[PDF_MAXT], s_out[PDF_MAXT];
     __shared__ float s_total;
     const int lane = threadIdx.x;
     const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
@@ -173,6 +173,32 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
             s_sort[Nc + i] = zs;
         }
         if (zfine_out) {
+            __syncthreads();
+            // Are the new samples already ascending?  (Always with deterministic u: the inverse CDF is monotone.)  Then the
+            // sorted union is a MERGE of two sorted lists: an element's final position is its own index plus the number
+            // of elements of the OTHER list that precede it (binary searches; coarse samples go first on ties).  The
+            // 36-stage LDS bitonic sort below was 2/3 of this kernel's time; it remains for random u.
+            bool asc = true;
+            for (int i = lane; i + 1 < Nf; i += 64) asc = asc && (s_sort[Nc + i] <= s_sort[Nc + i + 1]);
+            for (int i = lane; i + 1 < Nc; i += 64) asc = asc && (s_z[i] <= s_z[i + 1]);
+            if (__all(asc)) {
+                for (int i = lane; i < Nc; i += 64) {          // coarse z[i]: + #samples strictly below it
+                    const float v = s_z[i];
+                    int lo = 0, hi = Nf;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_sort[Nc + mid] < v) lo = mid + 1; else hi = mid; }
+                    s_out[i + lo] = v;
+                }
+                for (int j = lane; j < Nf; j += 64) {          // sample zs[j]: + #coarse z at or below it
+                    const float v = s_sort[Nc + j];
+                    int lo = 0, hi = Nc;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= v) lo = mid + 1; else hi = mid; }
+                    s_out[j + lo] = v;
+                }
+                __syncthreads();
+                for (int i = lane; i < Nt; i += 64) zfine_out[r * Nt + i] = s_out[i];
+                __syncthreads();
+                continue;
+            }
             for (int i = lane; i < Nc; i += 64) s_sort[i] = s_z[i];
             for (int i = Nt + lane; i < P; i += 64) s_sort[i] = INFINITY;
             __syncthreads();
