@@ -236,6 +236,7 @@ int pnr_gen_rays(const float* intr4_host, const float* c2w12_host, int width, in
  *   may be NULL.  sem (R,n_sem), inst (R,n_inst) or NULL, is_thing (n_sem) int32 device or NULL.
  * pnr_confusion: conf[gt*n_classes + pred] += 1 over pixels with both labels in [0, n_classes) (gt < 0 = ignore); conf is a
  *   device (n_classes^2) int64 array the caller zeroes once and accumulates into over frames.  Integer atomics: exact.
+ *   n_classes <= 8192 (above 128 without the per-block LDS histogram: used for the segment-pair counts of PQ).
  *   mIoU / accuracy are a handful of flops on that matrix (host side); PSNR = -10 log10 of pnr_losses' rgb term. */
 int pnr_panoptic_labels(const float* sem, const float* inst, const int32_t* is_thing, int64_t n_rays, int n_sem, int n_inst,
                         int32_t* sem_label, int32_t* inst_label, int32_t* panoptic, void* stream);

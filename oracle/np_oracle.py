@@ -153,3 +153,36 @@ def confusion(pred, gt, n_classes):
     pred, gt = np.asarray(pred, np.int64), np.asarray(gt, np.int64)
     v = (gt >= 0) & (gt < n_classes) & (pred >= 0) & (pred < n_classes)
     return np.bincount(gt[v] * n_classes + pred[v], minlength=n_classes * n_classes).reshape(n_classes, n_classes).astype(np.int64)
+
+
+def panoptic_quality_terms(pred_id, gt_id, n_classes):
+    """Per-class (sum of matched IoUs, TP, FP, FN) of one frame; ids = class*1000 + instance on things, class on stuff,
+    gt < 0 = ignore.  Plain loops over segments (Kirillov et al., "Panoptic Segmentation": match iff same class and
+    IoU > 0.5)."""
+    pred_id, gt_id = np.asarray(pred_id, np.int64), np.asarray(gt_id, np.int64)
+    valid = gt_id >= 0
+    cls = lambda i: int(i // 1000) if i >= 1000 else int(i)
+    out = np.zeros((n_classes, 4))
+    gts = [g for g in np.unique(gt_id[valid])]
+    preds = [p for p in np.unique(pred_id[valid])]
+    matched_p = set()
+    for g in gts:
+        gm = (gt_id == g) & valid
+        hit = False
+        for p in preds:
+            if cls(p) != cls(g):
+                continue
+            pm = (pred_id == p) & valid
+            inter = np.count_nonzero(gm & pm)
+            union = np.count_nonzero(gm) + np.count_nonzero(pm) - inter
+            if union > 0 and inter / union > 0.5:
+                out[cls(g), 0] += inter / union
+                out[cls(g), 1] += 1
+                matched_p.add(p)
+                hit = True
+        if not hit:
+            out[cls(g), 3] += 1
+    for p in preds:
+        if p not in matched_p:
+            out[cls(p), 2] += 1
+    return out

@@ -69,11 +69,28 @@ __global__ __launch_bounds__(256) void k_confusion(const int32_t* __restrict__ p
         if (h[i]) atomicAdd(&conf[i], (unsigned long long)h[i]);
 }
 
+// the same for label spaces too large for an LDS histogram (segment-pair counts of the panoptic-quality metric):
+// one global integer atomic per pixel
+__global__ __launch_bounds__(256) void k_confusion_big(const int32_t* __restrict__ pred, const int32_t* __restrict__ gt, int64_t R,
+                                                       int n_cls, unsigned long long* __restrict__ conf)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const int g = gt[r], p = pred[r];
+        if (g >= 0 && g < n_cls && p >= 0 && p < n_cls) atomicAdd(&conf[(int64_t)g * n_cls + p], 1ull);
+    }
+}
+
 PNR_EXPORT int pnr_confusion(const int32_t* pred, const int32_t* gt, int64_t n, int n_classes, int64_t* conf, void* stream)
 {
-    PNR_REQUIRE(n >= 0 && n_classes >= 1 && n_classes <= 128, "pnr_confusion: bad size (n_classes <= 128)");
+    PNR_REQUIRE(n >= 0 && n_classes >= 1 && n_classes <= 8192, "pnr_confusion: bad size (n_classes <= 8192)");
     if (n == 0) return PNR_OK;
     PNR_REQUIRE(pred && gt && conf, "pnr_confusion: null pointer");
+    if (n_classes > 128) {
+        hipLaunchKernelGGL(k_confusion_big, dim3(pnr_grid_cap((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n,
+                           n_classes, (unsigned long long*)conf);
+        PNR_CHECK_LAUNCH("pnr_confusion");
+        return PNR_OK;
+    }
     int grid = (int)((n + 256 * 16 - 1) / (256 * 16));
     grid = grid < 1 ? 1 : grid > 1024 ? 1024 : grid;
     hipLaunchKernelGGL(k_confusion, dim3(grid), dim3(256), (size_t)n_classes * n_classes * sizeof(unsigned int), (hipStream_t)stream,

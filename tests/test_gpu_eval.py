@@ -1,4 +1,6 @@
 """GPU tests of SURVEY.md 8f rank 4: label post-processing and the evaluator counters, bit-exact with oracle/np_oracle.py."""
+from types import SimpleNamespace as NS
+
 import numpy as np
 import pytest
 import torch
@@ -59,3 +61,31 @@ def test_evaluator_psnr_miou(dev):
     assert abs(s["psnr"] - np.mean(psnr)) < 1e-4
     assert abs(s["miou"] - np.mean(tp / union)) < 1e-12 and abs(s["pixel_acc"] - tp.sum() / ref_conf.sum()) < 1e-12
     assert ev.summarize() == {}                       # counters reset
+
+
+def test_panoptic_quality_matches_oracle(dev):
+    """PQ terms of the evaluator (pnr_confusion over compact segment ids + tensor ops) vs plain segment loops."""
+    g = torch.Generator().manual_seed(9)
+    C, K, H, W = 5, 4, 40, 60
+    thing = [1, 0, 1, 0, 0]
+    ev = Evaluator(NS(num_classes=C, num_instances=K), is_thing=thing)
+    ref = np.zeros((C, 4))
+    for f in range(3):
+        # blocky ground truth and a prediction that agrees on most of it
+        gt_sem = torch.randint(0, C, (H // 10, W // 10), generator=g).repeat_interleave(10, 0).repeat_interleave(10, 1)
+        gt_ins = torch.randint(0, K, (H // 10, W // 10), generator=g).repeat_interleave(10, 0).repeat_interleave(10, 1)
+        th = torch.tensor(thing)[gt_sem] != 0
+        gt_pan = torch.where(th, gt_sem * 1000 + gt_ins, gt_sem)
+        gt_pan[:3] = -1                                                  # an ignored band
+        noise = torch.rand(H, W, generator=g) < 0.25
+        sem_logits = torch.nn.functional.one_hot(torch.where(noise, torch.randint(0, C, (H, W), generator=g), gt_sem), C).float() * 5
+        ins_logits = torch.nn.functional.one_hot(torch.where(noise, torch.randint(0, K, (H, W), generator=g), gt_ins), K).float() * 5
+        out = {"rgb_1": torch.zeros(1, H * W, 3, device=dev), "semantic_1": sem_logits.reshape(1, -1, C).to(dev),
+               "instance_1": ins_logits.reshape(1, -1, K).to(dev)}
+        res = ev.evaluate(out, {"panoptic_gt": gt_pan.reshape(1, -1).to(dev)})
+        ref += no.panoptic_quality_terms(res["panoptic_id"].cpu().numpy(), gt_pan.reshape(-1).numpy(), C)
+    got = ev.pq.cpu().numpy()
+    assert np.allclose(got, ref, atol=1e-9), (got, ref)
+    s = ev.summarize()
+    den = ref[:, 1] + 0.5 * ref[:, 2] + 0.5 * ref[:, 3]
+    assert abs(s["pq"] - np.mean(ref[den > 0, 0] / den[den > 0])) < 1e-12

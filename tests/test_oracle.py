@@ -266,3 +266,19 @@ def test_postprocessing_oracle_known_answers():
     assert sl.tolist() == [1, 0, 0] and il.tolist() == [1, -1, -1] and pan.tolist() == [1001, 0, 0]
     conf = no.confusion(np.array([0, 1, 1, 2, 5]), np.array([0, 1, 2, -1, 1]), 3)
     assert conf.tolist() == [[1, 0, 0], [0, 1, 0], [0, 1, 0]]
+
+
+def test_panoptic_quality_oracle_known_answer():
+    """One thing class (1) with two instances and one stuff class (0) on a 1 x 10 strip: a perfect stuff segment, one
+    instance matched at IoU 3/4, one instance missed (IoU 1/3 -> an FN and an FP), one ignored pixel."""
+    gt = np.array([0, 0, 0, 1000, 1000, 1000, 1001, 1001, 1001, -1])
+    pr = np.array([0, 0, 0, 1000, 1000, 1000, 1000, 1002, 1002, 1002])
+    t = no.panoptic_quality_terms(pr, gt, 2)
+    # class 0: IoU 1, TP 1.  class 1: gt 1000 (3 px) vs pred 1000 (4 px): inter 3, union 4 -> TP with IoU .75;
+    # gt 1001 (3 px) vs pred 1002 (2 valid px): inter 2, union 3 -> IoU 2/3 > .5 -> TP as well
+    assert np.allclose(t[0], [1.0, 1, 0, 0])
+    assert np.allclose(t[1], [0.75 + 2 / 3, 2, 0, 0])
+    pr2 = np.array([0, 0, 0, 1000, 1000, 1000, 1000, 1000, 1002, 1002])
+    t2 = no.panoptic_quality_terms(pr2, gt, 2)
+    # gt 1000 vs pred 1000 (5 px): inter 3, union 5 -> .6 TP; gt 1001 vs pred 1002 (1 valid px): inter 1, union 3 -> FN, FP
+    assert np.allclose(t2[1], [0.6, 1, 1, 1])
