@@ -269,8 +269,8 @@ def test_postprocessing_oracle_known_answers():
 
 
 def test_panoptic_quality_oracle_known_answer():
-    """One thing class (1) with two instances and one stuff class (0) on a 1 x 10 strip: a perfect stuff segment, one
-    instance matched at IoU 3/4, one instance missed (IoU 1/3 -> an FN and an FP), one ignored pixel."""
+    """One thing class (1) with two instances and one stuff class (0) on a 1 x 10 strip with one ignored pixel: first a
+    prediction that matches both instances (IoU 3/4 and 2/3), then one that misses the second (IoU 1/3 -> an FN and an FP)."""
     gt = np.array([0, 0, 0, 1000, 1000, 1000, 1001, 1001, 1001, -1])
     pr = np.array([0, 0, 0, 1000, 1000, 1000, 1000, 1002, 1002, 1002])
     t = no.panoptic_quality_terms(pr, gt, 2)
