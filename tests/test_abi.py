@@ -36,6 +36,20 @@ def test_library_loads_and_exports_every_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.MlpDesc) == 64          # 9 ints + reserved[7]
     assert ctypes.sizeof(_lib.MlpParamsHost) == 18 * ctypes.sizeof(ctypes.c_void_p)
+    # pnr_loss_cfg: the binding's fields are, in order and type, the header's (a silent mismatch would scramble the weights)
+    import re
+    hdr = open(os.path.join(ROOT, "include", "pnr.h")).read()
+    body = re.search(r"typedef struct pnr_loss_cfg \{(.*?)\} pnr_loss_cfg;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            ty, names = decl.split(None, 1)
+            fields += [(n.strip(), ty) for n in names.split(",")]
+    ct = {"float": ctypes.c_float, "int32_t": ctypes.c_int32}
+    assert [(n, ct[t]) for n, t in fields] == list(_lib.LossCfg._fields_)
+    assert ctypes.sizeof(_lib.LossCfg) == 4 * len(fields)
 
 
 def test_invalid_arguments_are_rejected_before_any_launch():
@@ -59,6 +73,19 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1
     d = ops.make_desc()
     assert lib.pnr_mlp_forward(ctypes.byref(d), null, null, null, 4, 4, null, 1, 16, null) == -1
+    # entry points added for training and the SURVEY 8f rows
+    assert lib.pnr_mlp_wgrad(ctypes.byref(d), null, null, 64, None, null, null) == -1
+    assert lib.pnr_mlp_wgrad_workspace_bytes(ctypes.byref(ops.make_desc(precision="fp32")), 64) == -1
+    assert lib.pnr_mlp_wgrad_workspace_bytes(ctypes.byref(d), 786432) > 0
+    assert lib.pnr_losses(None, 4, 3, 0, *([null] * 19)) == -1
+    assert lib.pnr_losses_workspace_bytes(529408) >= 64 + 2068 * 32
+    assert lib.pnr_ce3d(null, 4, 4, 3, null, 4, null, null, null) == -1
+    assert lib.pnr_confusion(one, one, 4, 10000, one, null) == -1 and b"8192" in lib.pnr_last_error()
+    assert lib.pnr_panoptic_labels(null, null, null, 4, 3, 0, null, null, null, null) == -1
+    intr = (ctypes.c_float * 4)(0.0, 1.0, 0.0, 0.0)
+    c2w = (ctypes.c_float * 12)()
+    assert lib.pnr_gen_rays(intr, c2w, 8, 8, 0.5, 10.0, null, 64, one, null) == -1 and b"focal" in lib.pnr_last_error()
+    assert lib.pnr_gen_rays(intr, c2w, 8, 8, 0.5, 10.0, null, 0, null, null) == 0            # empty input: a no-op
     # zero rays is a no-op, not an error (empty input edge case)
     assert lib.pnr_stratified(one, 0, 8, 0, null, one, null) == 0
     assert lib.pnr_embed(one, 0, 10, one, null) == 0
