@@ -62,7 +62,8 @@ def test_mlp_backward_matches_autograd(dev, geom):
     bf16-emulating oracle MLP (same rounded activations => same ReLU gates; against the fp32 forward the
     gates of near-zero units differ and the error grows ~1.5 % per layer of depth, which says nothing about
     the kernels) for the same upstream d_raw.  Per-tensor relative L2 error < 3 %."""
-    from panopticnerf_amd import make_network, train
+    from panopticnerf_amd import make_network
+    import _wgrad_ref as wref
     from types import SimpleNamespace as NS
     D, W, skips, C, K = geom
     torch.manual_seed(D * 7 + W + C)
@@ -83,7 +84,7 @@ def test_mlp_backward_matches_autograd(dev, geom):
     d_cm = d_raw.reshape(R * N, -1).T.contiguous().to(dev)
     _, img_b = net.packed_bwd(0, dev)
     dys = ops.mlp_backward(desc, img_b, d_cm, acts, R, N)
-    g = train.weight_grads(nerf, desc, acts, dys, d_cm, R * N)
+    g = wref.weight_grads(nerf, desc, acts, dys, d_cm, R * N)
     assert set(g) == set(params)
     errs = {k: _rel(g[k].cpu(), params[k].grad) for k in params}
     print("rel L2 errors:", {k: round(v, 4) for k, v in errs.items()})
@@ -104,7 +105,8 @@ def test_wgrad_kernel_vs_plain_gemm(dev, S):
     """pnr_mlp_wgrad on random bf16 buffers against fp32 matmuls of the same (slot-ordered) regions, un-permuted with
     the host-side slot maps: every job shape (256x256, 256x64, 128x256, 128x32, 32x128, 32x256, 64x128), tile tails
     (S % 64 != 0), slab tails and several slabs.  Not symmetric / not identity: transposes and permutations show."""
-    from panopticnerf_amd import make_network, train
+    from panopticnerf_amd import make_network
+    import _wgrad_ref as wref
     from types import SimpleNamespace as NS
     torch.manual_seed(S)
     net = make_network(NS(num_classes=45, num_instances=32))
@@ -118,10 +120,10 @@ def test_wgrad_kernel_vs_plain_gemm(dev, S):
     D, W, H = nerf.D, nerf.W, nerf.W // 2
     A = lambda i, w: acts[ao[i]: ao[i] + S * w].view(S, w).float()
     Y = lambda i, w: dys[do[i]: do[i] + S * w].view(S, w).float()
-    fW, fH = train.feat_slots(W, str(dev)), train.feat_slots(H, str(dev))
-    f32s, f64s = train.feat_slots(32, str(dev)), train.feat_slots(64, str(dev))
-    ex, ed = train.embed_slots(5, nerf.xyz_L, str(dev)), train.embed_slots(2, nerf.dir_L, str(dev))
-    inv = lambda idx, n: train._inverse(idx, n)
+    fW, fH = wref.feat_slots(W, str(dev)), wref.feat_slots(H, str(dev))
+    f32s, f64s = wref.feat_slots(32, str(dev)), wref.feat_slots(64, str(dev))
+    ex, ed = wref.embed_slots(5, nerf.xyz_L, str(dev)), wref.embed_slots(2, nerf.dir_L, str(dev))
+    inv = lambda idx, n: wref._inverse(idx, n)
     def ref(dy, x, ridx, nrow, cidx, ncol, row0=0):
         full = dy.t() @ x                                            # (ma slots, nb slots)
         return full.index_select(0, inv(ridx, ridx.numel())[row0:row0 + nrow]).index_select(1, inv(cidx, ncol))

@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import _wgrad_ref as wref      # library-GEMM cross-check of pnr_mlp_wgrad
 from types import SimpleNamespace as NS
 from panopticnerf_amd import make_network, make_renderer, ops, synthetic, train
 dev = torch.device("cuda:0")
@@ -23,7 +25,7 @@ t, out = T(lambda: ops.composite(raw, z, rays, 45, 32, True)); print(f"composite
 g = {"rgb": torch.randn(R, 3, device=dev), "semantic": torch.randn(R, 45, device=dev)}
 t, d_raw = T(lambda: ops.composite_backward(raw, z, rays, 45, 32, g)); print(f"composite_backward     {t:8.3f} ms")
 t, dys = T(lambda: ops.mlp_backward(desc, img_b, d_raw, acts, R, N)); print(f"mlp_backward (dgrad)   {t:8.3f} ms")
-t, wg = T(lambda: train.weight_grads(nerf, desc, acts, dys, d_raw, R * N)); print(f"weight_grads (torch)   {t:8.3f} ms")
+t, wg = T(lambda: wref.weight_grads(nerf, desc, acts, dys, d_raw, R * N)); print(f"weight_grads (torch)   {t:8.3f} ms")
 shapes = {k: v.shape for k, v in nerf.state_dict().items()}
 t, wk = T(lambda: ops.mlp_wgrad(desc, acts, dys, R * N, shapes)); print(f"pnr_mlp_wgrad (HIP)    {t:8.3f} ms")
 opt = torch.optim.Adam(net.parameters(), lr=1e-3)
