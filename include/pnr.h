@@ -249,8 +249,10 @@ int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t
                    int n_fine, float* z_samples, int32_t* inds, float* z_fine, void* stream);
 
 /* ---- a8: bbox prior.  box (M,15) = centre(3) rotation rows(9) half extents(3).
- * hit_t (R,max_hits,2), hit_box (R,max_hits) int32 (-1 pad), hit_count (R) int32.
- * Bit-exact with pnro_bbox_hits. */
+ * Per ray the max_hits NEAREST intersected boxes (smallest t_in; ties: lower box index), stored in ascending
+ * (t_in, box index) order: hit_t (R,max_hits,2), hit_box (R,max_hits) int32 (-1 pad).  hit_count (R) int32 is the
+ * TRUE number of intersected boxes: a value > max_hits reports that the farthest ones were dropped (grow max_hits);
+ * pnr_sample_labels uses min(hit_count, max_hits) entries.  Bit-exact with pnro_bbox_hits. */
 int pnr_bbox_hits(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits,
                   float* hit_t, int32_t* hit_box, int32_t* hit_count, void* stream);
 

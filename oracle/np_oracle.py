@@ -109,6 +109,7 @@ def sample_pdf(z, weights, Nf, u=None):
 
 
 def bbox_hits(rays, box, max_hits):
+    """All hits per ray, then the max_hits nearest by (t_in, box index); count = true number of hits."""
     rays = np.asarray(rays, np.float64)
     box = np.asarray(box, np.float64)
     R, M = rays.shape[0], box.shape[0]
@@ -117,9 +118,8 @@ def bbox_hits(rays, box, max_hits):
     cnt = np.zeros(R, np.int64)
     for r in range(R):
         o, d, near, far = rays[r, 0:3], rays[r, 3:6], rays[r, 6], rays[r, 7]
+        found = []
         for m in range(M):
-            if cnt[r] >= max_hits:
-                break
             c, Rm, e = box[m, 0:3], box[m, 3:12].reshape(3, 3), box[m, 12:15]
             ol, dl = Rm @ (o - c), Rm @ d
             tmin, tmax = near, far
@@ -129,9 +129,11 @@ def bbox_hits(rays, box, max_hits):
                     tmin = np.fmax(tmin, np.fmin(t1, t2))
                     tmax = np.fmin(tmax, np.fmax(t1, t2))
             if tmin <= tmax:
-                hit_t[r, cnt[r]] = (tmin, tmax)
-                hit_box[r, cnt[r]] = m
-                cnt[r] += 1
+                found.append((tmin, m, tmax))
+        cnt[r] = len(found)
+        for k, (tmin, m, tmax) in enumerate(sorted(found)[:max_hits]):
+            hit_t[r, k] = (tmin, tmax)
+            hit_box[r, k] = m
     return hit_t, hit_box, cnt
 
 

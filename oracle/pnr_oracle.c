@@ -276,8 +276,10 @@ PNRO_API void pnro_merge_sorted(const float* z, const float* zs, int64_t R, int 
  *   inv = 1/dl_a; t1 = (-e_a - ol_a)*inv; t2 = (e_a - ol_a)*inv
  *   tmin = fmax(tmin, fmin(t1,t2)); tmax = fmin(tmax, fmax(t1,t2)); init tmin=near, tmax=far
  *   hit iff tmin <= tmax
- * Per ray the first max_hits hits in ascending box index: hit_t (R,max_hits,2) = (t_in,t_out),
- * hit_box (R,max_hits) int32 (-1 = none), hit_count (R) int32 = min(#hits, max_hits). */
+ * Per ray the max_hits NEAREST hits (smallest t_in; ties: lower box index) in ascending (t_in, box index)
+ * order: hit_t (R,max_hits,2) = (t_in,t_out), hit_box (R,max_hits) int32 (-1 = none), hit_count (R) int32 =
+ * the TRUE number of intersected boxes (> max_hits: the farthest were dropped; consumers use
+ * min(hit_count, max_hits) entries). */
 PNRO_API void pnro_bbox_hits(const float* rays, int64_t R, const float* box, int M, int max_hits,
                              float* hit_t, int32_t* hit_box, int32_t* hit_count)
 {
@@ -289,7 +291,7 @@ PNRO_API void pnro_bbox_hits(const float* rays, int64_t R, const float* box, int
             hit_t[(r * max_hits + h) * 2 + 0] = 0.0f;
             hit_t[(r * max_hits + h) * 2 + 1] = 0.0f;
         }
-        for (int m = 0; m < M && cnt < max_hits; ++m) {
+        for (int m = 0; m < M; ++m) {
             const float* b = box + m * 15;
             const float p0 = ry[0] - b[0], p1 = ry[1] - b[1], p2 = ry[2] - b[2];
             float tmin = ry[6], tmax = ry[7];
@@ -304,10 +306,21 @@ PNRO_API void pnro_bbox_hits(const float* rays, int64_t R, const float* box, int
                 tmax = fminf(tmax, fmaxf(t1, t2));
             }
             if (tmin <= tmax) {
-                hit_t[(r * max_hits + cnt) * 2 + 0] = tmin;
-                hit_t[(r * max_hits + cnt) * 2 + 1] = tmax;
-                hit_box[r * max_hits + cnt] = m;
-                ++cnt;
+                /* keep the max_hits nearest intervals in ascending (t_in, box index) order */
+                const int n = cnt < max_hits ? cnt : max_hits;
+                int pos = n;
+                while (pos > 0 && hit_t[(r * max_hits + pos - 1) * 2] > tmin) --pos;
+                if (pos < max_hits) {
+                    for (int k = (n < max_hits ? n : max_hits - 1); k > pos; --k) {
+                        hit_t[(r * max_hits + k) * 2 + 0] = hit_t[(r * max_hits + k - 1) * 2 + 0];
+                        hit_t[(r * max_hits + k) * 2 + 1] = hit_t[(r * max_hits + k - 1) * 2 + 1];
+                        hit_box[r * max_hits + k] = hit_box[r * max_hits + k - 1];
+                    }
+                    hit_t[(r * max_hits + pos) * 2 + 0] = tmin;
+                    hit_t[(r * max_hits + pos) * 2 + 1] = tmax;
+                    hit_box[r * max_hits + pos] = m;
+                }
+                ++cnt;   /* the TRUE number of intersected boxes; > max_hits means the farthest were dropped */
             }
         }
         hit_count[r] = cnt;
@@ -324,7 +337,8 @@ PNRO_API void pnro_sample_labels(const float* z, int64_t R, int N, const float* 
         for (int i = 0; i < N; ++i) {
             const float zz = z[r * N + i];
             int best = -1; float bt = 0.0f;
-            for (int h = 0; h < hit_count[r]; ++h) {
+            const int cnt = hit_count[r] < max_hits ? hit_count[r] : max_hits;
+            for (int h = 0; h < cnt; ++h) {
                 const float ti = hit_t[(r * max_hits + h) * 2], to = hit_t[(r * max_hits + h) * 2 + 1];
                 if (ti <= zz && zz <= to && (best < 0 || ti < bt)) { best = h; bt = ti; }
             }

@@ -204,8 +204,9 @@ def importance_z(z, weights, n_importance, u=None):
 
 # ------------------------------------------------------------------ a8 bbox prior
 def bbox_hits(rays, box, max_hits):
-    """rays (R,8), box (M,15) = c(3) Rrows(9) e(3).  Dense slab test -> first max_hits hits
-    per ray in ascending box index.  Returns hit_t (R,mh,2), hit_box (R,mh) int32, count."""
+    """rays (R,8), box (M,15) = c(3) Rrows(9) e(3).  Dense slab test -> the max_hits NEAREST hits per ray in
+    ascending (t_in, box index) order.  Returns hit_t (R,mh,2), hit_box (R,mh) int32, count (R) int32 = the true
+    number of intersected boxes (may exceed max_hits)."""
     o, d, near, far = rays[:, None, 0:3], rays[:, None, 3:6], rays[:, None, 6], rays[:, None, 7]
     c, Rm, e = box[None, :, 0:3], box[None, :, 3:12].reshape(1, -1, 3, 3), box[None, :, 12:15]
     p = o - c
@@ -220,21 +221,24 @@ def bbox_hits(rays, box, max_hits):
         tmax = torch.fmin(tmax, tf[..., a])
     hit = tmin <= tmax
     R, M = hit.shape
-    rank = torch.cumsum(hit.int(), 1) - 1
-    keep = hit & (rank < max_hits)
     hit_t = torch.zeros(R, max_hits, 2)
     hit_box = torch.full((R, max_hits), -1, dtype=torch.int32)
-    rr, mm = torch.nonzero(keep, as_tuple=True)
-    k = rank[rr, mm].long()
-    hit_t[rr, k, 0], hit_t[rr, k, 1] = tmin[rr, mm], tmax[rr, mm]
-    hit_box[rr, k] = mm.int()
-    return hit_t, hit_box, keep.sum(1).int()
+    if M == 0:
+        return hit_t, hit_box, torch.zeros(R, dtype=torch.int32)
+    key = torch.where(hit, tmin, torch.full_like(tmin, float("inf")))
+    order = torch.argsort(key, dim=1, stable=True)[:, :max_hits]          # stable: ties keep ascending box index
+    kept = torch.gather(hit, 1, order)
+    k = min(max_hits, M)
+    hit_t[:, :k, 0] = torch.where(kept, torch.gather(tmin, 1, order), torch.zeros(()))
+    hit_t[:, :k, 1] = torch.where(kept, torch.gather(tmax, 1, order), torch.zeros(()))
+    hit_box[:, :k] = torch.where(kept, order.int(), torch.full((), -1, dtype=torch.int32))
+    return hit_t, hit_box, hit.sum(1).int()
 
 
 def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     R, N = z.shape
     mh = hit_box.shape[1]
-    valid = (torch.arange(mh)[None, :] < hit_count[:, None])[:, None, :]
+    valid = (torch.arange(mh)[None, :] < hit_count.clamp(max=mh)[:, None])[:, None, :]
     ti, to = hit_t[:, None, :, 0], hit_t[:, None, :, 1]
     inside = valid & (ti <= z[..., None]) & (z[..., None] <= to)
     key = torch.where(inside, ti.expand(R, N, mh), torch.full((R, N, mh), float("inf")))

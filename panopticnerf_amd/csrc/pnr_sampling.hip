@@ -256,11 +256,24 @@ __global__ __launch_bounds__(256) void k_bbox_hits(const float* __restrict__ ray
                 tmin = fmaxf(tmin, fminf(t1, t2));
                 tmax = fminf(tmax, fmaxf(t1, t2));
             }
-            if (tmin <= tmax && cnt < max_hits) {
-                hit_t[(r * max_hits + cnt) * 2 + 0] = tmin;
-                hit_t[(r * max_hits + cnt) * 2 + 1] = tmax;
-                hit_box[r * max_hits + cnt] = m;
-                ++cnt;
+            if (tmin <= tmax) {
+                // keep the max_hits NEAREST intervals, ascending (t_in, box index): a street-scene ray crosses more boxes
+                // than max_hits, and the near ones are the ones its samples fall in.  Insertion from the back; the
+                // farthest entry falls off the end.  (Same op order as pnro_bbox_hits: bit-exact.)
+                const int n = cnt < max_hits ? cnt : max_hits;
+                int pos = n;
+                while (pos > 0 && hit_t[(r * max_hits + pos - 1) * 2] > tmin) --pos;
+                if (pos < max_hits) {
+                    for (int k = (n < max_hits ? n : max_hits - 1); k > pos; --k) {
+                        hit_t[(r * max_hits + k) * 2 + 0] = hit_t[(r * max_hits + k - 1) * 2 + 0];
+                        hit_t[(r * max_hits + k) * 2 + 1] = hit_t[(r * max_hits + k - 1) * 2 + 1];
+                        hit_box[r * max_hits + k] = hit_box[r * max_hits + k - 1];
+                    }
+                    hit_t[(r * max_hits + pos) * 2 + 0] = tmin;
+                    hit_t[(r * max_hits + pos) * 2 + 1] = tmax;
+                    hit_box[r * max_hits + pos] = m;
+                }
+                ++cnt;                      // TRUE number of intersected boxes: > max_hits reports the overflow
             }
         }
         hit_count[r] = cnt;
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256) void k_sample_labels(const float* __restrict__
          s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = s / N;
         const float zz = z[s];
-        const int cnt = hit_count[r];
+        const int cnt = hit_count[r] < max_hits ? hit_count[r] : max_hits;     // hit_count is the true count (overflow)
         int best = -1;
         float bt = 0.0f;
         for (int h = 0; h < cnt; ++h) {

@@ -98,6 +98,38 @@ def test_bbox_hits_and_labels_bitexact(dev, golden):
     assert int(e[2].sum()) == 0 and int((e[1] != -1).sum()) == 0
 
 
+def test_bbox_hits_keep_nearest_and_report_overflow(dev):
+    # a ray crossing more boxes than max_hits must keep the NEAREST ones (not the first in table order) and
+    # report the overflow through hit_count; bit-exact with the C oracle.
+    b = np.zeros((6, 15), np.float32)
+    b[:, 0:3] = [(0, 0, zc) for zc in (50, 10, 40, 20, 30, 45)]
+    b[:, 3:12] = np.eye(3).reshape(-1)
+    b[:, 12:15] = 1
+    rays = np.array([[0.5, 0.5, 0, 0, 0, 1, 0.1, 80]], np.float32)
+    ids = np.stack([np.arange(6), np.arange(6)], 1).astype(np.int32)
+    for mh in (1, 3, 6, 8):
+        a = ops.bbox_hits(T(rays, dev), T(b, dev), mh)
+        c = co.bbox_hits(rays, b, mh)
+        assert np.array_equal(N_(a[0]), c[0]) and np.array_equal(N_(a[1]), c[1]) and np.array_equal(N_(a[2]), c[2])
+        assert int(a[2][0]) == 6
+        assert list(N_(a[1])[0][: min(mh, 6)]) == [1, 3, 4, 2, 5, 0][: min(mh, 6)]
+        z = np.array([[10.0, 20.0, 30.0, 40.0]], np.float32)
+        l1 = ops.sample_labels(T(z, dev), *a, T(ids, dev))
+        l2 = co.sample_labels(z, *c, ids)
+        assert np.array_equal(N_(l1[0]), l2[0])
+    # random table, max_hits far below the hit count: every kept interval starts no later than any dropped one
+    rays = synthetic.camera_rays()[::1531].numpy()
+    box, _ = synthetic.random_boxes(64, 45, 32, seed=5)
+    box[:, 12:15] *= 6.0                                   # big boxes: many hits per ray
+    a3, a64 = ops.bbox_hits(T(rays, dev), box.to(dev), 3), ops.bbox_hits(T(rays, dev), box.to(dev), 64)
+    assert np.array_equal(N_(a3[2]), N_(a64[2])) and int(a3[2].max()) > 3
+    assert np.array_equal(N_(a3[0]), N_(a64[0])[:, :3]) and np.array_equal(N_(a3[1]), N_(a64[1])[:, :3])
+    t_in = N_(a64[0])[..., 0]
+    cnt = N_(a64[2])
+    for r in range(rays.shape[0]):
+        assert (np.diff(t_in[r, : cnt[r]]) >= 0).all()
+
+
 def test_bbox_axis_parallel_edge_cases(dev):
     b = np.zeros((1, 15), np.float32)
     b[0, 0:3] = (0, 0, 10)

@@ -175,7 +175,18 @@ def test_bbox_restatements_and_edge_cases():
     # empty box table and max_hits clipping
     assert co.bbox_hits(rays, np.zeros((0, 15), np.float32), 3)[2].sum() == 0
     many = np.repeat(b, 5, 0)
-    assert co.bbox_hits(r_in, many, 3)[2][0] == 3
+    t, bi, cnt = co.bbox_hits(r_in, many, 3)
+    assert cnt[0] == 5 and list(bi[0]) == [0, 1, 2]          # true count reports the overflow; ties keep the lower index
+    # more boxes than max_hits along the ray: the NEAREST max_hits survive, in ascending t_in, whatever the table order
+    line = np.repeat(b, 6, 0)
+    line[:, 2] = (50, 10, 40, 20, 30, 45)                     # centres along z; table order is not depth order
+    for fn in (co.bbox_hits, no.bbox_hits, lambda r, bb, mh: tuple(x.numpy() for x in to.bbox_hits(torch.tensor(r), torch.tensor(bb), mh))):
+        t, bi, cnt = fn(r_in.copy(), line, 3)
+        assert cnt[0] == 6 and list(bi[0]) == [1, 3, 4], (bi, cnt)
+        np.testing.assert_allclose(t[0, :, 0], (9.0, 19.0, 29.0))
+    ls, _ = co.sample_labels(np.array([[10.0, 20.0, 30.0, 40.0]], np.float32), *co.bbox_hits(r_in, line, 3),
+                             np.stack([np.arange(6), np.arange(6)], 1).astype(np.int32))
+    assert list(ls[0]) == [1, 3, 4, -1]                        # the dropped (far) box labels nothing; near samples are right
 
 
 def test_mlp_oracle_bf16_emulation_close_to_fp32():
