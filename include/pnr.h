@@ -96,7 +96,9 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params, vo
  * params_dev: the struct itself (and its pts_w / pts_b pointer arrays) in HOST memory, every pointer in it a
  * DEVICE pointer.  workspace: device scratch of pnr_mlp_pack_workspace_bytes bytes (fragment descriptors).
  * packed: device buffer of pnr_mlp_packed_bytes / pnr_mlp_bwd_packed_bytes bytes.  Three small host->device
- * copies (header, chunk table, descriptors) and one kernel are enqueued on `stream`. */
+ * copies (header, chunk table, descriptors) and one kernel are enqueued on `stream`, and `stream` is synchronised
+ * once before returning (the copies read call-local host staging memory): the ONE entry point that synchronises;
+ * it is set-up work -- never call it inside graph capture, use pnr_mlp_repack_device there. */
 int64_t pnr_mlp_pack_workspace_bytes(const pnr_mlp_desc* desc, int backward);
 int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, int backward,
                         void* workspace, void* packed, void* stream);

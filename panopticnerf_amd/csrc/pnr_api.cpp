@@ -14,6 +14,19 @@ void pnr_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+int pnr_cu_count(void)
+{
+    static int cached[64];                       // per device ordinal; 0 = not asked yet (benign race: same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 PNR_EXPORT int pnr_version(void) { return 1; }
 
 PNR_EXPORT const char* pnr_last_error(void) { return g_err; }

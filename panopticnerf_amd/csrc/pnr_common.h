@@ -36,11 +36,15 @@ void pnr_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
-// MI355X: 256 CUs.  Memory-bound grids are capped at 8 workgroups of 256 threads per CU
-// and grid-stride over the rest (cdna_hip_programming.md Guideline 11).
+// Compute units of the CURRENT device (256 on a full MI355X; partitioned / harvested parts report fewer),
+// queried once per device and cached (pnr_api.cpp).
+int pnr_cu_count(void);
+
+// Memory-bound grids are capped at 8 workgroups of 256 threads per CU and grid-stride over
+// the rest (cdna_hip_programming.md Guideline 11).
 static inline int pnr_grid_cap(int64_t wanted, int per_cu = 8)
 {
-    const int64_t cap = 256 * (int64_t)per_cu;
+    const int64_t cap = pnr_cu_count() * (int64_t)per_cu;
     if (wanted < 1) wanted = 1;
     return (int)(wanted < cap ? wanted : cap);
 }

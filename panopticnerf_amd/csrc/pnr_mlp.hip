@@ -328,8 +328,8 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
         PNR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 64 * WAVES, lds_bytes));
         wg_per_cu = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
     }
-    // persistent grid: every resident workgroup slot of the 256 CUs, grid-stride over sample groups
-    const int cap = 256 * wg_per_cu;
+    // persistent grid: every resident workgroup slot of the device's CUs, grid-stride over sample groups
+    const int cap = pnr_cu_count() * wg_per_cu;
     const int grid = a.n_groups < cap ? a.n_groups : cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
     PNR_CHECK_LAUNCH("pnr_mlp_forward");

@@ -180,7 +180,8 @@ static int launch_bwd(const MlpArgs& a0, hipStream_t stream)
         PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         configured = true;
     }
-    const int grid = a.n_groups < 256 ? a.n_groups : 256;
+    const int ncu = pnr_cu_count();               // persistent: one workgroup per CU
+    const int grid = a.n_groups < ncu ? a.n_groups : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
     PNR_CHECK_LAUNCH("pnr_mlp_backward");
     return PNR_OK;

@@ -298,8 +298,10 @@ PNR_EXPORT int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_param
     int rc = describe(desc, params_dev, backward, im);
     if (rc != PNR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    // header + chunk table, then the descriptors: small pageable-host copies (staged by the runtime before
-    // they return, so the local vectors may go out of scope); ordered on `st` before the kernel.
+    // header + chunk table, then the descriptors: small host-to-device copies ordered on `st` before the kernel.
+    // Their sources are this call's local vectors, so the stream is drained once before they go out of scope (the
+    // runtime happens to stage pageable copies before returning, but that is not documented behaviour).  This is the
+    // one entry point that synchronises -- setup, outside graph capture; pnr_mlp_repack_device is the sync-free form.
     PNR_HIP(hipMemcpyAsync(packed, &im.hdr, sizeof(im.hdr), hipMemcpyHostToDevice, st));
     PNR_HIP(hipMemcpyAsync((uint8_t*)packed + im.table_off, im.table.data(), im.table.size() * sizeof(pnr_chunk_entry),
                            hipMemcpyHostToDevice, st));
@@ -308,6 +310,7 @@ PNR_EXPORT int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_param
     hipLaunchKernelGGL(k_pack_fragments, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, (const PnrFragDesc*)workspace, n,
                        backward ? PNR_PREC_BF16 : desc->precision, (uint8_t*)packed + im.data_off);
     PNR_CHECK_LAUNCH("pnr_mlp_pack_device");
+    PNR_HIP(hipStreamSynchronize(st));
     return PNR_OK;
 }
 

@@ -49,26 +49,43 @@ class Evaluator:
         return res
 
     def _accumulate_pq(self, pred_id, gt_id):
-        """Per-frame PQ terms (Kirillov et al.): segments match when same class and IoU > 0.5 (then the match is unique)."""
-        C, K1 = self.n_classes, max(self.n_inst, 1) + 1
-        compact = lambda x: torch.where(x < 0, torch.full_like(x, -1),
-                                        torch.where(x >= 1000, (x // 1000) * K1 + (x % 1000) + 1, x * K1)).int().contiguous()
-        n_seg = C * K1
-        pair = ops.confusion(compact(pred_id), compact(gt_id), n_seg).double()          # [gt segment, pred segment]
+        """Per-frame PQ terms (Kirillov et al.): segments match when same class and IoU > 0.5 (then the match is unique).
+        Panoptic ids: class*1000 + instance for things, class for stuff; < 0 = ignore.  Segment ids are re-mapped PER
+        FRAME to 0..n-1 (torch.unique), so arbitrary instance indices (KITTI-360 ground truth uses large ones) can never
+        alias into another class's slots.  The pixel-pair counting is pnr_confusion; the small (n_seg x n_seg) IoU /
+        matching algebra below is host-side torch bookkeeping on the device (evaluation only, not on the render path)."""
+        C = self.n_classes
+        dev = pred_id.device
+
+        def segments(ids):
+            ok = ids >= 0
+            uniq, inv = torch.unique(ids[ok], return_inverse=True)
+            comp = torch.full_like(ids, -1)
+            comp[ok] = inv.int()
+            cls = torch.where(uniq >= 1000, uniq // 1000, uniq).long()
+            if uniq.numel() and int(cls.max()) >= C:
+                raise ValueError("panoptic id with class %d >= n_classes %d" % (int(cls.max()), C))
+            return comp.contiguous(), cls
+
+        seg_p, cls_p = segments(pred_id)
+        seg_g, cls_g = segments(gt_id)
+        n = max(int(cls_p.numel()), int(cls_g.numel()), 1)
+        pair = ops.confusion(seg_p, seg_g, n).double()[: max(cls_g.numel(), 1), : max(cls_p.numel(), 1)]   # [gt seg, pred seg]
+        if cls_g.numel() == 0 or cls_p.numel() == 0:
+            pair = torch.zeros((cls_g.numel(), cls_p.numel()), device=dev, dtype=torch.float64)
         # pixels whose ground truth is ignored do not count against the prediction
-        valid = gt_id >= 0
-        area_p = torch.bincount(compact(pred_id)[valid].long().clamp(min=0), minlength=n_seg).double()
+        valid = (gt_id >= 0) & (seg_p >= 0)
+        area_p = torch.bincount(seg_p[valid].long(), minlength=cls_p.numel()).double()
         area_g = pair.sum(1)
         union = area_g[:, None] + area_p[None, :] - pair
         iou = torch.where(union > 0, pair / union.clamp(min=1), torch.zeros_like(pair))
-        cls = torch.arange(n_seg, device=pair.device) // K1
-        match = (iou > 0.5) & (cls[:, None] == cls[None, :])
+        match = (iou > 0.5) & (cls_g[:, None] == cls_p[None, :])
         tp_g, tp_p = match.any(1), match.any(0)
-        terms = torch.zeros((C, 4), device=pair.device, dtype=torch.float64)
-        terms[:, 0].index_add_(0, cls, (iou * match).sum(1))
-        terms[:, 1].index_add_(0, cls, tp_g.double())
-        terms[:, 2].index_add_(0, cls, ((area_p > 0) & ~tp_p).double())
-        terms[:, 3].index_add_(0, cls, ((area_g > 0) & ~tp_g).double())
+        terms = torch.zeros((C, 4), device=dev, dtype=torch.float64)
+        terms[:, 0].index_add_(0, cls_g, (iou * match).sum(1))
+        terms[:, 1].index_add_(0, cls_g, tp_g.double())
+        terms[:, 2].index_add_(0, cls_p, ((area_p > 0) & ~tp_p).double())
+        terms[:, 3].index_add_(0, cls_g, ((area_g > 0) & ~tp_g).double())
         self.pq = terms if self.pq is None else self.pq + terms
 
     def summarize(self):

@@ -58,12 +58,32 @@ class Network(nn.Module):
         kw = dict(D=D, W=W, skip=skip, xyz_L=_get(cfg, "xyz_res", 10), dir_L=_get(cfg, "view_res", 4),
                   n_sem=_get(cfg, "num_classes", 0), n_inst=_get(cfg, "num_instances", 0))
         self.precision = _get(cfg, "precision", "bf16")
+        # the same key fallback as Renderer: N_importance, else cascade_samples
+        self.N_importance = _get(cfg, "N_importance", _get(cfg, "cascade_samples", 0))
+        # share_coarse_fine=True: ONE NeRF evaluated at both levels (must be asked for; never a silent fallback)
+        self.share_coarse_fine = bool(_get(cfg, "share_coarse_fine", False))
         self.nerf_0 = NeRF(**kw)
-        self.nerf_1 = NeRF(**kw) if _get(cfg, "N_importance", 0) > 0 else None
+        self.nerf_1 = NeRF(**kw) if (self.N_importance > 0 and not self.share_coarse_fine) else None
         self._packed = {}
 
     def nerf(self, level):
-        return self.nerf_0 if level == 0 or self.nerf_1 is None else self.nerf_1
+        if level == 0:
+            return self.nerf_0
+        if self.nerf_1 is not None:
+            return self.nerf_1
+        if self.share_coarse_fine:
+            return self.nerf_0
+        raise RuntimeError("Network has no fine NeRF (built with N_importance / cascade_samples = 0): a fine pass would "
+                           "silently evaluate and train the coarse weights.  Build the network from the same cfg as the "
+                           "renderer, or set cfg.share_coarse_fine = True to share one NeRF on purpose.")
+
+    def invalidate_packed(self):
+        """Drop the packed MFMA images so that the next render re-packs from the parameters.  Call after anything that
+        changes parameter VALUES without bumping tensor versions: `p.data.copy_()` / EMA / legacy loaders, and HIP-graph
+        replays of a captured optimiser step (the replay updates the parameters and the captured images, but an image
+        packed eagerly for another (level, precision, direction) key is stale afterwards)."""
+        for k, hit in list(self._packed.items()):
+            self._packed[k] = (None,) + tuple(hit[1:])        # keep the buffers (graph-captured pointers stay valid)
 
     def _version(self, level):
         return tuple(p._version for p in self.nerf(level).parameters())
@@ -72,15 +92,18 @@ class Network(nn.Module):
         """(desc, packed image on `device`) of level's NeRF, rebuilt when any parameter changed.  When the
         parameters live on that GPU the image is packed there (pnr_mlp_pack_device, buffers reused); otherwise
         on the host and uploaded."""
+        net = self.nerf(level)                   # raises when a fine level is asked of a coarse-only network
         key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision)
         ver = self._version(level)
         hit = self._packed.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1], hit[2]
-        net = self.nerf(level)
         desc = net.desc(precision)
         sd = dict(net.named_parameters())
         on_dev = torch.device(device).type == "cuda" and all(p.device == torch.device(device) for p in sd.values())
+        # cached until a parameter version changes (or invalidate_packed()).  Exception: a TRAINING network whose
+        # parameters live on the GPU is always re-packed -- the device packer is one small kernel, and tensor versions
+        # miss .data writes and HIP-graph replays of the optimiser step
+        if hit is not None and hit[0] == ver and not (self.training and on_dev):
+            return hit[1], hit[2]
         ptrs = tuple(p.data_ptr() for p in sd.values())
         if on_dev:
             # same parameter storage as last time (an in-place optimiser step): the descriptors already on the device
@@ -133,7 +156,7 @@ class Network(nn.Module):
             raise KeyError(f"load_reference_state_dict: missing {missing[:6]}{'...' if len(missing) > 6 else ''}, "
                            f"unexpected {unexpected[:6]}{'...' if len(unexpected) > 6 else ''}")
         self.load_state_dict(mapped, strict=False)
-        self._packed.clear()                 # the packed images are rebuilt from the new parameters
+        self.invalidate_packed()             # the packed images are rebuilt from the new parameters
         return {"loaded": sorted(mapped), "missing": missing, "unexpected": unexpected}
 
     def forward(self, *a, **k):

@@ -32,6 +32,27 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _on_device(fn):
+    """Run `fn` with the device of its first GPU-tensor argument current, so that `_stream()` is THAT device's current
+    stream (a tensor on cuda:1 while cuda:0 is current would otherwise be launched on the wrong device's stream)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        cand = []
+        for a in list(args) + list(kwargs.values()):
+            cand.extend(a.values() if isinstance(a, dict) else (a,))
+        for a in cand:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    break
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+
+    return wrapper
+
+
 def gen_rays(intr, c2w, width, height, near, far, pix=None, device=None):
     """Pinhole ray generation on the GPU (pnr_gen_rays).  intr: fx, fy, cx, cy; c2w: 3x4 camera-to-world
     (host values); pix: int32 GPU tensor of linear pixel indices or None (whole frame).  Returns rays (R,8)."""
@@ -49,6 +70,7 @@ def gen_rays(intr, c2w, width, height, near, far, pix=None, device=None):
     return rays
 
 
+@_on_device
 def stratified(rays, n_samples, lindisp=False, t_rand=None):
     """rays (R,8) -> z (R,N).  SURVEY 8a row a3."""
     rays = _chk(rays, "rays")
@@ -64,6 +86,7 @@ def stratified(rays, n_samples, lindisp=False, t_rand=None):
     return z
 
 
+@_on_device
 def points(rays, z):
     rays, z = _chk(rays, "rays"), _chk(z, "z")
     R, N = z.shape
@@ -72,6 +95,7 @@ def points(rays, z):
     return pts
 
 
+@_on_device
 def embed(x, L):
     """x (n,3) -> (n, 3+6L).  SURVEY 8a row a4."""
     x = _chk(x, "x")
@@ -123,6 +147,7 @@ def _param_struct(desc, params, device):
     return P, keep
 
 
+@_on_device
 def pack_mlp_device(desc, params, backward=False, out=None, workspace=None, repack=False):
     """Pack on the GPU straight from the (CUDA, fp32) parameter tensors: pnr_mlp_pack_device.
     Returns (image uint8 CUDA tensor, workspace) -- pass both back in to reuse the buffers.
@@ -181,6 +206,7 @@ def train_layout(desc, n_samples):
     return list(a), list(d)
 
 
+@_on_device
 def mlp_forward_train(desc, packed, rays, z):
     """Forward that also saves activations for the backward.  Returns (raw (ch,S) channel-major, acts bf16)."""
     rays, z = _chk(rays, "rays"), _chk(z, "z")
@@ -195,6 +221,7 @@ def mlp_forward_train(desc, packed, rays, z):
     return raw, acts
 
 
+@_on_device
 def mlp_backward(desc, packed_bwd, d_raw, acts, n_rays, n_samples):
     """Data-gradient pass: d_raw (ch,S) + saved activations -> dys (bf16, every layer's pre-activation gradient)."""
     d_raw = _chk(d_raw, "d_raw")
@@ -207,9 +234,7 @@ def mlp_backward(desc, packed_bwd, d_raw, acts, n_rays, n_samples):
     return dys
 
 
-_WG_WS = {}
-
-
+@_on_device
 def mlp_wgrad(desc, acts, dys, n_samples, shapes):
     """Weight gradients of every Linear from the training forward's `acts` and the data-gradient pass's `dys`
     (pnr_mlp_wgrad: hand-written MFMA kernel + deterministic slab reduction).  shapes: dict name -> shape of the
@@ -220,9 +245,9 @@ def mlp_wgrad(desc, acts, dys, n_samples, shapes):
     nbytes = lib.pnr_mlp_wgrad_workspace_bytes(ctypes.byref(desc), int(n_samples))
     if nbytes < 0:
         raise RuntimeError("pnr_mlp_wgrad_workspace_bytes: " + lib.pnr_last_error().decode(errors="replace"))
-    ws = _WG_WS.get(str(dev))                # one scratch buffer per device, grown to the largest size seen
-    if ws is None or ws.numel() < nbytes:
-        ws = _WG_WS[str(dev)] = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+    # per call, from torch's caching allocator: stream-ordered and graph-pool aware, so a captured step keeps its own
+    # block alive and concurrent streams never share scratch (a process-global buffer did neither)
+    ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
     grads = {k: torch.empty(tuple(shp), device=dev, dtype=torch.float32) for k, shp in shapes.items()}
     G, keep = _param_struct(desc, grads, dev)
     _lib.check(lib.pnr_mlp_wgrad(ctypes.byref(desc), _p(acts), _p(dys), int(n_samples), ctypes.byref(G), _p(ws), _stream()),
@@ -254,6 +279,7 @@ def _chk_raw(raw, ch, S):
     return raw.stride(0)
 
 
+@_on_device
 def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
     """Fused gamma() + NeRF MLP + heads on every sample.  SURVEY 8a rows a4+a5.
     Returns raw as (ch, R*N) when channel_major (fast layout; channel stride padded, see alloc_raw) else (R, N, ch)."""
@@ -274,6 +300,7 @@ def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
     return raw
 
 
+@_on_device
 def time_mlp_forward(desc, packed, rays, z, raw, iters):
     """Mean ms per launch measured with hipEvents on the launch stream (bench only)."""
     R, N = z.shape
@@ -284,6 +311,7 @@ def time_mlp_forward(desc, packed, rays, z, raw, iters):
     return float(ms.value)
 
 
+@_on_device
 def time_mlp_forward_clk(desc, packed, rays, z, raw, iters):
     """(mean ms per launch, mean shader MHz during the last launch) -- bench only."""
     R, N = z.shape
@@ -306,6 +334,7 @@ def probe_mfma_peak(random_operands, iters=20000, device=None):
     return float(tf.value), float(mhz.value)
 
 
+@_on_device
 def probe_raw_read(raw, n_rays, n_samples, iters=5):
     """GB/s of a pure read of the channel-major raw image in k_composite's access order (pnr_probe_raw_read) -- bench only."""
     gbs = ctypes.c_float(0.0)
@@ -316,6 +345,7 @@ def probe_raw_read(raw, n_rays, n_samples, iters=5):
     return float(gbs.value)
 
 
+@_on_device
 def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
               sem_mode=0, white_bkgd=False, want_weights=True):
     """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
@@ -353,6 +383,7 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
     return out
 
 
+@_on_device
 def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem=None, label_inst=None,
                        ce_sem=None, ce_inst=None, sem_mode=0):
     """Backward of composite() for channel-major raw.  grads: dict with any of rgb, depth, acc, semantic,
@@ -380,6 +411,7 @@ def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem
 _LOSS_KEYS = ("rgb", "depth", "semantic", "fix_semantic", "instance", "fix_instance")
 
 
+@_on_device
 def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e-5, want_grads=True, maps_are_prob=False):
     """The trainer's per-ray loss terms of one level and the gradient of their weighted total w.r.t. every map
     (pnr_losses; SURVEY 8f-1).  weights: dict over rgb/depth/semantic/fix_semantic/instance/fix_instance;
@@ -408,6 +440,7 @@ def losses(weights, maps, targets, n_sem=0, n_inst=0, depth_l2=False, fix_eps=1e
     return out, grads
 
 
+@_on_device
 def ce3d(raw, first_channel, n_classes, label):
     """Per-sample 3D cross-entropy of the learned logits raw[first_channel:+n_classes] (channel-major (ch,S)) against
     label (S or (R,N)) int32, -1 = unlabelled.  Returns a 2-element device tensor (mean CE, labelled count)."""
@@ -421,6 +454,7 @@ def ce3d(raw, first_channel, n_classes, label):
     return out
 
 
+@_on_device
 def sample_pdf(z, weights, n_importance, u=None, want_samples=True):
     """Coarse z, weights (R,Nc) -> z_fine (R,Nc+Nf) sorted [, z_samples (R,Nf), inds (R,Nf)].
     SURVEY 8a row a7."""
@@ -437,6 +471,7 @@ def sample_pdf(z, weights, n_importance, u=None, want_samples=True):
     return z_fine, zs, inds
 
 
+@_on_device
 def bbox_hits(rays, box, max_hits=8):
     """rays (R,8), box (M,15) -> hit_t (R,mh,2), hit_box (R,mh) int32, hit_count (R) int32.  Row a8."""
     rays, box = _chk(rays, "rays"), _chk(box, "box")
@@ -450,6 +485,7 @@ def bbox_hits(rays, box, max_hits=8):
     return hit_t, hit_box, hit_count
 
 
+@_on_device
 def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     z, hit_t = _chk(z, "z"), _chk(hit_t, "hit_t")
     hit_box, hit_count = _chk(hit_box, "hit_box", torch.int32), _chk(hit_count, "hit_count", torch.int32)
@@ -462,6 +498,7 @@ def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     return ls, li
 
 
+@_on_device
 def panoptic_labels(sem, inst=None, is_thing=None):
     """Composited maps -> (semantic label, instance label, panoptic id), each (R) int32 (pnr_panoptic_labels)."""
     sem, inst = _chk(sem, "sem"), _chk(inst, "inst")
@@ -474,6 +511,7 @@ def panoptic_labels(sem, inst=None, is_thing=None):
     return tuple(out)
 
 
+@_on_device
 def confusion(pred, gt, n_classes, conf=None):
     """Accumulate the (n_classes, n_classes) int64 confusion matrix conf[gt, pred] (pnr_confusion).  gt < 0 = ignore."""
     pred, gt = _chk(pred, "pred", torch.int32), _chk(gt, "gt", torch.int32)

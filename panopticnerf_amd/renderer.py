@@ -39,6 +39,11 @@ class Renderer:
         self.max_hits = _get(cfg, "max_hits", 8)
         self.sem_mode = {"none": 0, "logits": 0, "softmax": 1}[_get(cfg, "semantic_activation", "none")]
         self.keep_weights = _get(cfg, "keep_weights", True)
+        self.strict_hits = bool(_get(cfg, "strict_hits", False))
+        if self.N_importance > 0 and getattr(net, "nerf_1", None) is None and not getattr(net, "share_coarse_fine", False):
+            raise ValueError("make_renderer: cfg asks for a fine pass (N_importance / cascade_samples = %d) but the network "
+                             "was built without a fine NeRF -- build it with make_network(cfg) from the SAME cfg, or set "
+                             "cfg.share_coarse_fine = True to evaluate one NeRF at both levels on purpose" % self.N_importance)
 
     # --- one chunk of rays: the reference's render_rays (row a2)
     def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False):
@@ -50,6 +55,10 @@ class Renderer:
         hits = None
         if box is not None:
             hits = ops.bbox_hits(rays, box, self.max_hits)
+            if self.strict_hits and int((hits[2] > self.max_hits).sum()) > 0:      # opt-in: costs a device sync
+                raise RuntimeError("render_rays: %d ray(s) cross more than max_hits = %d boxes (up to %d): the farthest "
+                                   "intervals were dropped -- raise cfg.max_hits" % (int((hits[2] > self.max_hits).sum()),
+                                                                                    self.max_hits, int(hits[2].max())))
         if t_rand is None and self.perturb > 0 and train:
             t_rand = torch.rand((rays.shape[0], Nc), device=dev)
         z = ops.stratified(rays, Nc, self.lindisp, t_rand)
@@ -112,8 +121,17 @@ class Renderer:
                                          None if u is None else u[s:e], train, grad))
         ret = {}
         for k in outs[0]:
-            if outs[0][k].dim() == 0:       # per-level scalars of the training path (ce3d_*): mean over the chunks
-                ret[k] = outs[0][k] if len(outs) == 1 else torch.stack([o[k] for o in outs]).mean()
+            if outs[0][k].dim() == 0:
+                # per-level scalars of the training path: ce3d_<field>_<lv> is a mean over the chunk's LABELLED samples,
+                # ce3d_<field>_n_<lv> their number -> the frame's mean weights every chunk by its count
+                if len(outs) == 1:
+                    ret[k] = outs[0][k]
+                elif k.rsplit("_", 1)[0].endswith("_n"):
+                    ret[k] = torch.stack([o[k] for o in outs]).sum()
+                else:
+                    head, lv = k.rsplit("_", 1)
+                    n = torch.stack([o[f"{head}_n_{lv}"] for o in outs])
+                    ret[k] = (torch.stack([o[k] for o in outs]) * n).sum() / n.sum().clamp(min=1.0)
                 continue
             v = outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)
             ret[k] = v.reshape(*lead, *v.shape[1:])

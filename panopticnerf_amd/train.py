@@ -21,7 +21,7 @@ class LevelFn(torch.autograd.Function):
     per-sample 3D cross-entropies of the learned fields against those labels."""
 
     OUT = ("rgb", "depth", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance",
-           "ce3d_semantic", "ce3d_instance")
+           "ce3d_semantic", "ce3d_instance", "ce3d_semantic_n", "ce3d_instance_n")
 
     @staticmethod
     def forward(ctx, rend, lv, rays, z, ls, li, noise, names, *params):
@@ -43,11 +43,15 @@ class LevelFn(torch.autograd.Function):
         ctx.has_noise, ctx.has_ls, ctx.has_li = noise is not None, ls is not None, li is not None
         out["ce3d_semantic"] = ce_s[0].clone() if ce_s is not None else None
         out["ce3d_instance"] = ce_i[0].clone() if ce_i is not None else None
+        out["ce3d_semantic_n"] = ce_s[1].clone() if ce_s is not None else None        # labelled-sample counts: the
+        out["ce3d_instance_n"] = ce_i[1].clone() if ce_i is not None else None        # weights of the per-chunk means
         res = [out.get(k) for k in LevelFn.OUT]
-        return tuple(r if r is not None else empty for r in res)
+        res = tuple(r if r is not None else empty for r in res)
+        ctx.mark_non_differentiable(res[10], res[11])
+        return res
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_acc, g_w, g_sem, g_inst, g_fs, g_fi, g_ces, g_cei):
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w, g_sem, g_inst, g_fs, g_fi, g_ces, g_cei, _g_ns=None, _g_ni=None):
         raw, acts, z, rays, noise, ls, li, ce_s, ce_i = ctx.saved_tensors
         rend, lv = ctx.rend, ctx.lv
         net = rend.net
@@ -78,8 +82,7 @@ def level_train(rend, lv, rays, z, ls, li, noise):
     named = list(nerf.named_parameters())
     names = tuple((n, p.dtype) for n, p in named)
     res = LevelFn.apply(rend, lv, rays, z, ls, li, noise, names, *[p for _, p in named])
-    out = {k: v for k, v in zip(LevelFn.OUT, res) if v.numel()}
-    return out
+    return {k: v for k, v in zip(LevelFn.OUT, res) if v.numel()}
 
 
 def allreduce_grads(module, world=None, group=None):

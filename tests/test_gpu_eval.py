@@ -67,7 +67,7 @@ def test_panoptic_quality_matches_oracle(dev):
     """PQ terms of the evaluator (pnr_confusion over compact segment ids + tensor ops) vs plain segment loops."""
     g = torch.Generator().manual_seed(9)
     C, K, H, W = 5, 4, 40, 60
-    thing = [1, 0, 1, 0, 0]
+    thing = [0, 1, 1, 0, 0]        # class 0 is stuff: id = class*1000 + instance cannot tell a class-0 thing from a stuff class
     ev = Evaluator(NS(num_classes=C, num_instances=K), is_thing=thing)
     ref = np.zeros((C, 4))
     for f in range(3):
@@ -75,11 +75,13 @@ def test_panoptic_quality_matches_oracle(dev):
         gt_sem = torch.randint(0, C, (H // 10, W // 10), generator=g).repeat_interleave(10, 0).repeat_interleave(10, 1)
         gt_ins = torch.randint(0, K, (H // 10, W // 10), generator=g).repeat_interleave(10, 0).repeat_interleave(10, 1)
         th = torch.tensor(thing)[gt_sem] != 0
+        if f == 2:
+            gt_ins = gt_ins * 37 + 500        # arbitrary, large ground-truth instance indices (KITTI-360 style): ids are re-mapped per frame
         gt_pan = torch.where(th, gt_sem * 1000 + gt_ins, gt_sem)
         gt_pan[:3] = -1                                                  # an ignored band
         noise = torch.rand(H, W, generator=g) < 0.25
         sem_logits = torch.nn.functional.one_hot(torch.where(noise, torch.randint(0, C, (H, W), generator=g), gt_sem), C).float() * 5
-        ins_logits = torch.nn.functional.one_hot(torch.where(noise, torch.randint(0, K, (H, W), generator=g), gt_ins), K).float() * 5
+        ins_logits = torch.nn.functional.one_hot(torch.where(noise, torch.randint(0, K, (H, W), generator=g), gt_ins % 37 % K if f == 2 else gt_ins), K).float() * 5
         out = {"rgb_1": torch.zeros(1, H * W, 3, device=dev), "semantic_1": sem_logits.reshape(1, -1, C).to(dev),
                "instance_1": ins_logits.reshape(1, -1, K).to(dev)}
         res = ev.evaluate(out, {"panoptic_gt": gt_pan.reshape(1, -1).to(dev)})

@@ -49,6 +49,35 @@ def test_packed_cache_tracks_parameter_updates():
     assert img3 is not img1 and not torch.equal(img3, img1)
 
 
+def test_packed_cache_eval_vs_invalidate():
+    net = make_network(NS(D=2, W=128, skips=[])).eval()
+    _, img1 = net.packed(0, "cpu")
+    net.nerf_0.rgb_linear.bias.data.add_(1.0)            # .data write: the tensor version does NOT move
+    assert net.packed(0, "cpu")[1] is img1                # ... so the cache cannot see it
+    net.invalidate_packed()
+    _, img2 = net.packed(0, "cpu")
+    assert img2 is not img1 and not torch.equal(img2, img1)
+
+
+def test_fine_level_needs_a_fine_network_unless_sharing_is_asked_for():
+    # Network() / Network(cfg without N_importance) used to serve level 1 from the coarse NeRF silently
+    net0 = make_network(None)
+    assert net0.nerf_1 is None
+    with pytest.raises(RuntimeError, match="no fine NeRF"):
+        net0.nerf(1)
+    with pytest.raises(ValueError, match="fine pass"):
+        make_renderer(NS(N_samples=64, N_importance=128), net0)
+    with pytest.raises(ValueError, match="fine pass"):
+        make_renderer(NS(N_samples=64, cascade_samples=128), make_network(NS(N_samples=64)))
+    # the same key fallback on both sides: cascade_samples alone builds the fine NeRF
+    net = make_network(NS(N_samples=64, cascade_samples=128))
+    assert net.nerf_1 is not None and make_renderer(NS(N_samples=64, cascade_samples=128), net).N_importance == 128
+    # explicit weight sharing
+    shared = make_network(NS(N_samples=64, N_importance=128, share_coarse_fine=True))
+    assert shared.nerf_1 is None and shared.nerf(1) is shared.nerf_0
+    make_renderer(NS(N_samples=64, N_importance=128), shared)
+
+
 def test_renderer_fails_loudly_without_gpu():
     cfg = NS(N_samples=8, N_importance=0)
     rend = make_renderer(cfg, make_network(cfg).eval())
