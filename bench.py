@@ -1,27 +1,35 @@
 """bench.py -- BASELINE.json's metric on MI355X: Msamples/s (coarse+fine) of the render_rays
-path on synthetic KITTI-360-shaped frames (1408x376 rays, 64 + 128 hierarchical samples,
-8x256 NeRF MLPs with semantic + instance heads, 3D bbox prior).
+path on synthetic KITTI-360-shaped frames (1408x376 rays).
 
-A "step" is one pass of the whole hot path (Renderer.render) over one full frame per rank:
-stratified sampler -> bbox hits/labels -> coarse MLP -> compositing -> sample_pdf ->
-fine MLP -> compositing.  Inputs (rays, boxes, packed weights) are resident in HBM before the
-timed region.  MLP sample evaluations per frame = rays * (64 + 192).
+A "step" is one pass of the whole hot path (Renderer.render) over one full frame:
+stratified sampler -> [bbox hits/labels] -> coarse MLP -> compositing -> [sample_pdf ->
+fine MLP -> compositing].  Inputs (rays, boxes, packed weights) are resident in HBM before the
+timed region.  MLP sample evaluations per ray = N_samples + (N_samples + N_importance).
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W] [--config 1..5] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (fused fine-level MLP, MFMA-bound): algorithmic FLOP per
-                  launch / mean launch duration from hipEvents on the launch stream;
-  cpu_baseline -- the oracle's PyTorch CPU restatement of the same path timed on the host
-                  cores on a bounded ray sample (a reported baseline, not the target).
+--config n   BASELINE.json configs[n-1] (panopticnerf_amd/synthetic.py::BASELINE_CONFIGS); default 5 = the
+             configuration the metric is quoted on (full panoptic, 64+128 samples, 8x256 MLPs, 45+32 heads, bbox prior).
+--scaling    weak (default): every rank renders its own full frame, no collective on the data path.
+             strong: ONE frame, rays sharded over the ranks (shard.render_sharded), fine-level label maps + rgb +
+             depth all-gathered inside the timed region (BASELINE configs[4]: "rays sharded over 8 GPUs").
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline                  -- the dominant kernel (fused top-level MLP, MFMA-bound): algorithmic FLOP per launch /
+                               mean launch duration from hipEvents on the launch stream;
+  roofline_composite[_coarse] -- the compositing scan (HBM-bound) at the top / coarse level;
+  cpu_baseline              -- the oracle's PyTorch CPU restatement of the same workload timed on the host cores on a
+                               bounded ray sample (a reported baseline, not the target);
+  cpu_baseline_config1      -- BASELINE configs[0] (the reference's CPU-runnable case) on the host, full frame if the
+                               time budget allows;
+  train_step                -- secondary: one training step on a ray batch per rank (never the headline value).
 """
 import argparse
 import json
 import os
 import sys
 import time
-from types import SimpleNamespace as NS
 
 import torch
 
@@ -30,15 +38,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 W_IMG, H_IMG = 1408, 376
-N_C, N_F = 64, 128
-N_SEM, N_INST = 45, 32           # KITTI-360 label ids 0..44; 32 instance slots (reference values unverifiable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md chip table
+MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
 
-def mlp_flops_per_sample(D=8, W=256, ex=63, ed=27, n_sem=N_SEM, n_inst=N_INST):
+def mlp_flops_per_sample(D=8, W=256, skip=4, ex=63, ed=27, n_sem=45, n_inst=32):
     """Algorithmic (unpadded) forward FLOP per sample, SURVEY.md 8d: 2 * MACs."""
-    mac = ex * W + (D - 1) * W * W + ex * W          # trunk incl. the skip layer's extra gamma(x) columns
+    mac = ex * W + (D - 1) * W * W                   # trunk
+    if 0 <= skip < D - 1:
+        mac += ex * W                                # the skip layer's extra gamma(x) columns
     mac += W + W * W + (W + ed) * (W // 2) + (W // 2) * 3
     for n in (n_sem, n_inst):
         if n:
@@ -46,17 +55,40 @@ def mlp_flops_per_sample(D=8, W=256, ex=63, ed=27, n_sem=N_SEM, n_inst=N_INST):
     return 2 * mac
 
 
-def traffic(kernel, n_rays_launch):
+def composite_bytes_per_ray(N, C, K, labels, weights):
+    """Algorithmic HBM bytes per ray of k_composite: raw + z read, [one int32 label array per labelled
+    field read], [weights written], maps written (learned + fixed fields), the ray record."""
+    n_lab = ((1 if C else 0) + (1 if K else 0)) if labels else 0
+    fixed = (C + K) if labels else 0
+    return 4 * N * (4 + C + K + 1) + n_lab * 4 * N + (4 * N if weights else 0) + 4 * (5 + C + K + fixed) + 32
+
+
+def traffic(kernel, n_rays_launch, config):
     """HBM bytes per launch of `kernel` from the last committed rocprofv3 PMC passes of this same bench
     command (profiles/latest_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs,
     FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed
-    process, so this is the recorded value for the 65,536-ray fine-level launch, or None."""
+    process, so this is the recorded value for the 65,536-ray fine-level launch of config 5, or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)[kernel]
-        return int(t["hbm_bytes_per_launch"]) if n_rays_launch == 65536 else None
+        return int(t["hbm_bytes_per_launch"]) if (n_rays_launch == 65536 and config == 5) else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def make_train_batch(rays, box, ids, n_rays, C, K, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    idx = torch.randint(0, rays.shape[0], (n_rays,), generator=g, device=dev)
+    tb = {"rays": rays[idx][None].contiguous(),
+          "rgb": torch.rand((1, n_rays, 3), generator=g, device=dev),
+          "depth": torch.rand((1, n_rays), generator=g, device=dev) * 60.0 - 10.0}     # <= 0: no stereo depth
+    if box is not None:
+        tb.update(bbox=box, bbox_ids=ids)
+    if C:
+        tb["pseudo_label"] = torch.randint(-1, C, (1, n_rays), generator=g, device=dev)
+    if K:
+        tb["instance_label"] = torch.randint(-1, K, (1, n_rays), generator=g, device=dev)
+    return tb
 
 
 def graph_step_child(args):
@@ -66,21 +98,18 @@ def graph_step_child(args):
     from panopticnerf_amd import NetworkWrapper, make_network, synthetic
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    cfg = NS(N_samples=N_C, N_importance=N_F, num_classes=N_SEM, num_instances=N_INST, precision=args.precision)
+    c = synthetic.BASELINE_CONFIGS[args.config]
+    cfg = synthetic.baseline_cfg(args.config, precision=args.precision)
     torch.manual_seed(0)
     tnet = make_network(cfg).to(dev).train()
     synthetic.trained_like_(tnet)
     wrap = NetworkWrapper(tnet, cfg)
     opt = torch.optim.Adam(tnet.parameters(), lr=5e-4, capturable=True)
-    g = torch.Generator(device=dev).manual_seed(0)
     rays = synthetic.camera_rays().to(dev)
-    box, ids = synthetic.random_boxes(64, N_SEM, N_INST)
-    idx = torch.randint(0, rays.shape[0], (args.train_rays,), generator=g, device=dev)
-    tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
-          "rgb": torch.rand((1, args.train_rays, 3), generator=g, device=dev),
-          "depth": torch.rand((1, args.train_rays), generator=g, device=dev) * 60.0 - 10.0,
-          "pseudo_label": torch.randint(-1, N_SEM, (1, args.train_rays), generator=g, device=dev),
-          "instance_label": torch.randint(-1, N_INST, (1, args.train_rays), generator=g, device=dev)}
+    box = ids = None
+    if c["bbox"]:
+        box, ids = (t.to(dev) for t in synthetic.random_boxes(64, c["num_classes"], max(c["num_instances"], 1)))
+    tb = make_train_batch(rays, box, ids, args.train_rays, c["num_classes"], c["num_instances"], dev, 0)
 
     def step():
         opt.zero_grad(set_to_none=False)
@@ -108,19 +137,95 @@ def graph_step_child(args):
     print(json.dumps({"graph_ms": round((time.perf_counter() - t0) / args.train_steps * 1e3, 3)}), flush=True)
 
 
+def event_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_leg(config, params, rays_c, box, ids, seconds, full_frame):
+    """The oracle's PyTorch CPU path on `config`, time-bounded.  full_frame: walk the frame in 8192-ray chunks in order
+    (stops early when the budget is spent); otherwise an evenly strided 512-ray-per-chunk subsample.  Returns
+    (Msamples/s, rays done, seconds, threads used, threads available, first chunk (rays, reference output))."""
+    from oracle import torch_oracle as to
+    from panopticnerf_amd import synthetic
+    c = synthetic.BASELINE_CONFIGS[config]
+    oc = to.mlp_config(D=c["D"], W=c["W"], skips=tuple(c["skips"]), n_sem=c["num_classes"], n_inst=c["num_instances"],
+                       head_W=c["W"] // 2)
+    Nc, Nf = c["N_samples"], c["N_importance"]
+    per_ray = Nc + (Nc + Nf if Nf else 0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+
+    def run(sub):
+        t0 = time.perf_counter()
+        r = to.render_rays(params, oc, sub, Nc, Nf, box=box if c["bbox"] else None, box_ids=ids if c["bbox"] else None)
+        return r, time.perf_counter() - t0
+
+    n_rays = rays_c.shape[0]
+    stride = max(n_rays // 512, 1)
+    # pick the thread count that is fastest on this host (all logical CPUs is often NOT: SMT +
+    # oversubscribed OpenMP teams), then spend the time budget at that setting
+    probe = rays_c[::stride][:256].contiguous()
+    best_n, best_t = 1, float("inf")
+    first = None
+    with torch.no_grad():
+        for n in sorted({min(k, avail) for k in (8, 16, 32, 64, 128, avail)}):
+            torch.set_num_threads(n)
+            run(probe[:64])
+            _, t = run(probe)
+            if t < best_t:
+                best_n, best_t = n, t
+            if t > 20.0:
+                break
+        torch.set_num_threads(best_n)
+        done, t_cpu, k = 0, 0.0, 0
+        while t_cpu < seconds:
+            if full_frame:
+                sub = rays_c[k * 8192:(k + 1) * 8192]
+            else:
+                sub = rays_c[k::stride][:512].contiguous() if k < stride else rays_c[:0]
+            if sub.shape[0] == 0:
+                break
+            ref, t = run(sub)
+            if first is None:
+                first = (sub, ref)
+            t_cpu += t
+            done += sub.shape[0]
+            k += 1
+    return done * per_ray / t_cpu / 1e6, done, t_cpu, best_n, avail, first
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=5, choices=[1, 2, 3, 4, 5], help="BASELINE.json configs[n-1]")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (0 = skip)")
+    ap.add_argument("--cpu1-seconds", type=float, default=None,
+                    help="time budget of the config-1 CPU leg (default: 15 s with --config 5 or 1, else 0)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=3, help="secondary training-step measurement (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=None, help="secondary training-step measurement (0 = skip; "
+                    "default 3 with --config 5, else 0)")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--graph-step-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.train_steps is None:
+        args.train_steps = 3 if args.config == 5 else 0
+    if args.cpu1_seconds is None:
+        args.cpu1_seconds = 15.0 if (args.config in (1, 5) and args.cpu_seconds > 0) else 0.0
     if args.graph_step_child:
         return graph_step_child(args)
 
@@ -136,22 +241,47 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from panopticnerf_amd import make_network, make_renderer, ops, synthetic
+    from panopticnerf_amd import make_network, make_renderer, ops, shard, synthetic
 
-    cfg = NS(N_samples=N_C, N_importance=N_F, num_classes=N_SEM, num_instances=N_INST, precision=args.precision,
-             chunk_size=args.chunk, keep_weights=False)
+    c = synthetic.BASELINE_CONFIGS[args.config]
+    N_C, N_F, N_SEM, N_INST = c["N_samples"], c["N_importance"], c["num_classes"], c["num_instances"]
+    N_TOP = N_C + N_F
+    per_ray = N_C + (N_TOP if N_F else 0)
+    cfg = synthetic.baseline_cfg(args.config, precision=args.precision, chunk_size=args.chunk, keep_weights=False)
     torch.manual_seed(0)
     net = make_network(cfg).eval()
     synthetic.trained_like_(net)
     net = net.to(dev)
     rend = make_renderer(cfg, net)
-    # weak scaling: every rank renders its own full frame (a different camera yaw); rays are independent,
-    # so there is no data-path collective
-    rays = synthetic.camera_rays(yaw=0.05 * rank).to(dev)
-    box, ids = synthetic.random_boxes(64, N_SEM, N_INST)
-    batch = {"rays": rays.reshape(H_IMG, W_IMG, 8), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    strong = args.scaling == "strong"
+    # weak scaling: every rank renders its own full frame (a different camera yaw); strong: every rank holds the SAME
+    # frame and renders its interleaved share of the rays.  Rays are independent: no data-path collective;
+    # strong scaling adds the all-gather of the per-ray output maps.
+    rays = synthetic.camera_rays(yaw=0.0 if strong else 0.05 * rank).to(dev)
+    box = ids = None
+    if c["bbox"]:
+        box, ids = (t.to(dev) for t in synthetic.random_boxes(64, N_SEM, max(N_INST, 1)))
     n_rays = rays.shape[0]
-    samples_per_frame = n_rays * (N_C + (N_C + N_F))
+    top = 1 if N_F else 0
+
+    def bdict(r):
+        b = {"rays": r}
+        if box is not None:
+            b.update(bbox=box, bbox_ids=ids)
+        return b
+
+    if strong:
+        reduce_fn = shard.label_maps(level=top) if N_SEM else None
+        keys = None if N_SEM else (f"rgb_{top}", f"depth_{top}")
+
+        def frame():
+            return shard.render_sharded(lambda r: {k: v[0] for k, v in rend.render(bdict(r[None])).items()}, rays, rank, world,
+                                        gather=True, keys=keys, reduce_fn=reduce_fn)
+    else:
+        full = bdict(rays.reshape(H_IMG, W_IMG, 8))
+
+        def frame():
+            return rend.render(full)
 
     def sync():
         if world > 1:
@@ -160,11 +290,11 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            rend.render(batch)
+            frame()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            rend.render(batch)
+            frame()
         sync()
         dt = time.perf_counter() - t0
     if world > 1:
@@ -172,60 +302,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = samples_per_frame * world * args.steps / dt / 1e6
+    frames_per_step = 1 if strong else world
+    value = n_rays * per_ray * frames_per_step * args.steps / dt / 1e6
 
     roofline = None
     extra = {}
     if rank == 0 and not args.no_roofline:
-        # dominant kernel: the fused fine-level MLP on one renderer chunk
         with torch.no_grad():
+            # dominant kernel: the fused top-level MLP on one renderer chunk
             rc = rays[: args.chunk].contiguous()
-            z = ops.stratified(rc, N_C + N_F)
-            desc, img = net.packed(1, dev)
-            raw = ops.alloc_raw(4 + N_SEM + N_INST, rc.shape[0] * (N_C + N_F), dev)   # as Renderer allocates it
+            Rc = rc.shape[0]
+            z = ops.stratified(rc, N_TOP)
+            desc, img = net.packed(top, dev)
+            ch = 4 + N_SEM + N_INST
+            raw = ops.alloc_raw(ch, Rc * N_TOP, dev)   # as Renderer allocates it
             ops.time_mlp_forward(desc, img, rc, z, raw, 1)
             ms, kernel_mhz = ops.time_mlp_forward_clk(desc, img, rc, z, raw, 5)
             # what the matrix pipe of THIS device sustains (register-only MFMA loop): with constant operands, and with
             # random operands that change from MFMA to MFMA (the toggle rate of real data: the chip lowers its clock)
             pk_const, mhz_const = ops.probe_mfma_peak(False, 12000, dev)
             pk_rand, mhz_rand = ops.probe_mfma_peak(True, 12000, dev)
-            S = rc.shape[0] * (N_C + N_F)
-            flops = S * mlp_flops_per_sample()
+            S = Rc * N_TOP
+            skip = c["skips"][0] if c["skips"] else -1
+            flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
-            peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
-            roofline = {"kernel": "k_mlp_fused (fine level, %d rays x %d samples)" % (rc.shape[0], N_C + N_F),
+            peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+            roofline = {"kernel": "k_mlp_fused (%s level, %d rays x %d samples, %dx%d MLP)" % ("fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", rc.shape[0]),
+                        "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", Rc, args.config),
                         "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
                         "shader_mhz_during_kernel": round(kernel_mhz, 0),
                         "mfma_sustained": {"note": "register-only bf16 MFMA loop on every SIMD of this device, measured in this run",
                                            "constant_operands_tflops": round(pk_const, 1), "constant_operands_mhz": round(mhz_const, 0),
                                            "random_operands_tflops": round(pk_rand, 1), "random_operands_mhz": round(mhz_rand, 0)},
-                        "frac_of_sustained_random_operand_peak": round(ach / pk_rand, 4) if pk_rand > 0 else None}
-            # secondary: compositing scan (HBM-bound), algorithmic bytes per SURVEY.md 8d
-            lab = torch.zeros((rc.shape[0], N_C + N_F), device=dev, dtype=torch.int32)
-            for _ in range(2):
-                ops.composite(raw, z, rc, N_SEM, N_INST, True, None, lab, lab, 0, False, True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                ops.composite(raw, z, rc, N_SEM, N_INST, True, None, lab, lab, 0, False, True)
-            e1.record()
-            torch.cuda.synchronize()
-            cms = e0.elapsed_time(e1) / 5
-            N = N_C + N_F
-            ch = 4 + N_SEM + N_INST
-            bytes_ray = 4 * N * (ch + 1) + 2 * 4 * N + 4 * N + 4 * (5 + 2 * (N_SEM + N_INST)) + 32
-            gbs = rc.shape[0] * bytes_ray / (cms * 1e-3) / 1e9
-            read_gbs = ops.probe_raw_read(raw, rc.shape[0], N, 5)     # same image, same order, no arithmetic
-            extra["roofline_composite"] = {"kernel": "k_composite<channel-major>", "bound": "hbm",
-                                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k_composite", rc.shape[0]),
-                                           "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray,
-                                           "pure_read_same_pattern_gbs": round(read_gbs, 1),
-                                           "frac_of_pure_read": round(gbs / read_gbs, 4) if read_gbs > 0 else None}
+                        "frac_of_sustained_random_operand_peak": round(ach / pk_rand, 4) if (pk_rand > 0 and args.precision == "bf16") else None}
 
-    # secondary measurement (never the headline value): one training step on a 4096-ray batch per rank --
+            # secondary: compositing scan (HBM-bound), algorithmic bytes per SURVEY.md 8d, at the top and the coarse level
+            def comp_roofline(N, want_w, tag):
+                zz = ops.stratified(rc, N)
+                rw = raw if N == N_TOP else ops.alloc_raw(ch, Rc * N, dev)
+                if N != N_TOP:
+                    rw.copy_(raw[:, : Rc * N])
+                lab = torch.zeros((Rc, N), device=dev, dtype=torch.int32) if c["bbox"] else None
+                ls, li = (lab if N_SEM else None), (lab if N_INST else None)
+                cms = event_ms(lambda: ops.composite(rw, zz, rc, N_SEM, N_INST, True, None, ls, li, 0, False, want_w), 5)
+                bytes_ray = composite_bytes_per_ray(N, N_SEM, N_INST, c["bbox"] and (N_SEM or N_INST), want_w)
+                gbs = Rc * bytes_ray / (cms * 1e-3) / 1e9
+                read_gbs = ops.probe_raw_read(rw, Rc, N, 5)     # same image, same order, no arithmetic
+                return {"kernel": "k_composite<channel-major> (%s, N=%d, %d channels)" % (tag, N, ch), "bound": "hbm",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": traffic("k_composite", Rc, args.config) if N == 192 else None,
+                        "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray,
+                        "pure_read_same_pattern_gbs": round(read_gbs, 1),
+                        "frac_of_pure_read": round(gbs / read_gbs, 4) if read_gbs > 0 else None}
+
+            # weights are written where the renderer needs them: the coarse level of a coarse+fine render (sample_pdf input)
+            extra["roofline_composite"] = comp_roofline(N_TOP, not N_F, "top level")
+            if N_F:
+                extra["roofline_composite_coarse"] = comp_roofline(N_C, True, "coarse level, weights written")
+
+    # secondary measurement (never the headline value): one training step on a ray batch per rank --
     # render with autograd, the loss wrapper (RGB / depth / 2D CE on learned and fixed fields / 3D CE; fused HIP),
     # backward through the HIP kernels (compositing, dgrad, wgrad), flat-bucket
     # gradient all-reduce over RCCL, Adam.  Guarded: a failure here must not lose the headline line.
@@ -237,19 +373,14 @@ def main():
             synthetic.trained_like_(tnet)
             wrap = NetworkWrapper(tnet, cfg)       # the trainer's loss wrapper: render + fused losses
             opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
-            g = torch.Generator(device=dev).manual_seed(rank)
-            idx = torch.randint(0, n_rays, (args.train_rays,), generator=g, device=dev)
-            tb = {"rays": rays[idx][None].contiguous(), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
-                  "rgb": torch.rand((1, args.train_rays, 3), generator=g, device=dev),
-                  "depth": torch.rand((1, args.train_rays), generator=g, device=dev) * 60.0 - 10.0,     # <= 0: no stereo depth
-                  "pseudo_label": torch.randint(-1, N_SEM, (1, args.train_rays), generator=g, device=dev),
-                  "instance_label": torch.randint(-1, N_INST, (1, args.train_rays), generator=g, device=dev)}
+            tb = make_train_batch(rays, box, ids, args.train_rays, N_SEM, N_INST, dev, rank)
 
-            def step():
+            def step(reduce=True):
                 opt.zero_grad(set_to_none=True)
                 _, loss, _, _ = wrap(tb)
                 loss.backward()
-                pnr_train.allreduce_grads(tnet, world)
+                if reduce:
+                    pnr_train.allreduce_grads(tnet, world)
                 opt.step()
                 return loss
 
@@ -260,10 +391,13 @@ def main():
                 ll = step()
             sync()
             tdt = (time.perf_counter() - t0) / args.train_steps
+            ar_ms = None
             if world > 1:
                 tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tdt = float(tt.item())
+                # the collective alone: ONE flat bucket of every gradient, RCCL over xGMI
+                ar_ms = event_ms(lambda: pnr_train.allreduce_grads(tnet, world), 10, 3)
             graph_ms = None
             if world == 1:
                 # the same step captured into ONE HIP graph (fresh process: torch's capture wants a network whose autograd
@@ -271,82 +405,78 @@ def main():
                 import subprocess
                 try:
                     cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-step-child", "--train-rays", str(args.train_rays),
-                                         "--train-steps", str(max(args.train_steps, 5)), "--precision", args.precision],
-                                        capture_output=True, text=True, timeout=180)
+                                         "--train-steps", str(max(args.train_steps, 5)), "--precision", args.precision,
+                                         "--config", str(args.config)], capture_output=True, text=True, timeout=180)
                     line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
                     graph_ms = json.loads(line[-1])["graph_ms"] if line else "failed: rc %d" % cp.returncode
                 except Exception as e:      # noqa: BLE001
                     graph_ms = "failed: %s" % type(e).__name__
+            S_step = args.train_rays * per_ray
+            skip = c["skips"][0] if c["skips"] else -1
+            fwd_flops = mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
+            n_par = sum(p.numel() for p in tnet.parameters())
             train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms, "rays_per_rank": args.train_rays,
-                          "Msamples_per_s_fwd_bwd": round(args.train_rays * world * (N_C + N_C + N_F) / tdt / 1e6, 2),
+                          "Msamples_per_s_fwd_bwd": round(S_step * world / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
-                          "grad_allreduce": "flat bucket, %s" % ("RCCL (nccl)" if world > 1 else "single rank: skipped"),
-                          "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE"}
+                          "grad_allreduce": "flat bucket of %d fp32, %s" % (n_par, "RCCL (nccl)" if world > 1 else "single rank: skipped"),
+                          "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
+                          "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE",
+                          # forward + data-gradient + weight-gradient GEMMs = 3x the forward's algorithmic FLOPs
+                          "roofline": {"bound": "mfma", "flop_per_sample_fwd_bwd": 3 * fwd_flops,
+                                       "achieved": round(3 * fwd_flops * S_step / tdt / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(3 * fwd_flops * S_step / tdt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "note": "whole step per rank incl. losses, Adam and host launch gaps; the saved activations "
+                                               "+ dY regions move ~2*(%d+%d) B/sample through HBM (DESIGN.md 7)" % (
+                                                   2 * (64 + 32 + (c["D"] + 1) * c["W"] + 3 * (c["W"] // 2)),
+                                                   2 * ((c["D"] + 1) * c["W"] + 3 * (c["W"] // 2) + 160))}}
         except Exception as e:      # noqa: BLE001
             train_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
     cpu_baseline = None
-    if rank == 0 and args.cpu_seconds > 0:
-        from oracle import torch_oracle as to
-        oc = to.mlp_config(n_sem=N_SEM, n_inst=N_INST)
-        params = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
-                  "fine": {k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}}
+    if rank == 0 and (args.cpu_seconds > 0 or args.cpu1_seconds > 0):
         rays_c = rays.cpu()
-        stride = n_rays // 512
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
+        box_c, ids_c = (None, None) if box is None else (box.cpu(), ids.cpu())
 
-        def run(sub):
-            t0 = time.perf_counter()
-            r = to.render_rays(params, oc, sub, N_C, N_F, box=box, box_ids=ids)
-            return r, time.perf_counter() - t0
+        def leg(config, seconds, full_frame, prm):
+            v, done, t_cpu, best_n, avail, first = cpu_leg(config, prm, rays_c, box_c, ids_c, seconds, full_frame)
+            cc = synthetic.BASELINE_CONFIGS[config]
+            what = ("the first %d rays of the frame in 8192-ray chunks%s" % (done, " = the FULL frame" if done == n_rays else "")
+                    if full_frame else "%d rays of the same frame (every %d-th ray)" % (done, max(n_rays // 512, 1)))
+            return {"value": round(v, 4), "unit": "Msamples/s", "cores": best_n, "kind": "port",
+                    "sample": "%s, %s, fp32, oracle/torch_oracle.py, %.1f s, %d of %d host CPUs (fastest setting probed)"
+                              % (what, cc["name"], t_cpu, best_n, avail)}, first
 
-        # pick the thread count that is fastest on this host (all logical CPUs is often NOT: SMT +
-        # oversubscribed OpenMP teams), then spend the time budget at that setting
-        probe = rays_c[::stride][:256].contiguous()
-        best_n, best_t = 1, float("inf")
-        with torch.no_grad():
-            for n in sorted({min(c, avail) for c in (8, 16, 32, 64, 128, avail)}):
-                torch.set_num_threads(n)
-                run(probe[:64])
-                _, t = run(probe)
-                if t < best_t:
-                    best_n, best_t = n, t
-                if t > 20.0:
-                    break
-            torch.set_num_threads(best_n)
-            done, t_cpu, k = 0, 0.0, 0
-            psnr = None
-            while t_cpu < args.cpu_seconds and k < stride:
-                sub = rays_c[k::stride][:512].contiguous()
-                ref, t = run(sub)
-                t_cpu += t
-                done += sub.shape[0]
-                if k == 0:
-                    out = rend.render({"rays": sub[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)})
-                    mse = torch.mean((out["rgb_1"][0].cpu() - ref["rgb_1"]) ** 2).item()
-                    psnr = -10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item()
-                k += 1
-        cpu_val = done * (N_C + N_C + N_F) / t_cpu / 1e6
-        cpu_baseline = {"value": round(cpu_val, 4), "unit": "Msamples/s", "cores": torch.get_num_threads(),
-                        "kind": "port",
-                        "sample": "%d rays of the same frame (every %d-th ray), full coarse+fine path, fp32, "
-                                  "oracle/torch_oracle.py, %.1f s, %d of %d host CPUs (fastest setting probed)"
-                                  % (done, stride, t_cpu, best_n, avail)}
-        extra["psnr_db_hip_vs_oracle_fp32_render"] = None if psnr is None else round(psnr, 2)
+        if args.cpu_seconds > 0:
+            params = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
+                      "fine": {k: v.detach().cpu() for k, v in (net.nerf_1 or net.nerf_0).state_dict().items()}}
+            cpu_baseline, first = leg(args.config, args.cpu_seconds, args.config == 1, params)
+            if first is not None:
+                sub, ref = first
+                with torch.no_grad():
+                    out = rend.render(bdict(sub[None].to(dev)))
+                mse = torch.mean((out[f"rgb_{top}"][0].cpu() - ref[f"rgb_{top}"]) ** 2).item()
+                extra["psnr_db_hip_vs_oracle_fp32_render"] = round(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2)
+        if args.cpu1_seconds > 0 and args.config != 1:
+            # BASELINE configs[0], the reference's own CPU-runnable case (BASELINE.md's CPU-baseline plan): its own small network
+            from oracle import torch_oracle as to
+            c1 = synthetic.BASELINE_CONFIGS[1]
+            p1 = to.init_params(to.mlp_config(D=c1["D"], W=c1["W"], skips=tuple(c1["skips"])), seed=0, sigma_bias=0.03)
+            extra["cpu_baseline_config1"], _ = leg(1, args.cpu1_seconds, True, {"coarse": p1, "fine": p1})
 
     if rank == 0:
+        if strong:
+            par = "ONE frame, rays interleaved over %d rank(s); per-ray label maps + rgb + depth all-gathered (RCCL) inside the timed region" % world
+        else:
+            par = "one frame per rank, %d rank(s), no data-path collective" % world
         line = {"metric": "Msamples/sec (coarse+fine), KITTI-360 1408x376", "value": round(value, 2),
                 "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
                 "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                "config": {"workload": "BASELINE configs[4] per GPU: full panoptic (semantic %d + instance %d heads, "
-                                       "3D bbox prior), %dx%d frame, %d+%d samples/ray, 8x256 MLPs; one frame per rank"
-                                       % (N_SEM, N_INST, W_IMG, H_IMG, N_C, N_F),
-                           "rays_per_rank": n_rays, "samples_per_ray": N_C + N_C + N_F, "chunk_rays": args.chunk,
-                           "parallelism": "rays sharded, %d rank(s), no data-path collective" % world},
+                "config": {"workload": "BASELINE %s; %dx%d frame, %d%s samples/ray, %dx%d MLP%s, semantic %d / instance %d heads, bbox prior %s"
+                                       % (c["name"], W_IMG, H_IMG, N_C, "+%d" % N_F if N_F else "", c["D"], c["W"], "s" if N_F else "",
+                                          N_SEM, N_INST, "on" if c["bbox"] else "off"),
+                           "baseline_config": args.config, "rays_per_frame": n_rays, "frames_per_step": frames_per_step,
+                           "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "parallelism": par},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)
         if train_info is not None:

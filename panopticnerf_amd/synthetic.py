@@ -9,6 +9,31 @@ KITTI_W, KITTI_H = 1408, 376
 KITTI_F, KITTI_CX, KITTI_CY = 552.554261, 682.049453, 238.769549
 
 
+# BASELINE.json `configs` as renderer / network config keys (SURVEY.md 8d "config mapping").  `bbox`: whether the 3D
+# bbox prior is part of the workload.  C = 45 / K = 32 are this build's choices (the reference's are unverifiable,
+# SURVEY.md 9 item 8); every consumer prints what it used.
+BASELINE_CONFIGS = {
+    1: dict(name="configs[0]: coarse-only 32 samples/ray, 4x128 MLP, appearance only",
+            N_samples=32, N_importance=0, D=4, W=128, skips=[4], num_classes=0, num_instances=0, bbox=False),
+    2: dict(name="configs[1]: coarse-only 64 samples/ray, 8x256 MLP, appearance only",
+            N_samples=64, N_importance=0, D=8, W=256, skips=[4], num_classes=0, num_instances=0, bbox=False),
+    3: dict(name="configs[2]: coarse+fine 64+128 (sample_pdf), 8x256 MLPs, appearance + depth",
+            N_samples=64, N_importance=128, D=8, W=256, skips=[4], num_classes=0, num_instances=0, bbox=False),
+    4: dict(name="configs[3]: + semantic head 45 (3D bbox prior + learned), panoptic logit compositing",
+            N_samples=64, N_importance=128, D=8, W=256, skips=[4], num_classes=45, num_instances=0, bbox=True),
+    5: dict(name="configs[4]: full panoptic (semantic 45 + instance 32 heads, 3D bbox prior)",
+            N_samples=64, N_importance=128, D=8, W=256, skips=[4], num_classes=45, num_instances=32, bbox=True),
+}
+
+
+def baseline_cfg(n, **extra):
+    """BASELINE config n (1..5) as an attribute-style cfg for make_network / make_renderer (+ overrides)."""
+    from types import SimpleNamespace
+    d = {k: v for k, v in BASELINE_CONFIGS[n].items() if k not in ("name", "bbox")}
+    d.update(extra)
+    return SimpleNamespace(**d)
+
+
 def camera_rays(width=KITTI_W, height=KITTI_H, yaw=0.0, origin=(0.0, 1.55, 0.0), near=0.5, far=100.0):
     """(H*W, 8) rays: o(3), d(3) (unnormalised pixel directions, z forward), near, far."""
     j, i = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32),

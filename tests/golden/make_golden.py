@@ -99,6 +99,42 @@ def main():
         g["e2e_" + k] = e2e[k].numpy()
     np.savez_compressed(os.path.join(HERE, "path_small.npz"), **g)
     print("wrote", os.path.join(HERE, "path_small.npz"), sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
+    make_configs()
+
+
+def config_case(n, R=24):
+    """Inputs of the per-config end-to-end fixture: (oracle MLP config, params, rays, box, ids).  Shared with
+    tests/test_gpu_configs.py so that the test renders exactly what the fixture holds."""
+    from panopticnerf_amd import synthetic
+    c = synthetic.BASELINE_CONFIGS[n]
+    oc = to.mlp_config(D=c["D"], W=c["W"], skips=tuple(c["skips"]), n_sem=c["num_classes"], n_inst=c["num_instances"],
+                       head_W=c["W"] // 2)
+    params = {"coarse": to.init_params(oc, seed=10 + n, sigma_bias=0.05), "fine": to.init_params(oc, seed=20 + n, sigma_bias=0.05)}
+    rays = synthetic.camera_rays()[(7 * n) :: (1408 * 376) // R][:R].contiguous()
+    box = ids = None
+    if c["bbox"]:
+        box, ids = synthetic.random_boxes(48, max(c["num_classes"], 1), max(c["num_instances"], 1), seed=30 + n)
+    return c, oc, params, rays, box, ids
+
+
+def make_configs():
+    """tests/golden/configs.npz: one small end-to-end render (torch fp32 oracle) per BASELINE.json config 1..5."""
+    g = {}
+    for n in range(1, 6):
+        c, oc, params, rays, box, ids = config_case(n)
+        out = to.render_rays(params, oc, rays, c["N_samples"], c["N_importance"], box=box, box_ids=ids)
+        lv = 1 if c["N_importance"] else 0
+        keys = [f"{k}_{l}" for l in range(lv + 1) for k in ("rgb", "depth", "acc")]
+        if c["num_classes"]:
+            keys += [f"semantic_{lv}"] + ([f"fix_semantic_{lv}"] if c["bbox"] else [])
+        if c["num_instances"]:
+            keys += [f"instance_{lv}"] + ([f"fix_instance_{lv}"] if c["bbox"] else [])
+        keys.append(f"z_vals_{lv}")
+        for k in keys:
+            g[f"c{n}_{k}"] = out[k].numpy()
+        g[f"c{n}_keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(HERE, "configs.npz"), **g)
+    print("wrote", os.path.join(HERE, "configs.npz"), sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
 
 
 if __name__ == "__main__":

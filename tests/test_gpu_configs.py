@@ -1,0 +1,122 @@
+"""BASELINE.json configs 1..5 rendered END TO END through make_network / make_renderer:
+coarse-only 32-sample 4x128, coarse-only 64-sample 8x256, coarse+fine without heads, + semantic head and bbox prior,
+full panoptic -- each against (a) the committed per-config fixture tests/golden/configs.npz (an independent fp32
+oracle run), (b) the oracle evaluated on the HIP path's own z (identical stage inputs: 1e-4 in fp32-MFMA mode, 1e-2 in
+bf16 mode against the bf16-emulating oracle), (c) the strict-order C oracle for z, bit for bit; then at BASELINE's
+full-frame size through size-independent properties."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import torch_oracle as to
+from panopticnerf_amd import make_network, make_renderer, synthetic
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden import config_case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg_golden():
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "configs.npz")))
+
+
+def _build(n, prec, dev, **extra):
+    c, oc, params, rays, box, ids = config_case(n)
+    cfg = synthetic.baseline_cfg(n, precision=prec, **extra)
+    net = make_network(cfg).eval()
+    net.nerf_0.load_state_dict(params["coarse"])
+    if c["N_importance"]:
+        net.nerf_1.load_state_dict(params["fine"])
+    else:
+        assert net.nerf_1 is None
+    return c, oc, params, rays, box, ids, cfg, make_renderer(cfg, net.to(dev))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+def test_render_baseline_configs(dev, cfg_golden, n, prec):
+    c, oc, params, rays, box, ids, cfg, rend = _build(n, prec, dev, chunk_size=16)       # 24 rays: two chunks, one ragged
+    batch = {"rays": rays[None].to(dev)}
+    if c["bbox"]:
+        batch.update(bbox=box.to(dev), bbox_ids=ids.to(dev))
+    with torch.no_grad():
+        out = rend.render(batch)
+    top = 1 if c["N_importance"] else 0
+    C, K = c["num_classes"], c["num_instances"]
+    # the key set says which parts of the path ran
+    assert ("rgb_1" in out) == bool(c["N_importance"]) and ("semantic_0" in out) == bool(C) and ("instance_0" in out) == bool(K)
+    assert ("fix_semantic_0" in out) == bool(C and c["bbox"]) and ("fix_instance_0" in out) == bool(K and c["bbox"])
+    assert out[f"z_vals_{top}"].shape == (1, 24, c["N_samples"] + c["N_importance"])
+    # (c) z: strict-order oracle, bit for bit (z_1 given the HIP coarse weights)
+    z0 = out["z_vals_0"][0].cpu().numpy()
+    assert np.array_equal(z0, co.stratified(rays.numpy(), c["N_samples"]))
+    if top:
+        zs, _ = co.sample_pdf(z0, out["weights_0"][0].cpu().numpy(), c["N_importance"])
+        assert np.array_equal(out["z_vals_1"][0].cpu().numpy(), co.merge_sorted(z0, zs))
+    # (a) committed fixture (independent end-to-end fp32 run of the torch oracle: PE-amplified tolerance, see test_gpu_render)
+    if prec == "fp32":
+        for k in cfg_golden[f"c{n}_keys"]:
+            tol = 5e-2 if k.startswith(("depth", "z_vals")) else 1e-2
+            np.testing.assert_allclose(out[str(k)][0].cpu().numpy(), cfg_golden[f"c{n}_{k}"], atol=tol, rtol=0, err_msg=f"config {n} {k}")
+    # (b) identical stage inputs
+    hits = co.bbox_hits(rays.numpy(), box.numpy(), 8) if c["bbox"] else None
+    for lv in range(top + 1):
+        z = out[f"z_vals_{lv}"][0].cpu()
+        raw = to.run_network(params["coarse" if lv == 0 else "fine"], oc, rays, z, emulate_bf16=(prec == "bf16"))
+        ls = li = None
+        if hits is not None:
+            ls, li = (torch.tensor(a) for a in co.sample_labels(z.numpy(), *hits, ids.numpy()))
+        want = to.raw2outputs(raw, z, rays[:, 3:6], C, K, None, ls, li)
+        # bf16: the last sample's 1e10 interval makes alpha_last a step function of sign(sigma_last); a ray whose
+        # sigma_last sits within bf16 noise of zero may flip -- such rays are judged in fp32 mode only
+        ok = torch.ones(24, dtype=torch.bool) if prec == "fp32" else raw[:, -1, 3].abs() > 2e-2
+        assert ok.sum() >= 16
+        tol = 1e-4 if prec == "fp32" else 1e-2
+        for k in ("rgb", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance"):
+            if f"{k}_{lv}" in out:
+                err = (out[f"{k}_{lv}"][0].cpu() - want[k])[ok].abs().max().item()
+                assert err < tol, (n, prec, k, lv, err)
+        derr = (out[f"depth_{lv}"][0].cpu() - want["depth"])[ok].abs().max().item()
+        assert derr < (1e-4 if prec == "fp32" else 1e-2) * 100.0, (n, prec, "depth", lv, derr)     # metres, far = 100
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_baseline_config_full_frame_properties(dev, n):
+    """Configs 1..4 at the size BASELINE quotes (one 1408x376 frame), bf16 (config 5: test_gpu_render.py)."""
+    c, oc, params, _, box, ids, cfg, rend = _build(n, "bf16", dev)
+    rays = synthetic.camera_rays()
+    batch = {"rays": rays.reshape(376, 1408, 8).to(dev)}
+    if c["bbox"]:
+        batch.update(bbox=box.to(dev), bbox_ids=ids.to(dev))
+    with torch.no_grad():
+        out = rend.render(batch)
+    top = 1 if c["N_importance"] else 0
+    assert out[f"rgb_{top}"].shape == (376, 1408, 3)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    for lv in range(top + 1):
+        w = out[f"weights_{lv}"]
+        assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-4).all() and torch.allclose(out[f"acc_{lv}"], w.sum(-1), atol=1e-4)
+        z = out[f"z_vals_{lv}"]
+        assert (z[..., 1:] >= z[..., :-1]).all() and z.min() >= 0.5 and z.max() <= 100.0
+        assert (out[f"rgb_{lv}"] >= 0).all() and (out[f"rgb_{lv}"] <= 1 + 1e-5).all()
+    # chunk independence: a ray subset rendered alone gives the same maps, bit for bit
+    idx = torch.arange(5, 376 * 1408, 2311)
+    sb = {"rays": rays[idx][None].to(dev)}
+    if c["bbox"]:
+        sb.update(bbox=box.to(dev), bbox_ids=ids.to(dev))
+    with torch.no_grad():
+        sub = rend.render(sb)
+    for k in out:
+        a = out[k].reshape(-1, *out[k].shape[2:])[idx.to(dev)]
+        assert torch.equal(a, sub[k][0]), (n, k)
+    # the subset agrees with the bf16-emulating oracle where it can afford to run
+    want = to.render_rays(params, oc, rays[idx], c["N_samples"], c["N_importance"], box=box, box_ids=ids, emulate_bf16=True)
+    e = (sub[f"rgb_{top}"][0].cpu() - want[f"rgb_{top}"]).abs()
+    assert torch.quantile(e.flatten(), 0.95) < 1e-2, (n, e.max())
