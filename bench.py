@@ -76,18 +76,31 @@ def traffic(kernel, n_rays_launch, config):
         return None
 
 
-def make_train_batch(rays, box, ids, n_rays, C, K, dev, seed):
+def make_train_batch(cfg, rays, box, ids, n_rays, C, K, dev, seed):
+    """A training batch whose targets are LEARNABLE: a teacher network (same architecture, different seed) renders the
+    batch's rays; its fine-level colour / depth are the rgb / stereo-depth targets and the argmax of its composited
+    logits the 2D pseudo labels.  (Round 1 used uniform-random targets: nothing to learn, the loss of a fixed batch
+    wandered upwards.)"""
+    from panopticnerf_amd import make_network, make_renderer, synthetic
     g = torch.Generator(device=dev).manual_seed(seed)
     idx = torch.randint(0, rays.shape[0], (n_rays,), generator=g, device=dev)
-    tb = {"rays": rays[idx][None].contiguous(),
-          "rgb": torch.rand((1, n_rays, 3), generator=g, device=dev),
-          "depth": torch.rand((1, n_rays), generator=g, device=dev) * 60.0 - 10.0}     # <= 0: no stereo depth
+    tb = {"rays": rays[idx][None].contiguous()}
     if box is not None:
         tb.update(bbox=box, bbox_ids=ids)
+    state = torch.random.get_rng_state()
+    torch.manual_seed(1234)
+    teacher = make_network(cfg).eval()
+    torch.random.set_rng_state(state)
+    synthetic.trained_like_(teacher, 0.06)
+    with torch.no_grad():
+        t = make_renderer(cfg, teacher.to(dev)).render(tb)
+    top = 1 if "rgb_1" in t else 0
+    tb["rgb"] = t[f"rgb_{top}"].clone()
+    tb["depth"] = t[f"depth_{top}"].clone()
     if C:
-        tb["pseudo_label"] = torch.randint(-1, C, (1, n_rays), generator=g, device=dev)
+        tb["pseudo_label"] = t[f"semantic_{top}"].argmax(-1).int()
     if K:
-        tb["instance_label"] = torch.randint(-1, K, (1, n_rays), generator=g, device=dev)
+        tb["instance_label"] = t[f"instance_{top}"].argmax(-1).int()
     return tb
 
 
@@ -109,7 +122,7 @@ def graph_step_child(args):
     box = ids = None
     if c["bbox"]:
         box, ids = (t.to(dev) for t in synthetic.random_boxes(64, c["num_classes"], max(c["num_instances"], 1)))
-    tb = make_train_batch(rays, box, ids, args.train_rays, c["num_classes"], c["num_instances"], dev, 0)
+    tb = make_train_batch(cfg, rays, box, ids, args.train_rays, c["num_classes"], c["num_instances"], dev, 0)
 
     def step():
         opt.zero_grad(set_to_none=False)
@@ -373,7 +386,7 @@ def main():
             synthetic.trained_like_(tnet)
             wrap = NetworkWrapper(tnet, cfg)       # the trainer's loss wrapper: render + fused losses
             opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
-            tb = make_train_batch(rays, box, ids, args.train_rays, N_SEM, N_INST, dev, rank)
+            tb = make_train_batch(cfg, rays, box, ids, args.train_rays, N_SEM, N_INST, dev, rank)
 
             def step(reduce=True):
                 opt.zero_grad(set_to_none=True)
