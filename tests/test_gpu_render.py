@@ -184,3 +184,36 @@ def test_render_chunk_is_graph_capturable(dev):
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
     assert not torch.equal(got["rgb_1"], rend.render_rays(rays_a, box, ids)["rgb_1"])      # it really re-ran on the new rays
+
+
+def test_reference_checkpoint_loads_packs_and_renders(dev, tmp_path):
+    """SURVEY 8f-3 on the GPU: a reference-style checkpoint file ({'net': state_dict with wrapper
+    prefixes / alternative names, 'epoch': ...}) -> load_reference_state_dict on a GPU-resident network -> the packed MFMA
+    images are rebuilt -> the render equals the source network's render bit for bit (and differs from the render before
+    the load: the stale packed image was dropped)."""
+    C, K = 6, 4
+    cfg, src, _, _ = _setup(dev, C, K, "bf16", seeds=(11, 12))
+    ren = lambda k: "module.net." + k.replace("nerf_0.", "coarse.").replace("nerf_1.", "fine.").replace("alpha_linear", "sigma_linear")
+    path = tmp_path / "latest.pth"
+    torch.save({"net": {ren(k): v.detach().cpu() for k, v in src.state_dict().items()}, "epoch": 7}, path)
+    rays = synthetic.camera_rays()[::2311][:200].contiguous().to(dev)
+    box, ids = synthetic.random_boxes(16, C, K)
+    batch = {"rays": rays[None], "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    dst = make_network(cfg).to(dev).eval()
+    rend = make_renderer(cfg, dst)
+    with torch.no_grad():
+        before = rend.render(batch)                                  # packs dst's random initialisation
+        rep = dst.load_reference_state_dict(torch.load(path, map_location="cpu")["net"])
+        assert not rep["missing"] and not rep["unexpected"]
+        after = rend.render(batch)
+        want = make_renderer(cfg, src).render(batch)
+    assert not torch.equal(before["rgb_1"], after["rgb_1"])
+    for k in want:
+        assert torch.equal(after[k], want[k]), k
+    # a .data write (no version bump) is picked up after invalidate_packed()
+    with torch.no_grad():
+        dst.nerf_1.rgb_linear.bias.data.add_(0.5)
+        stale = rend.render(batch)
+        dst.invalidate_packed()
+        fresh = rend.render(batch)
+    assert torch.equal(stale["rgb_1"], after["rgb_1"]) and not torch.equal(fresh["rgb_1"], after["rgb_1"])
