@@ -66,7 +66,7 @@ def trained_like_(net, sigma_bias=0.03, seed=0):
     """Shift the density bias so a useful fraction of samples has alpha > 0 (a freshly
     initialised NeRF composites to almost nothing)."""
     with torch.no_grad():
-        for lv in (0, 1):
-            n = net.nerf(lv)
-            n.alpha_linear.bias.fill_(sigma_bias)
+        for n in (net.nerf_0, net.nerf_1):
+            if n is not None:
+                n.alpha_linear.bias.fill_(sigma_bias)
     return net
