@@ -78,7 +78,10 @@ def test_training_converges_like_the_oracle(dev):
         hip_eval = make_renderer(cfg, net.eval()).render({"rays": held[None].to(dev)})
     psnr_hip = _psnr(hip_eval["rgb_1"][0].cpu(), t_held["rgb_1"])
 
-    # ---- oracle student: same init, same batches, fp32 torch autograd on the CPU
+    # ---- oracle student: same init, same batches, fp32 torch autograd on the CPU (a few threads: the GEMMs are small, and
+    # an OpenMP team over all 256 logical CPUs of the GPU host is several times slower than 16 threads)
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(16, n_thr))
     prm = {lv: {k: v.clone().requires_grad_(True) for k, v in init[lv].items()} for lv in ("coarse", "fine")}
     opt_o = torch.optim.Adam([p for d in prm.values() for p in d.values()], lr=LR)
     ora_losses = []
@@ -92,6 +95,7 @@ def test_training_converges_like_the_oracle(dev):
     with torch.no_grad():
         ora_eval = to.render_rays({lv: {k: v.detach() for k, v in d.items()} for lv, d in prm.items()}, oc, held, NC, NF)
     psnr_ora = _psnr(ora_eval["rgb_1"], t_held["rgb_1"])
+    torch.set_num_threads(n_thr)
 
     first, last = np.mean(hip_losses[:10]), np.mean(hip_losses[-10:])
     print(f"convergence: HIP loss {first:.5f} -> {last:.5f}; oracle loss {np.mean(ora_losses[:10]):.5f} -> {np.mean(ora_losses[-10:]):.5f}; "
