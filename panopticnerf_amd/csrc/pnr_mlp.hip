@@ -27,6 +27,7 @@
 // (-3 %), one wave per SIMD with 1 or 2 tiles (-30 %), two 4-wave workgroups per CU (-10 %), 4 blocks per hidden
 // chunk (-2 %), a phase-split weight stream (half the waves join each chunk's barrier mid-loop, 3 slots: -7..-9 %).
 // Debug: -DPNR_TRACE=1 builds stamp s_memtime per chunk phase into LDS (tools/mlp_trace.py).
+#include <stdlib.h>
 #include <string.h>
 
 #include "pnr_mlp_plan.h"
@@ -34,8 +35,12 @@
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
+#include "pnr_mlp_pp.h"
 #ifndef PNR_OPT_EAGER_EPI
 #define PNR_OPT_EAGER_EPI 1
+#endif
+#ifndef PNR_PP_UNROLL2
+#define PNR_PP_UNROLL2 0     /* two trunk layers per loop trip (no hand-over copies): -2 % measured (code size) */
 #endif
 // Hidden layer: inputs = up to two register segments, output -> registers (next B operand).
 // save != nullptr (training, bf16): the output block is also stored slot-ordered for the backward.
@@ -310,6 +315,229 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------- ping-pong form (pnr_mlp_pp.h)
+// Same arithmetic, same packed image, same register-resident activations as k_mlp_fused<bf16, W, 1 tile, 8 waves>;
+// only the time structure of the weight stream differs (two wave groups in phase opposition, 3 LDS slots).
+template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
+__device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
+                                              const uint32_t (&inB)[NB > 0 ? NB : 1], uint32_t (&out)[NOUT],
+                                              uint16_t* save, int samp)
+{
+    constexpr int FBC0 = pnr_layer_fbc(KIND, PNR_PREC_BF16);
+    constexpr int FBC = (NFB_OUT % FBC0 == 0) ? FBC0 : 1;      // mirrors pnr_build_plan
+    using CH = PPChunk<FBC, NA, NB>;
+    static_assert(NOUT >= NFB_OUT * 8, "output register array too small");
+    f32x4 q[FBC][4];                                            // bias quads in flight across the chunk boundary
+#pragma unroll
+    for (int cb = 0; cb < NFB_OUT / FBC; ++cb) {
+        // L of chunk cb, last part.  For the layer's 2nd, 3rd, ... chunk the first fragments and the bias were already
+        // requested (below) in the shadow of the previous chunk's refill / epilogue; only the drain is left.
+        if (cb == 0 || !PNR_PP_EARLY) CH::first_frags(c.frag_addr(), A);
+        if (cb == 0 || !PNR_PP_EARLY_BIAS) CH::bias_issue(c.bias_addr(), q);
+        f32x16 acc[FBC];
+        CH::bias_finish(q, acc);                                // waits for every LDS read of the phase
+        c.barrier();                                            // L -> M
+        c.stamp(2);
+        CH::mma(c.frag_addr(), A, inA, inB, acc);
+        c.m_done();                                             // M -> L of the next chunk; own refill pieces landed
+        const bool nxt_same = cb + 1 < NFB_OUT / FBC;           // the next chunk has this chunk's shape
+        if (PNR_PP_EARLY && nxt_same) CH::first_frags(c.next_frag_addr(), A);
+        c.refill_begin();
+#pragma unroll
+        for (int b = 0; b < FBC; ++b) {
+            c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
+            const int fb = cb * FBC + b;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                uint32_t v = pack_bf16(acc[b][2 * p], acc[b][2 * p + 1]);
+                if (MODE == MODE_RELU) v = relu_bf16x2(v);
+                asm volatile("" : "+v"(v));
+                out[fb * 8 + p] = v;
+            }
+            if (save) store_slots(save, NFB_OUT * 32, samp, fb, c.hi, &out[fb * 8]);
+        }
+        if (PNR_PP_EARLY_BIAS && nxt_same) CH::bias_issue(c.next_bias_addr(), q);   // accumulators free: next chunk's bias, asynchronous
+        c.refill_rest();
+        c.advance();
+    }
+}
+
+template <class CTX, int NA, int NB>
+__device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
+                                             const uint32_t (&inB)[NB > 0 ? NB : 1], int n_out, int ch_base, int samp)
+{
+    using CH = PPChunk<1, NA, NB>;
+    const int nfb = (n_out + 31) >> 5;
+#pragma unroll 1
+    for (int fb = 0; fb < nfb; ++fb) {
+        f32x16 acc[1];
+        CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
+        c.barrier();
+        c.stamp(2);
+        CH::mma(c.frag_addr(), A, inA, inB, acc);
+        c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
+        c.refill_begin();
+        c.refill_one();
+        if (samp >= 0) {
+            float* dst = c.a.raw + (int64_t)samp * c.a.ss;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = fb * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.hi;
+                if (row < n_out) dst[(int64_t)(ch_base + row) * c.a.sc] = acc[0][r];
+            }
+        }
+        c.refill_rest();
+        c.advance();
+    }
+}
+
+template <int W, bool TRAIN>
+__global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
+{
+    constexpr int WAVES = 8;
+    using CTX = CtxPP<WAVES>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NFB = W / 32, HFB = W / 64;
+    constexpr int HR = NFB * 8, GR = HFB * 8, GXR = 16, GDR = 8;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    CTX c{a, smem, (int)(threadIdx.x & 63), wave, (int)((threadIdx.x & 63) >> 5), wave >= WAVES / 2 ? 1 : 0, 0, 0, 0u, 0u, {0, 0}};
+#if PNR_TRACE
+    c.tr = reinterpret_cast<unsigned long long*>(smem + 3 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.titer = 0;
+#endif
+    const int n = c.lane & 31;
+    c.start();
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (a.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    uint32_t dummy[1] = {0};
+    u32x4 A[CTX::P];
+    struct SampleIn { float4 o4, d4; float zz; };
+    auto fetch = [&](int grp) {
+        const int s = (grp * WAVES + c.wave) * 32 + n;
+        const int sl = s < a.S ? s : a.S - 1;
+        const int ray = sl / a.N;
+        SampleIn in;
+        in.o4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8);
+        in.d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
+        in.zz = a.z[sl];
+        return in;
+    };
+    SampleIn nextin = fetch(blockIdx.x < a.n_groups ? blockIdx.x : 0);
+
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        const int s0 = (grp * WAVES + c.wave) * 32 + n;
+        const int samp = s0 < a.S ? s0 : -1;
+        float vd[3];
+        uint32_t ex[GXR];
+        {
+            const float4 o4 = nextin.o4, d4 = nextin.d4;
+            const float zz = nextin.zz;
+            const float dx = o4.w, dy = d4.x, dz = d4.y;
+            const float px = __fadd_rn(o4.x, __fmul_rn(dx, zz));
+            const float py = __fadd_rn(o4.y, __fmul_rn(dy, zz));
+            const float pz = __fadd_rn(o4.z, __fmul_rn(dz, zz));
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            vd[0] = dx / nrm; vd[1] = dy / nrm; vd[2] = dz / nrm;
+            embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
+            if constexpr (TRAIN) {
+                if (samp >= 0) {   // EX: [S][64], slot = hi*32 + v
+                    u32x4* p = reinterpret_cast<u32x4*>(a.acts + a.acts_off[0] + (size_t)samp * 64 + c.hi * 32);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { u32x4 v; v[0] = ex[4 * k]; v[1] = ex[4 * k + 1]; v[2] = ex[4 * k + 2]; v[3] = ex[4 * k + 3]; p[k] = v; }
+                }
+            }
+        }
+        auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
+
+        uint32_t cur[HR], nxt[HR];
+        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), samp);
+        auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
+            if (l - 1 == a.skip)
+                pp_layer_regs<CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, A, ex, in, out, sv(2 + l), samp);
+            else
+                pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, A, in, dummy, out, sv(2 + l), samp);
+        };
+#if PNR_PP_UNROLL2
+        // two layers per trip, cur -> nxt -> cur: no 64-register hand-over copy per layer (it sat in the L phase of every
+        // layer's first chunk); one copy per sample group remains when D-1 is odd
+#pragma unroll 1
+        for (int l = 1; l < a.D; l += 2) {
+            trunk(l, cur, nxt);
+            if (l + 1 < a.D) trunk(l + 1, nxt, cur);
+            else {
+#pragma unroll
+                for (int i = 0; i < HR; ++i) cur[i] = nxt[i];
+            }
+        }
+#else
+#pragma unroll 1
+        for (int l = 1; l < a.D; ++l) {
+            trunk(l, cur, nxt);
+#pragma unroll
+            for (int i = 0; i < HR; ++i) cur[i] = nxt[i];
+        }
+#endif
+        if (a.n_sem) {
+            uint32_t sh[GR];
+            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), samp);
+            pp_layer_out<CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
+        }
+        if (a.n_inst) {
+            uint32_t sh[GR];
+            pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), samp);
+            pp_layer_out<CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+        }
+        {
+            const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
+            nextin = fetch(g2);
+        }
+        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), samp);
+        uint32_t ed[GDR];
+        embed_lane<PNR_PREC_BF16, 2, 16, GDR>(vd[0], vd[1], vd[2], c.hi, ed);
+        if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp, 0, c.hi, ed);   // ED: [S][32]
+        uint32_t g[GR];
+        pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), samp);
+        pp_layer_out<CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
+#if PNR_TRACE
+        ++c.titer;
+#endif
+    }
+    c.end();
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#if PNR_TRACE
+    __syncthreads();
+    if (blockIdx.x == 0 && a.trace) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes);
+        for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
+    }
+#endif
+}
+
+template <int W, bool TRAIN>
+static int launch_mlp_pp(const MlpArgs& a0, hipStream_t stream)
+{
+    MlpArgs a = a0;
+    const int lds_bytes = 3 * a.slot_bytes + (PNR_TRACE ? 8 * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
+    PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_forward: three weight slots of %d bytes exceed the 160 KiB LDS", a.slot_bytes);
+    PNR_REQUIRE(a.n_chunks >= 4, "pnr_mlp_forward: network too small for the weight stream");
+    a.n_groups = (a.S + 255) / 256;
+    auto kern = k_mlp_pp<W, TRAIN>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        attr_set = true;
+    }
+    const int cap = pnr_cu_count();           // one 8-wave workgroup per CU (2 x 256 registers per SIMD)
+    const int grid = a.n_groups < cap ? a.n_groups : cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, a);
+    PNR_CHECK_LAUNCH("pnr_mlp_forward");
+    return PNR_OK;
+}
+
 // ------------------------------------------------------------------------------- launcher
 template <int PREC, int W, int TILES, int WAVES, int MINW, bool TRAIN = false>
 static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
@@ -334,6 +562,20 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
     PNR_CHECK_LAUNCH("pnr_mlp_forward");
     return PNR_OK;
+}
+
+// PNR_MLP_VARIANT (A/B builds and tools only): 0 = lock-step double buffer, 1 = ping-pong (default: PNR_MLP_DEFAULT_VARIANT)
+#ifndef PNR_MLP_DEFAULT_VARIANT
+#define PNR_MLP_DEFAULT_VARIANT 1
+#endif
+static int mlp_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PNR_MLP_VARIANT");
+        v = e ? atoi(e) : PNR_MLP_DEFAULT_VARIANT;
+    }
+    return v;
 }
 
 static thread_local unsigned long long* g_clk_buf = nullptr;     // set by pnr_time_mlp_forward_clk around its launches
@@ -373,6 +615,10 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
     // fp32 parity mode: 4 waves x 1 tile, one wave per SIMD (its activations need ~300 registers)
     if (desc->precision == PNR_PREC_BF16) {
+        if (mlp_variant() == 1) {              // ping-pong form (pnr_mlp_pp.h)
+            if (acts) return desc->W == 256 ? launch_mlp_pp<256, true>(a, st) : launch_mlp_pp<128, true>(a, st);
+            return desc->W == 256 ? launch_mlp_pp<256, false>(a, st) : launch_mlp_pp<128, false>(a, st);
+        }
         if (acts)
             return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2, true>(a, st)
                                   : launch_mlp<PNR_PREC_BF16, 128, 1, 8, 2, true>(a, st);

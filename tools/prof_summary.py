@@ -15,10 +15,10 @@ def kernel_stats(path):
         print(f"{r[0][:72]:72s} {r[1]:6d} {r[2] / 1e6:10.3f} {100 * r[2] / tot:6.2f} {r[3] / 1e3:10.1f} {r[4] / 1e3:10.1f} {r[5] / 1e3:10.1f}")
     # the bench's dominant launch: fine-level MLP chunks are the longest k_mlp_fused dispatches
     big = cur.execute("select (end-start)/1e3, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                      "from kernels where name like '%k_mlp_fused%' order by 1 desc").fetchall()
+                      "from kernels where (name like '%k_mlp_fused%' or name like '%k_mlp_pp%') order by 1 desc").fetchall()
     if big:
         top = [b for b in big if b[0] > 0.7 * big[0][0]]
-        print(f"k_mlp_fused fine-level chunk launches (>70% of longest): n={len(top)} avg={sum(b[0] for b in top) / len(top):.1f} us "
+        print(f"fused MLP fine-level chunk launches (>70% of longest): n={len(top)} avg={sum(b[0] for b in top) / len(top):.1f} us "
               f"grid={big[0][1]} wg={big[0][2]} vgpr={big[0][3]} agpr={big[0][4]} sgpr={big[0][5]} lds={big[0][6]} scratch={big[0][7]}")
     print()
 
