@@ -284,6 +284,11 @@ int pnr_probe_mfma_peak(int random_operands, int iters, void* scratch, float* tf
  * channel-major raw image, per wave the 8 channel rows of a batch of one ray, 8 loads in flight.  scratch: >= 1 KiB. */
 int pnr_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,
                        void* scratch, float* gbs_out_host, void* stream);
+/* Time structure of the fused bf16 MLP's weight stream (tests and A/B tools only; the arithmetic, the packed image and
+ * the results are identical bit for bit): 0 = lock-step double buffer (k_mlp_fused), 1 = ping-pong (k_mlp_pp) for
+ * inference launches [default], 2 = ping-pong for the training forward as well.  Returns the previous value; a negative
+ * argument only queries.  The environment variable PNR_MLP_VARIANT sets the initial value. */
+int pnr_mlp_set_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ SIGNATURES = {
                                          c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_probe_mfma_peak": (c_int, [c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), c_f]),
+    "pnr_mlp_set_variant": (c_int, [c_int]),
 }
 
 _lib = None

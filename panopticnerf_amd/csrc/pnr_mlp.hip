@@ -568,14 +568,20 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
 #ifndef PNR_MLP_DEFAULT_VARIANT
 #define PNR_MLP_DEFAULT_VARIANT 1
 #endif
+static int g_mlp_variant = -1;
 static int mlp_variant()
 {
-    static int v = -1;
-    if (v < 0) {
+    if (g_mlp_variant < 0) {
         const char* e = getenv("PNR_MLP_VARIANT");
-        v = e ? atoi(e) : PNR_MLP_DEFAULT_VARIANT;
+        g_mlp_variant = e ? atoi(e) : PNR_MLP_DEFAULT_VARIANT;
     }
-    return v;
+    return g_mlp_variant;
+}
+PNR_EXPORT int pnr_mlp_set_variant(int variant)
+{
+    const int prev = mlp_variant();
+    if (variant >= 0 && variant <= 2) g_mlp_variant = variant;
+    return prev;
 }
 
 static thread_local unsigned long long* g_clk_buf = nullptr;     // set by pnr_time_mlp_forward_clk around its launches
@@ -615,10 +621,11 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
     // fp32 parity mode: 4 waves x 1 tile, one wave per SIMD (its activations need ~300 registers)
     if (desc->precision == PNR_PREC_BF16) {
-        if (mlp_variant() == 1) {              // ping-pong form (pnr_mlp_pp.h)
-            if (acts) return desc->W == 256 ? launch_mlp_pp<256, true>(a, st) : launch_mlp_pp<128, true>(a, st);
+        // ping-pong form (pnr_mlp_pp.h): variant 1 = inference launches, 2 = the training forward as well
+        if (mlp_variant() >= 1 && !acts)
             return desc->W == 256 ? launch_mlp_pp<256, false>(a, st) : launch_mlp_pp<128, false>(a, st);
-        }
+        if (mlp_variant() == 2 && acts)
+            return desc->W == 256 ? launch_mlp_pp<256, true>(a, st) : launch_mlp_pp<128, true>(a, st);
         if (acts)
             return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2, true>(a, st)
                                   : launch_mlp<PNR_PREC_BF16, 128, 1, 8, 2, true>(a, st);

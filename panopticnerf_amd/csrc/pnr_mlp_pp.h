@@ -16,8 +16,9 @@
 // LDS: THREE weight slots (chunk c lives from phase 2c-1, when P reads its bias, to 2c+1, when Q
 // finishes its MFMAs).  In L(k), P refills its share of chunk k+1 and Q its share of chunk k+2 -- the
 // slot of chunk k-2 / k-1, whose last reader passed the previous barrier -- and each wave waits for
-// its own pieces (vmcnt(0)) at the START of its next L, two phases later, so no phase ever waits for
-// a copy issued inside it.  Both groups execute the same code; Q is simply one barrier behind.
+// its own pieces (vmcnt(0)) at the END of its next M, almost two phases later and BEFORE that phase's
+// barrier: no phase ever waits for a copy issued inside it, and every piece is covered by its issuer's
+// wait plus a barrier before any wave reads it.  Both groups execute the same code; Q is one barrier behind.
 // Order inside L(k+1), which starts when M(k) ends: refill pieces INTERLEAVED with the epilogue of
 // chunk k (a wave blocks 100-200 cycles per 1 KiB LDS-DMA piece while the CU's queue is full; the
 // pack/ReLU VALU work runs in those gaps), then bias + first fragments of chunk k+1, then the barrier.
@@ -159,15 +160,19 @@ struct CtxPP {
     __device__ __forceinline__ uint32_t bias_addr() const { return lds_bias + slot_off; }
     __device__ __forceinline__ uint32_t next_frag_addr() const { return lds_frag + wrap_slot(slot_off + a.slot_bytes); }
     __device__ __forceinline__ uint32_t next_bias_addr() const { return lds_bias + wrap_slot(slot_off + a.slot_bytes); }
-    // After the chunk's MFMAs: close the M phase.  The L phase of the NEXT chunk starts here: this wave's refill pieces
-    // of two phases ago have landed (vmcnt(0) never waits for a copy issued in the running phase).
+    // After the chunk's MFMAs: close the M phase.  BEFORE the barrier this wave waits for its own refill pieces (issued at
+    // the start of its previous L, ~2 phases ago: landed long since, the wait is free) -- so that every piece is covered by
+    // its issuer's vmcnt(0) AND a barrier before anybody reads it, including the other waves of the issuer's own group,
+    // whose early fragment reads follow this barrier directly.  (Waiting after the barrier covers only the reader's own
+    // pieces: a race that showed as run-to-run differences in a ragged last sample group of the training forward, where
+    // the pieces queue behind activation stores.)
     __device__ __forceinline__ void m_done()
     {
         stamp(3);
-        barrier();
-        stamp(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(5);
+        barrier();
+        stamp(4);
     }
     // Refill of the next L -- this wave's share (fragments wave, wave + WAVES, ...) of chunk ci+2+grp, i.e. of chunk
     // (k+1)+1+grp for the L(k+1) that starts when M(k) ends -- issued piece by piece so that the caller can put the

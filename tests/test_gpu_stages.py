@@ -365,3 +365,41 @@ def test_gen_rays_bit_exact_with_c_oracle(dev):
     assert np.array_equal(N_(sub), co.gen_rays(intr, c2w, 1408, 376, 0.25, 80.0, pix.numpy()))
     assert torch.equal(sub, full[pix.long().to(dev)] * torch.tensor([1, 1, 1, 1, 1, 1, 0, 0], device=dev) + torch.tensor([0, 0, 0, 0, 0, 0, 0.25, 80.0], device=dev))
     assert ops.gen_rays(intr, c2w, 1408, 376, 0.5, 100.0, pix=torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 8)
+
+
+# ----------------------------------------------------------------------------- a5: the two time structures of the weight stream
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("R,N", [(510, 192), (510, 64), (37, 32), (512, 192)])
+def test_mlp_pingpong_equals_lockstep_bit_for_bit(dev, R, N, train):
+    """k_mlp_pp (two wave groups in phase opposition, three LDS slots) against k_mlp_fused (lock-step double buffer): same
+    arithmetic in the same order, so raw -- and the activations the training forward saves -- must be IDENTICAL, run after
+    run, also for a ragged last sample group whose second wave group holds no valid sample (the case that exposed a
+    refill piece read by a wave of the issuer's own group before a barrier covered it)."""
+    import ctypes
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import _lib, make_network
+    lib = _lib.load()
+    torch.manual_seed(0)
+    net = make_network(NS(N_importance=128, num_classes=5, num_instances=3)).to(dev)
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: (1408 * 376) // R][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    desc, img = net.packed(1, dev, "bf16")
+
+    def run():
+        if train:
+            raw, acts = ops.mlp_forward_train(desc, img, rays, z)
+            return raw.clone(), acts.view(torch.int16).clone()
+        return ops.mlp_forward(desc, img, rays, z).clone(), None
+
+    prev = lib.pnr_mlp_set_variant(0)
+    try:
+        want = run()
+        lib.pnr_mlp_set_variant(2)
+        for rep in range(4):
+            got = run()
+            assert torch.equal(got[0], want[0]), (rep, int((got[0] != want[0]).any(0).sum()))
+            if train:
+                assert torch.equal(got[1], want[1]), rep
+    finally:
+        lib.pnr_mlp_set_variant(prev)
