@@ -1,36 +1,57 @@
-import re,sys
-def regs(tok):
-    m=re.match(r'v\[(\d+):(\d+)\]',tok)
-    if m: return set(range(int(m.group(1)),int(m.group(2))+1))
-    m=re.match(r'v(\d+)$',tok)
-    if m: return {int(m.group(1))}
-    return set()
-pending=[]  # list of (regset, line)
-flags=0
-for ln,line in enumerate(open(sys.argv[1]),1):
-    s=line.split(';')[0].strip()
-    if not s or s.startswith('.') or s.endswith(':'): continue
-    parts=s.replace(',',' ').split()
-    op=parts[0]; ops=parts[1:]
-    if op=='s_waitcnt':
-        m=re.search(r'lgkmcnt\((\d+)\)',s)
-        if m:
-            n=int(m.group(1)); pending=pending[len(pending)-n:] if n>0 else []
-        continue
-    if op.startswith('s_') : continue
-    if op.startswith('ds_read'):
-        d=regs(ops[0]); src=set().union(*[regs(o) for o in ops[1:]]) if len(ops)>1 else set()
-        for p,l in pending:
-            if p&src: print("READ-BEFORE-WAIT",ln,s,"pending from",l); flags+=1
-            if p&d: print("WAW on pending",ln,s,"pending from",l); flags+=1
-        pending.append((d,ln)); continue
-    # other instructions: sources = all operands except first (dest) for most; stores: all
-    isstore = 'store' in op or op.startswith('ds_write') or op.startswith('global_load_lds')
-    srcs=ops if isstore else ops[1:]
-    dst=set() if isstore else (regs(ops[0]) if ops else set())
-    if op.startswith('v_mfma'): srcs=ops[1:]
-    src=set().union(*[regs(o) for o in srcs]) if srcs else set()
-    for p,l in pending:
-        if p&src: print("READ-BEFORE-WAIT",ln,s,"| pending ds_read at",l); flags+=1
-        if p&dst: print("WRITE-OVER-PENDING",ln,s,"| pending ds_read at",l); flags+=1
-print("flags:",flags)
+"""Static lint of gfx950 assembly for the one hazard hipcc cannot see in pnr_mlp_pp.h: the ping-pong MLP issues its LDS
+reads as inline asm and waits for them with hand-counted `s_waitcnt lgkmcnt(N)`, so the compiler believes a read's
+destination registers are valid as soon as the asm statement has "executed".  If register allocation ever inserts a copy
+of such a register (or re-uses it) between the `ds_read` and the wait that covers it, the kernel computes on stale data --
+silently and timing-dependently.  This walks the instruction stream in program order (branches ignored: the chunk pipeline
+is straight-line), keeps the list of outstanding LDS reads exactly as the hardware counter does (in-order return), and
+flags any instruction that reads or overwrites a destination that is still pending.
+
+usage: python tools/check_lds_pending.py file.s      (hipcc -S --cuda-device-only ...)"""
+import re
+import sys
+
+
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(lines):
+    """lines: iterable of assembly lines -> list of (line number, text, kind, line of the pending ds_read)."""
+    pending, flags = [], []
+    for ln, line in enumerate(lines, 1):
+        s = line.split(";")[0].strip()
+        if not s or s.startswith(".") or s.endswith(":"):
+            continue
+        parts = s.replace(",", " ").split()
+        op, ops = parts[0], parts[1:]
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", s)
+            if m:
+                n = int(m.group(1))
+                pending = pending[len(pending) - n:] if n > 0 else []
+            continue
+        if op.startswith("s_") or not ops:
+            continue
+        store = "store" in op or op.startswith("ds_write") or op.startswith("global_load_lds")
+        dst = set() if store else _regs(ops[0])
+        src = set().union(*[_regs(o) for o in (ops if store else ops[1:])]) if ops else set()
+        for p, l in pending:
+            if p & src:
+                flags.append((ln, s, "reads a pending LDS destination", l))
+            if p & dst:
+                flags.append((ln, s, "overwrites a pending LDS destination", l))
+        if op.startswith("ds_read"):
+            pending.append((dst, ln))
+    return flags
+
+
+if __name__ == "__main__":
+    fl = check(open(sys.argv[1]))
+    for f in fl[:40]:
+        print("line %d: %s  <- %s (ds_read at line %d)" % f)
+    print("flags:", len(fl))
+    sys.exit(1 if fl else 0)

@@ -1,0 +1,27 @@
+"""profiles/latest_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (rocpd sqlite): HBM bytes of the
+fine-level launch (the largest dispatch) of the fused MLP and of the compositing kernel.  FETCH_SIZE is doubled per
+MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported.
+usage: python tools/update_traffic.py <fetch.db> <write.db> <summary file name for the note>"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def biggest(db, counter, pat):
+    cur = sqlite3.connect(db).cursor()
+    r = cur.execute("select max(value) from counters_collection where counter_name=? and kernel_name like ?", (counter, pat)).fetchone()
+    return float(r[0])
+
+
+fetch_db, write_db, note = sys.argv[1:4]
+out = {}
+for key, pat in (("k_mlp_fused", "%k_mlp_%"), ("k_composite", "%k_composite<true, 64%")):
+    f, w = biggest(fetch_db, "FETCH_SIZE", pat), biggest(write_db, "WRITE_SIZE", pat)
+    out[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024),
+                "note": "fine-level launch (65536 rays x 192); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128 B requests "
+                        "as 64 B on wide coalesced reads); WRITE_SIZE as reported (uncalibrated); profiles/" + note}
+json.dump(out, open(os.path.join(ROOT, "profiles", "latest_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
