@@ -356,8 +356,11 @@ def main():
                 rw = raw if N == N_TOP else ops.alloc_raw(ch, Rc * N, dev)
                 if N != N_TOP:
                     rw.copy_(raw[:, : Rc * N])
-                lab = torch.zeros((Rc, N), device=dev, dtype=torch.int32) if c["bbox"] else None
-                ls, li = (lab if N_SEM else None), (lab if N_INST else None)
+                ls = li = None
+                if c["bbox"]:      # the scene's own per-sample labels (most samples are outside every box: -1)
+                    hits = ops.bbox_hits(rc, box, cfg.max_hits if hasattr(cfg, "max_hits") else 8)
+                    ls, li = ops.sample_labels(zz, hits[0], hits[1], hits[2], ids)
+                    ls, li = (ls if N_SEM else None), (li if N_INST else None)
                 cms = event_ms(lambda: ops.composite(rw, zz, rc, N_SEM, N_INST, True, None, ls, li, 0, False, want_w), 5)
                 bytes_ray = composite_bytes_per_ray(N, N_SEM, N_INST, c["bbox"] and (N_SEM or N_INST), want_w)
                 gbs = Rc * bytes_ray / (cms * 1e-3) / 1e9

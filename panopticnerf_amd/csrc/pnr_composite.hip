@@ -17,6 +17,8 @@
 //     order), instead of one compare-select reduction per class.
 // Nothing is re-read, so samples are staged in registers, not LDS: there is no reuse for LDS
 // to serve (cdna_hip_programming.md common mistake 7).
+#include <stdlib.h>
+
 #include "pnr_common.h"
 
 struct CompositeArgs {
@@ -262,6 +264,212 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------- second mapping (channel-major raw)
+// L lanes per ray x M = 4*M4 CONSECUTIVE samples per lane (N <= L*M): the weighted partial sum is M FMAs per lane, and
+// both the transmittance scan and the per-ray sums stay inside a 16-lane DPP row (row_shr / quad_perm / row_mirror: no
+// LDS crossbar, no bpermute); CMP2_UB rows (x M4 loads) are in flight per wave through the reductions.
+// Measured on MI355X against the 4-samples-per-lane mapping above, same process and buffers (tools/composite_ab.py,
+// profiles/README.md): N = 64 as 8 lanes x 8 samples (8 rays per wave): +1..3 % -> used for 32 < N <= 64;
+// N = 192 as 16 lanes x 12 samples (every lane busy, ~3x fewer issued instructions per byte): -1..-4 % at 4 or 8 rows
+// in flight, -9 % at 2 -> NOT used there: at N = 192 the kernel is bound by what HBM delivers for 768-byte pieces, not
+// by instruction issue.
+#ifndef CMP2_UB
+#define CMP2_UB 8
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_or(float x, float identity)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+template <int L, int M4, bool SOFTMAX>
+__global__ __launch_bounds__(256) void k_composite2(CompositeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];   // [4 waves][RPW][C+K] when use_hist
+    constexpr int M = 4 * M4, RPW = 64 / L;
+    static_assert(L == 8 || L == 16, "a ray must sit inside one 16-lane DPP row");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.N;
+    const int q = lane & (L - 1), g = lane / L;
+    const int i0 = q * M;                  // this lane's first sample
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_groups = (a.R + RPW - 1) / RPW;
+    const int CK = a.C + a.K;
+    const int nq = 3 + CK;
+    uint32_t* hist = s_hist + ((size_t)wave * RPW + g) * CK;
+    const int64_t sc = a.stride_c;
+
+    for (int64_t grp = wave_global; grp < n_groups; grp += n_waves) {
+        const int64_t ray = grp * RPW + g;
+        const bool rvalid = ray < a.R;
+        const int64_t rayc = rvalid ? ray : a.R - 1;
+        bool act[M4];
+#pragma unroll
+        for (int j = 0; j < M4; ++j) act[j] = rvalid && (i0 + 4 * j < N);
+        const int64_t s0 = rayc * N + (act[0] ? i0 : 0);
+        const bool writer = rvalid && q == 0;
+        auto row = [&](const float* base, float (&v)[M]) {       // one channel row's share of this lane
+#pragma unroll
+            for (int j = 0; j < M4; ++j) {
+                float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (act[j]) t = *reinterpret_cast<const float4*>(base + s0 + 4 * j);
+                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+            }
+        };
+
+        // ---- phase 1: weights
+        float zz[M], w[M];
+        row(a.z, zz);
+        row(a.raw + 3 * sc, w);                                   // sigma, becomes the weights below
+        float nxt[CMP2_UB][M];
+#pragma unroll
+        for (int j = 0; j < CMP2_UB; ++j) {
+            if (j < nq) row(a.raw + (int64_t)(j < 3 ? j : j + 1) * sc, nxt[j]);
+        }
+        if (a.noise) {
+            float nz[M];
+            row(a.noise, nz);
+#pragma unroll
+            for (int k = 0; k < M; ++k) w[k] += nz[k];
+        }
+        const float dx = a.rays[rayc * 8 + 3], dy = a.rays[rayc * 8 + 4], dz = a.rays[rayc * 8 + 5];
+        const float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float znext = dpp_or<0x101>(zz[0], 0.0f);           // row_shl:1 -- first sample of the next lane
+        float P = 1.0f;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const int i = i0 + k;
+            const float zn = (k < M - 1) ? zz[k + 1] : znext;
+            float dist = (i + 1 < N) ? (zn - zz[k]) : 1e10f;
+            dist *= dn;
+            const float sgm = fmaxf(w[k], 0.0f);
+            const float alpha = 1.0f - expf(-(sgm * dist));
+            w[k] = alpha * P;
+            P *= (1.0f - alpha) + 1e-10f;
+        }
+        if (!act[0]) P = 1.0f;
+        // segmented inclusive product scan over the L lanes of the ray, inside the DPP row (row_shr:d; a lane without a
+        // source keeps the identity)
+        float x = P;
+        {
+            float y = dpp_or<0x111>(x, 1.0f); x *= (L == 16 || q >= 1) ? y : 1.0f;
+            y = dpp_or<0x112>(x, 1.0f); x *= (L == 16 || q >= 2) ? y : 1.0f;
+            y = dpp_or<0x114>(x, 1.0f); x *= (L == 16 || q >= 4) ? y : 1.0f;
+            if constexpr (L == 16) { y = dpp_or<0x118>(x, 1.0f); x *= y; }
+        }
+        float excl = dpp_or<0x111>(x, 1.0f);
+        if (q == 0) excl = 1.0f;
+        float accp = 0.0f, depp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            w[k] = act[k >> 2] ? w[k] * excl : 0.0f;
+            accp += w[k];
+            depp = fmaf(w[k], zz[k], depp);
+        }
+        if (a.weights) {
+#pragma unroll
+            for (int j = 0; j < M4; ++j)
+                if (act[j]) *reinterpret_cast<float4*>(a.weights + s0 + 4 * j) = make_float4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+        }
+        const float accv = group_sum<L>(accp);
+        const float depv = group_sum<L>(depp);
+        if (writer) {
+            if (a.depth) a.depth[ray] = depv;
+            if (a.acc) a.acc[ray] = accv;
+        }
+
+        // ---- fixed (bbox-prior) fields: per-ray LDS histogram in 2^-30 fixed point (integer adds: order-independent)
+        const bool want_fs = a.fix_sem && a.label_sem && a.C, want_fi = a.fix_inst && a.label_inst && a.K;
+        if (want_fs || want_fi) {
+            for (int c = q; c < CK; c += L) hist[c] = 0;
+#pragma unroll
+            for (int j = 0; j < M4; ++j) {
+                int4 ls = make_int4(-1, -1, -1, -1), li = make_int4(-1, -1, -1, -1);
+                if (act[j] && want_fs) ls = *reinterpret_cast<const int4*>(a.label_sem + s0 + 4 * j);
+                if (act[j] && want_fi) li = *reinterpret_cast<const int4*>(a.label_inst + s0 + 4 * j);
+                const int lsv[4] = {ls.x, ls.y, ls.z, ls.w}, liv[4] = {li.x, li.y, li.z, li.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t fx = (uint32_t)(w[4 * j + k] * CMP_FIX_SCALE + 0.5f);
+                    if (want_fs && lsv[k] >= 0 && lsv[k] < a.C) atomicAdd(&hist[lsv[k]], fx);
+                    if (want_fi && liv[k] >= 0 && liv[k] < a.K) atomicAdd(&hist[a.C + liv[k]], fx);
+                }
+            }
+            if (rvalid) {
+                if (want_fs) for (int c = q; c < a.C; c += L) a.fix_sem[ray * a.C + c] = (float)hist[c] * (1.0f / CMP_FIX_SCALE);
+                if (want_fi) for (int c = q; c < a.K; c += L) a.fix_inst[ray * a.K + c] = (float)hist[a.C + c] * (1.0f / CMP_FIX_SCALE);
+            }
+        }
+
+        // ---- softmax mode: per-sample max / denominator of each learned field (extra pass over its rows)
+        float mx_s[SOFTMAX ? M : 1], den_s[SOFTMAX ? M : 1], mx_i[SOFTMAX ? M : 1], den_i[SOFTMAX ? M : 1];
+        if constexpr (SOFTMAX) {
+            auto field_stats = [&](int nch, int ch0, float (&mx)[M], float (&den)[M]) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) { mx[k] = -INFINITY; den[k] = 0.0f; }
+                for (int c = 0; c < nch; ++c) {
+                    float v[M];
+                    row(a.raw + (int64_t)(ch0 + c) * sc, v);
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        const float m2 = fmaxf(mx[k], v[k]);
+                        den[k] = den[k] * expf(mx[k] - m2) + expf(v[k] - m2);
+                        mx[k] = m2;
+                    }
+                }
+            };
+            field_stats(a.C, 4, mx_s, den_s);
+            field_stats(a.K, 4 + a.C, mx_i, den_i);
+        }
+
+        // ---- phase 2: every composited channel, CMP2_UB rows per batch; a row's registers are re-armed with the row of
+        // the next batch as soon as its partial sum is taken
+#pragma unroll 1
+        for (int q0 = 0; q0 < nq; q0 += CMP2_UB) {
+            float r[CMP2_UB];
+#pragma unroll
+            for (int j = 0; j < CMP2_UB; ++j) {
+                const int qq = q0 + j;
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    float v = nxt[j][k];
+                    if (qq < 3) v = 1.0f / (1.0f + expf(-v));
+                    else if constexpr (SOFTMAX) {
+                        const bool fs = (qq - 3) < a.C;
+                        v = expf(v - (fs ? mx_s[k] : mx_i[k])) / (fs ? den_s[k] : den_i[k]);
+                    }
+                    acc = fmaf(w[k], v, acc);
+                }
+                r[j] = acc;
+                const int q2 = qq + CMP2_UB;                     // >= 4 > 3: never an rgb row -> raw channel q2 + 1
+                if (q2 < nq) row(a.raw + (int64_t)(q2 + 1) * sc, nxt[j]);
+            }
+            group_sum_batch<L, CMP2_UB>(r);
+            if (writer) {
+#pragma unroll
+                for (int j = 0; j < CMP2_UB; ++j) {
+                    const int qq = q0 + j;
+                    if (qq >= nq) continue;
+                    if (qq < 3) { if (a.rgb) a.rgb[ray * 3 + qq] = a.white_bkgd ? r[j] + (1.0f - accv) : r[j]; }
+                    else if (qq - 3 < a.C) { if (a.sem) a.sem[ray * a.C + (qq - 3)] = r[j]; }
+                    else { if (a.inst) a.inst[ray * a.K + (qq - 3 - a.C)] = r[j]; }
+                }
+            }
+        }
+    }
+}
+
+template <bool SOFTMAX>
+static void launch_composite2(int L, int m4, int grid, size_t lds, hipStream_t st, const CompositeArgs& a)
+{
+#define PNR_C2(LL, MM) hipLaunchKernelGGL((k_composite2<LL, MM, SOFTMAX>), dim3(grid), dim3(256), lds, st, a)
+    if (L == 16) { if (m4 == 1) PNR_C2(16, 1); else if (m4 == 2) PNR_C2(16, 2); else if (m4 == 3) PNR_C2(16, 3); else PNR_C2(16, 4); }
+    else { if (m4 == 1) PNR_C2(8, 1); else PNR_C2(8, 2); }
+#undef PNR_C2
+}
+
 template <bool CH_MAJOR, bool SOFTMAX>
 static void launch_composite(int sub, int grid, size_t lds, hipStream_t st, const CompositeArgs& a)
 {
@@ -274,6 +482,20 @@ static void launch_composite(int sub, int grid, size_t lds, hipStream_t st, cons
     case 32: hipLaunchKernelGGL((k_composite<CH_MAJOR, 32, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
     default: hipLaunchKernelGGL((k_composite<CH_MAJOR, 64, SOFTMAX>), dim3(grid), dim3(256), lds, st, a); break;
     }
+}
+
+// PNR_CMP_VARIANT (A/B tools): 0 = 4-samples-per-lane mapping only, 1 = second mapping for 32 < N <= 64 [default], 2 = for every N > 32
+#ifndef PNR_CMP_DEFAULT_VARIANT
+#define PNR_CMP_DEFAULT_VARIANT 1
+#endif
+static int composite_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PNR_CMP_VARIANT");
+        v = e ? atoi(e) : PNR_CMP_DEFAULT_VARIANT;
+    }
+    return v;
 }
 
 PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw_stride_c, const float* z,
@@ -303,10 +525,27 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
     const bool want_fix = (fix_sem && label_sem && n_sem) || (fix_inst && label_inst && n_inst);
     a.use_hist = (want_fix && hist_bytes <= 48 * 1024) ? 1 : 0;
     const size_t lds = a.use_hist ? hist_bytes : 0;
-    const int64_t n_groups = (n_rays + rpw - 1) / rpw;
-    const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
     const bool ch_major = raw_stride_s == 1 && (raw_stride_c % 4) == 0 && (((uintptr_t)raw) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
+    // second mapping (L lanes x 4*m4 consecutive samples per lane): channel-major images with 33..64 samples per ray
+    // [variant 2, A/B only: every N > 32]
+    const int variant = composite_variant();
+    if (ch_major && n_samples > 32 && ((variant >= 1 && n_samples <= 64) || variant >= 2)) {
+        const int L = n_samples > 64 ? 16 : 8;
+        const int m4 = (n_samples + 4 * L - 1) / (4 * L);
+        const int rpw2 = 64 / L;
+        const size_t hb = (size_t)4 * rpw2 * (n_sem + n_inst) * sizeof(uint32_t);
+        if (!want_fix || hb <= 48 * 1024) {
+            const int64_t ng = (n_rays + rpw2 - 1) / rpw2;
+            const int grid2 = pnr_grid_cap((ng + 3) / 4, 8);
+            a.use_hist = want_fix ? 1 : 0;
+            if (sem_mode) launch_composite2<true>(L, m4, grid2, want_fix ? hb : 0, st, a); else launch_composite2<false>(L, m4, grid2, want_fix ? hb : 0, st, a);
+            PNR_CHECK_LAUNCH("pnr_composite");
+            return PNR_OK;
+        }
+    }
+    const int64_t n_groups = (n_rays + rpw - 1) / rpw;
+    const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
     if (ch_major) { if (sem_mode) launch_composite<true, true>(sub, grid, lds, st, a); else launch_composite<true, false>(sub, grid, lds, st, a); }
     else { if (sem_mode) launch_composite<false, true>(sub, grid, lds, st, a); else launch_composite<false, false>(sub, grid, lds, st, a); }
     PNR_CHECK_LAUNCH("pnr_composite");

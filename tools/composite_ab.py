@@ -1,6 +1,6 @@
 """Same-process A/B of two libpnr builds on pnr_composite: identical buffers (the physical placement of the 4 GB raw
 image alone moves the result by ~4 % between processes), interleaved repeats, with and without bbox labels.
-usage: python tools/composite_ab.py <libA.so> <libB.so>"""
+usage: python tools/composite_ab.py <libA.so> <libB.so> [N=192]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,7 @@ for path in sys.argv[1:3]:
     res, args = _lib.SIGNATURES["pnr_composite"]
     lib.pnr_composite.restype, lib.pnr_composite.argtypes = res, args
     libs[os.path.basename(path)] = lib
-R, N, C, K = 65536, 192, 45, 32
+R, N, C, K = 65536, (int(sys.argv[3]) if len(sys.argv) > 3 else 192), 45, 32
 S, ch = R * N, 81
 rays = synthetic.camera_rays()[:R].to(dev)
 z = ops.stratified(rays, N)
@@ -50,6 +50,7 @@ for labels in (False, True):
         for k, lib in libs.items():
             res[k].append(timed(lib, labels))
             chk[k] = (o["rgb"].double().sum() + o["sem"].double().sum() + o["depth"].double().sum()).item()
-    same = len(set(chk.values())) == 1
+    vals = list(chk.values())
+    same = abs(vals[0] - vals[-1]) <= 1e-6 * abs(vals[0])
     for k in libs:
-        print(f"labels={int(labels)} {k:24s} " + " ".join(f"{t:6.3f}" for t in res[k]) + f" ms   best {nbytes / min(res[k]) / 1e9:5.2f} TB/s   outputs {'identical' if same else 'DIFFER'}")
+        print(f"labels={int(labels)} {k:24s} " + " ".join(f"{t:6.3f}" for t in res[k]) + f" ms   best {nbytes / min(res[k]) / 1e9:5.2f} TB/s   outputs {'agree' if same else 'DIFFER'}")
