@@ -146,11 +146,11 @@ def run_checks(root, sheet, write_golden=False):
             # torch's vectorised cumsum and the strict-order oracle differ by an ulp in the CDF: a sample that sits on a bin
             # edge may land in the neighbouring bin (a whole coarse interval away).  Judge the bulk, count the flips.
             d = np.abs(zs.astype(np.float64) - g["pdf_det_zs"])
-            flips = float((d > 1e-3).mean())
-            bulk = float(d[d <= 1e-3].max()) if (d <= 1e-3).any() else float("inf")
-            print("   %-22s max |reference - oracle| = %.3e away from bin edges; %.3f %% of the samples flip to a neighbouring bin"
-                  % ("z_samples (det)", bulk, 100 * flips))
-            results["sample_pdf"] = bulk < 1e-4 and flips < 0.01
+            flips = float((d > 1e-4).mean())
+            bulk = float(np.median(d))
+            print("   %-22s median |reference - oracle| = %.3e; %.3f %% of the samples differ by > 1e-4 (bin-edge flips), max %.3e"
+                  % ("z_samples (det)", bulk, 100 * flips, d.max()))
+            results["sample_pdf"] = bulk < 1e-5 and flips < 0.01
             if write_golden:
                 new["pdf_det_zs"] = zs.astype(np.float32)
         except Exception as e:      # noqa: BLE001
