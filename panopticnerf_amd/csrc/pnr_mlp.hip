@@ -39,6 +39,15 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 #ifndef PNR_OPT_EAGER_EPI
 #define PNR_OPT_EAGER_EPI 1
 #endif
+#ifndef PNR_PP_STORES_LAST
+#define PNR_PP_STORES_LAST 0      /* pieces first + counted vmcnt (1): no gain measured; the plain order stays */
+#endif
+#ifndef PNR_RAW_STORE
+#define PNR_RAW_STORE 0           /* cache policy of the raw-output stores: 0 plain, 1 nt, 2 sc1 */
+#endif
+#ifndef PNR_PP_EPI_IN_M
+#define PNR_PP_EPI_IN_M 0
+#endif
 #ifndef PNR_PP_UNROLL2
 #define PNR_PP_UNROLL2 0     /* two trunk layers per loop trip (no hand-over copies): -2 % measured (code size) */
 #endif
@@ -102,6 +111,31 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
     }
 }
 
+// One 32-row output block of one sample tile -> raw channels ch_base + row.  The lane-dependent part of the address
+// (the sample, and the half-wave's 4-row offset) is folded into ONE 64-bit base per call; every row then adds a
+// wave-uniform offset, so a store costs a compare, an exec mask and one 64-bit add instead of two 64-bit multiplies
+// per lane (the stores' address arithmetic was ~1000 cycles per output block).
+__device__ __forceinline__ void store_raw_block(const MlpArgs& a, int samp, int hi, int fb, int n_out, int ch_base, const f32x16& acc)
+{
+    if (samp < 0) return;
+    float* const dst0 = a.raw + ((int64_t)samp * a.ss + (int64_t)(4 * hi) * a.sc);
+    const int lim = n_out - 4 * hi;                 // row u (of the hi = 0 half) is stored iff u < lim
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int u = fb * 32 + (r & 3) + 8 * (r >> 2);
+        if (u < lim) {
+            float* const p = dst0 + (int64_t)(ch_base + u) * a.sc;
+#if PNR_RAW_STORE == 1
+            __builtin_nontemporal_store(acc[r], p);                                   // nt
+#elif PNR_RAW_STORE == 2
+            __hip_atomic_store(p, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: write-through, line dropped from L2
+#else
+            *p = acc[r];
+#endif
+        }
+    }
+}
+
 // Output layer: rows [0, n_out) are stored to raw channels ch_base + row (one 32-row block per chunk).
 template <int PREC, int TILES, class CTX, int NA, int NB>
 __device__ __forceinline__ void layer_out(CTX& c, const uint32_t (&inA)[TILES][NA],
@@ -123,16 +157,7 @@ __device__ __forceinline__ void layer_out(CTX& c, const uint32_t (&inA)[TILES][N
         // chunk ago, not the raw stores below (an HBM write round trip per output block otherwise).
         c.finish();
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            if (samp[t] >= 0) {
-                float* dst = c.a.raw + (int64_t)samp[t] * c.a.ss;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = fb * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.hi;
-                    if (row < n_out) dst[(int64_t)(ch_base + row) * c.a.sc] = acc[0][t][r];
-                }
-            }
-        }
+        for (int t = 0; t < TILES; ++t) store_raw_block(c.a, samp[t], c.hi, fb, n_out, ch_base, acc[0][t]);
     }
 }
 
@@ -339,13 +364,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         c.barrier();                                            // L -> M
         c.stamp(2);
         CH::mma(c.frag_addr(), A, inA, inB, acc);
-        c.m_done();                                             // M -> L of the next chunk; own refill pieces landed
-        const bool nxt_same = cb + 1 < NFB_OUT / FBC;           // the next chunk has this chunk's shape
-        if (PNR_PP_EARLY && nxt_same) CH::first_frags(c.next_frag_addr(), A);
-        c.refill_begin();
-#pragma unroll
-        for (int b = 0; b < FBC; ++b) {
-            c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
+        auto epilogue = [&](int b) {
             const int fb = cb * FBC + b;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -354,7 +373,20 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
                 asm volatile("" : "+v"(v));
                 out[fb * 8 + p] = v;
             }
-            if (save) store_slots(save, NFB_OUT * 32, samp, fb, c.hi, &out[fb * 8]);
+        };
+        // The M wave reaches the barrier ~200 cycles before its partner finishes L: the pack / ReLU of the chunk's first
+        // PNR_PP_EPI_IN_M blocks (complete one MFMA before the chunk's last) is done here, in that slack, instead of in L.
+#pragma unroll
+        for (int b = 0; b < (PNR_PP_EPI_IN_M < FBC ? PNR_PP_EPI_IN_M : FBC); ++b) epilogue(b);
+        c.m_done();                                             // M -> L of the next chunk; own refill pieces landed
+        const bool nxt_same = cb + 1 < NFB_OUT / FBC;           // the next chunk has this chunk's shape
+        if (PNR_PP_EARLY && nxt_same) CH::first_frags(c.next_frag_addr(), A);
+        c.refill_begin();
+#pragma unroll
+        for (int b = 0; b < FBC; ++b) {
+            c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
+            if (b >= PNR_PP_EPI_IN_M) epilogue(b);
+            if (save) store_slots(save, NFB_OUT * 32, samp, cb * FBC + b, c.hi, &out[(cb * FBC + b) * 8]);
         }
         if (PNR_PP_EARLY_BIAS && nxt_same) CH::bias_issue(c.next_bias_addr(), q);   // accumulators free: next chunk's bias, asynchronous
         c.refill_rest();
@@ -362,7 +394,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
     }
 }
 
-template <class CTX, int NA, int NB>
+template <bool TRAIN, class CTX, int NA, int NB>
 __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
                                              const uint32_t (&inB)[NB > 0 ? NB : 1], int n_out, int ch_base, int samp)
 {
@@ -378,15 +410,24 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
         c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
         c.refill_begin();
         c.refill_one();
-        if (samp >= 0) {
-            float* dst = c.a.raw + (int64_t)samp * c.a.ss;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = fb * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.hi;
-                if (row < n_out) dst[(int64_t)(ch_base + row) * c.a.sc] = acc[0][r];
-            }
-        }
+#if PNR_PP_STORES_LAST
+        // Every piece first, then the stores, and the NUMBER of store instructions this wave issues is handed to the next
+        // m_done(): VMEM operations of a wave complete in order, so `s_waitcnt vmcnt(#stores)` there covers the pieces
+        // without waiting for the stores' HBM write acknowledgements (which take longer than two phases).
         c.refill_rest();
+        if (!(PNR_PP_ABL & 4)) {
+            store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
+            int cnt = 0;
+            if (!TRAIN && __builtin_amdgcn_ballot_w64(samp >= 0) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cnt += (fb * 32 + (r & 3) + 8 * (r >> 2) < n_out) ? 1 : 0;   // row of the hi = 0 half
+            }
+            c.pending_stores = cnt;
+        }
+#else
+        if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
+        c.refill_rest();
+#endif
         c.advance();
     }
 }
@@ -481,12 +522,12 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         if (a.n_sem) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), samp);
-            pp_layer_out<CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
+            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), samp);
-            pp_layer_out<CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
         {
             const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
@@ -498,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp, 0, c.hi, ed);   // ED: [S][32]
         uint32_t g[GR];
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), samp);
-        pp_layer_out<CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
+        pp_layer_out<TRAIN, CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
 #if PNR_TRACE
         ++c.titer;
 #endif

@@ -75,6 +75,10 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #ifndef PNR_PP_PRIO
 #define PNR_PP_PRIO 1        /* s_setprio of the M phase: +1 % measured */
 #endif
+// cache policy bits of the refill's global_load_lds (0 = default, 1 = sc0, 2 = nt)
+#ifndef PNR_PP_DMA_AUX
+#define PNR_PP_DMA_AUX 0
+#endif
 // timing-only ablations (A/B builds; results are wrong): 1 = no refill pieces, 2 = no fragment reads inside the MFMA loop
 // 1: the first fragments of a layer's 2nd, 3rd, ... chunk are read right after the previous chunk's M -> L barrier
 #ifndef PNR_PP_EARLY
@@ -169,10 +173,26 @@ struct CtxPP {
     __device__ __forceinline__ void m_done()
     {
         stamp(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_pieces();
         stamp(5);
         barrier();
         stamp(4);
+    }
+    // vmcnt wait that covers every refill piece of this wave but not the `pending_stores` raw-output stores it issued
+    // AFTER them (pp_layer_out): s_waitcnt takes an immediate, hence the ladder (uniform branches, output chunks only)
+    int pending_stores;
+    __device__ __forceinline__ void wait_pieces()
+    {
+        const int n = pending_stores;
+        pending_stores = 0;
+        if (n == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+#define PNR_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n) {
+            PNR_VM(1) PNR_VM(2) PNR_VM(3) PNR_VM(4) PNR_VM(5) PNR_VM(6) PNR_VM(7) PNR_VM(8)
+            PNR_VM(9) PNR_VM(10) PNR_VM(11) PNR_VM(12) PNR_VM(13) PNR_VM(14) PNR_VM(15) PNR_VM(16)
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+#undef PNR_VM
     }
     // Refill of the next L -- this wave's share (fragments wave, wave + WAVES, ...) of chunk ci+2+grp, i.e. of chunk
     // (k+1)+1+grp for the L(k+1) that starts when M(k) ends -- issued piece by piece so that the caller can put the
@@ -194,7 +214,7 @@ struct CtxPP {
     {
         if (!(PNR_PP_ABL & 1) && rf_f < rf_n) {
             __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)rf_f * PNR_FRAG_BYTES),
-                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, 0);
+                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
             rf_f += WAVES;
         }
     }
@@ -202,7 +222,7 @@ struct CtxPP {
     {
         for (; !(PNR_PP_ABL & 1) && rf_f < rf_n; rf_f += WAVES)
             __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)rf_f * PNR_FRAG_BYTES),
-                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, 0);
+                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
         stamp(1);
     }
     __device__ __forceinline__ void advance()
