@@ -343,9 +343,13 @@ def test_raw_channel_stride_is_free(dev):
     assert torch.equal(padded, dense) and torch.equal(odd, dense)
     lab = torch.randint(-1, C, (R, N), device=dev, dtype=torch.int32)
     a = ops.composite(dense, z, rays, C, K, True, None, lab, None)
-    for other in (padded, odd):
-        b = ops.composite(other, z, rays, C, K, True, None, lab, None)
-        assert all(torch.equal(a[k], b[k]) for k in a)
+    b = ops.composite(padded, z, rays, C, K, True, None, lab, None)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    # rows that are not 16-byte aligned take the generic strided kernel, whose per-ray sums associate differently from
+    # the 8-lanes-x-8-samples mapping the aligned N = 64 image runs on: equal to rounding, not bit for bit
+    b = ops.composite(odd, z, rays, C, K, True, None, lab, None)
+    for k in a:
+        assert (a[k] - b[k]).abs().max() < 2e-5 * max(1.0, float(a[k].abs().max())), k
     with pytest.raises(ValueError):
         ops.composite(dense.T.contiguous().T, z, rays, C, K, True)     # sample stride != 1
 
