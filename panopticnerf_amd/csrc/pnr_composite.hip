@@ -35,6 +35,9 @@ struct f4 { float v[4]; };
 #define CMP_UB 8        // channel rows per batch
 #endif
 #define CMP_FIX_SCALE 1073741824.0f   // 2^30
+#ifndef CMP_PREFETCH
+#define CMP_PREFETCH 0      /* z / sigma of the next ray group requested one group ahead: -2.5..-5 % at N = 192 (registers 126 -> 160), +-0 at N = 64 */
+#endif
 
 template <bool CH_MAJOR>
 __device__ __forceinline__ f4 load4(const float* __restrict__ raw, int64_t ss, int64_t sc, int64_t s0, int c, bool active)
@@ -110,6 +113,25 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
     const int nq = 3 + CK;                 // composited raw channels: rgb, semantic, instance (sigma excluded)
     uint32_t* hist = s_hist + ((size_t)wave * RPW + g) * CK;
 
+    // z and sigma of a ray group: the head of the dependent chain (load -> exp -> scan -> weights).  With CMP_PREFETCH
+    // they are requested one group ahead, while the previous group's channel rows are being reduced, so a wave's next
+    // weights never wait for an HBM round trip.
+    auto load_zs = [&](int64_t grp, f4& zz, f4& sg) {
+        const int64_t ray = grp * RPW + g;
+        const bool active = (ray < a.R) && (q < nq4) && (grp < n_groups);
+        const int64_t rayc = ray < a.R ? ray : a.R - 1;
+        const int64_t s0 = rayc * N + (active ? 4 * q : 0);
+        if (active) {
+            const float4 t = *reinterpret_cast<const float4*>(a.z + s0);
+            zz.v[0] = t.x; zz.v[1] = t.y; zz.v[2] = t.z; zz.v[3] = t.w;
+        } else {
+            zz.v[0] = zz.v[1] = zz.v[2] = zz.v[3] = 0.0f;
+        }
+        sg = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, 3, active);
+    };
+    f4 pz, ps;
+    if (CMP_PREFETCH) load_zs(wave_global, pz, ps);
+
     for (int64_t grp = wave_global; grp < n_groups; grp += n_waves) {
         const int64_t ray = grp * RPW + g;
         const bool active = (ray < a.R) && (q < nq4);
@@ -119,17 +141,13 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
 
         // ---- phase 1: weights
         f4 zz, sg;
-        if (active) {
-            const float4 t = *reinterpret_cast<const float4*>(a.z + s0);
-            zz.v[0] = t.x; zz.v[1] = t.y; zz.v[2] = t.z; zz.v[3] = t.w;
-        } else {
-            zz.v[0] = zz.v[1] = zz.v[2] = zz.v[3] = 0.0f;
-        }
-        sg = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, 3, active);
+        if (CMP_PREFETCH) { zz = pz; sg = ps; }
+        else load_zs(grp, zz, sg);
         // first batch of channel rows: in flight while the weights are computed
         f4 nxt[CMP_UB];
 #pragma unroll
         for (int j = 0; j < CMP_UB; ++j) nxt[j] = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, j < 3 ? j : j + 1, active && j < nq);
+        if (CMP_PREFETCH) load_zs(grp + n_waves, pz, ps);         // next group's chain head
         if (a.noise && active) {
             const float4 t = *reinterpret_cast<const float4*>(a.noise + s0);
             sg.v[0] += t.x; sg.v[1] += t.y; sg.v[2] += t.z; sg.v[3] += t.w;

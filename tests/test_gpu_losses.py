@@ -153,6 +153,43 @@ def test_network_wrapper_end_to_end(dev):
     assert set(stats) >= {"loss", "rgb_loss_0", "fix_semantic_loss_1", "ce3d_semantic_loss_1"}
 
 
+def test_chunked_training_render_weights_the_3d_ce_by_labelled_samples(dev):
+    """the per-level 3D cross-entropy of a render split into ray chunks must be the mean over ALL labelled
+    samples of the batch (chunk means weighted by their labelled-sample counts), not the mean of chunk means -- chunks
+    see very different numbers of in-box samples.  One chunk vs ragged chunks: same scalars, same loss, same gradients."""
+    from panopticnerf_amd import NetworkWrapper, make_network, synthetic
+    C, K = 5, 3
+    base = dict(N_samples=32, N_importance=32, num_classes=C, num_instances=K, precision="bf16", D=4, W=128, skips=[1],
+                w_sem3d=0.3, w_inst3d=0.2)
+    torch.manual_seed(5)
+    net = make_network(NS(**base)).to(dev).train()
+    with torch.no_grad():
+        for lv in (0, 1):
+            net.nerf(lv).alpha_linear.bias.fill_(0.2)
+    R = 300
+    rays = synthetic.camera_rays()[::1733][:R].contiguous()
+    box, ids = synthetic.random_boxes(12, C, K, seed=4)
+    box[:6, 0] -= 60.0                                   # half of the boxes far left: in-box samples concentrate in some rays
+    g = torch.Generator().manual_seed(3)
+    batch = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev), "rgb": torch.rand(1, R, 3, generator=g).to(dev)}
+    res = {}
+    for chunk in (4096, 77):
+        wrap = NetworkWrapper(net, NS(chunk_size=chunk, **base))
+        net.zero_grad(set_to_none=True)
+        ret, loss, stats, _ = wrap(batch)
+        loss.backward()
+        res[chunk] = (ret, loss.detach(), {n: p.grad.clone() for n, p in net.named_parameters()})
+    one, many = res[4096], res[77]
+    for lv in (0, 1):
+        for f in ("semantic", "instance"):
+            k, kn = f"ce3d_{f}_{lv}", f"ce3d_{f}_n_{lv}"
+            assert float(one[0][kn]) > 0 and float(one[0][kn]) == float(many[0][kn])
+            assert abs(float(one[0][k].detach()) - float(many[0][k].detach())) < 2e-5 * abs(float(one[0][k].detach())), k
+    assert abs(float(one[1]) - float(many[1])) < 1e-5 * abs(float(one[1]))
+    for n in one[2]:
+        assert _rel(many[2][n], one[2][n]) < 2e-3, n
+
+
 @pytest.mark.parametrize("N", [16, 192])
 def test_softmax_compositing_backward(dev, N):
     """sem_mode 1 (softmax(logits) composited per sample): d_raw of pnr_composite_backward3 vs torch autograd of the
