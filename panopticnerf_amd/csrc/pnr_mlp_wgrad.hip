@@ -33,8 +33,23 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 
-#define WG_KT 64                    /* samples per LDS tile */
+// LDS ring: WG_NBUF buffers of WG_KT-sample tiles, WG_NBUF - 1 tiles requested ahead (counted vmcnt).  Measured at
+// 786 K samples (tools/train_profile.py, same box): 64 x 2 buffers 2.89 ms, 48 x 3: 3.19, 32 x 4: 3.61, 32 x 5: 3.61 --
+// deeper prefetch does not pay, smaller tiles cost: the kernel is not waiting for HBM latency.
+#ifndef WG_KT
+#define WG_KT 64                    /* samples per LDS tile (a multiple of the 16-sample k-step) */
+#endif
+#ifndef WG_NBUF
+#define WG_NBUF 2
+#endif
+#ifndef WG_DMA_AUX
+#define WG_DMA_AUX 2                /* cache policy of the tile loads: 0 default, 2 nt (every byte is read once per job): -3 % */
+#endif
+#ifndef WG_SPREAD
+#define WG_SPREAD 0                 /* 1: the next tile's pieces are issued between the k-steps instead of en bloc: +30 % time */
+#endif
 #define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
+static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && 2 * WG_NBUF * WG_TILE_BYTES <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
 #define WG_MAX_JOBS 24
 #define WG_BIAS_COLS 32             /* partial block: [ma][nb + 32], column nb = row sum (bias gradient) */
 
@@ -55,7 +70,7 @@ __device__ __forceinline__ int wg_swz(int row, int cpr) { return cpr >= 16 ? ((r
 
 __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][A tile | B tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [WG_NBUF][A tile | B tile]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int jb = blockIdx.x / a.n_slabs, slab = blockIdx.x - jb * a.n_slabs;
     const int ma = a.job[jb].ma, nb = a.job[jb].nb;
@@ -68,10 +83,10 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
     const int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64;
 
     // ---- LDS-DMA of tile t into buffer buf: piece p of an operand covers 64 consecutive chunk positions
-    auto issue = [&](int t, int buf) {
+    auto issue = [&](int t, int buf, int part = 0, int nparts = 1) {     // part / nparts: this wave's pieces split round-robin
         const int s0 = s_begin + t * WG_KT;
         char* const dA = smem + buf * 2 * WG_TILE_BYTES;
-        for (int p = wave; p < piecesA + piecesB; p += 8) {
+        for (int p = wave + 8 * part; p < piecesA + piecesB; p += 8 * nparts) {
             const bool isA = p < piecesA;
             const int pp = isA ? p : p - piecesA;
             const int cpr = isA ? cprA : cprB;
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
             const int srow = s0 + r;
             const char* src = srow < s_end ? reinterpret_cast<const char*>((isA ? Ag : Bg) + (int64_t)srow * (cpr * 8)) + c * 16
                                            : reinterpret_cast<const char*>(a.zeros) + c * 16;
-            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dA + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dA + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
         }
     };
 
@@ -121,14 +136,36 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    if (ntiles > 0) issue(0, 0);
+    // this wave's LDS-DMA pieces per tile (the same for every tile of the job): what a counted vmcnt may leave in flight
+    const int total_pieces = piecesA + piecesB;
+    const int n_mine = wave < total_pieces ? (total_pieces - wave + 7) / 8 : 0;
+    auto wait_but = [&](int n) {        // s_waitcnt takes an immediate: a ladder over the possible piece counts
+#define PNR_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n) {
+            PNR_VM(1) PNR_VM(2) PNR_VM(3) PNR_VM(4) PNR_VM(5) PNR_VM(6) PNR_VM(7) PNR_VM(8) PNR_VM(9) PNR_VM(10) PNR_VM(11) PNR_VM(12)
+            PNR_VM(13) PNR_VM(14) PNR_VM(15) PNR_VM(16) PNR_VM(17) PNR_VM(18) PNR_VM(19) PNR_VM(20) PNR_VM(21) PNR_VM(22) PNR_VM(23) PNR_VM(24)
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+#undef PNR_VM
+    };
+#pragma unroll
+    for (int d = 0; d < WG_NBUF - 1; ++d)
+        if (d < ntiles) issue(d, d);
+    int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                            // tile t landed; everybody is done with tile t-1
-        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
-        const char* tile = smem + (t & 1) * 2 * WG_TILE_BYTES;
+        // tile t has landed once only the pieces of the younger tiles already requested are outstanding (VMEM operations
+        // of a wave complete in order)
+        const int ahead = ntiles - 1 - t < WG_NBUF - 2 ? ntiles - 1 - t : WG_NBUF - 2;
+        wait_but(n_mine * ahead);
+        __syncthreads();                                            // tile t landed for everybody; everybody is done with tile t-1
+        const bool more = t + WG_NBUF - 1 < ntiles;
+        const int nbuf = buf == 0 ? WG_NBUF - 1 : buf - 1;          // tile t-1's buffer
+        if (more && !WG_SPREAD) issue(t + WG_NBUF - 1, nbuf);
+        const char* tile = smem + buf * 2 * WG_TILE_BYTES;
+        buf = buf + 1 == WG_NBUF ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < WG_KT / 16; ++ks) {
+            if (more && WG_SPREAD) issue(t + WG_NBUF - 1, nbuf, ks, WG_KT / 16);
             bf16x8 fa[2], fb[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -310,10 +347,10 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES));
+        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_NBUF * WG_TILE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 4 * WG_TILE_BYTES, st, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 2 * WG_NBUF * WG_TILE_BYTES, st, a);
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
     WgRedArgs r;
     memset(&r, 0, sizeof(r));
