@@ -280,16 +280,25 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
             }
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
+        // ReLU gate bits of a layer output for the data-gradient pass (pnr_train_layout: gate_off)
+        auto gv = [&](int idx, auto& regs) {
+            if constexpr (TRAIN && PREC == PNR_PREC_BF16) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) save_gates(a.acts + a.gate_off[idx], samp[t], c.hi, regs[t]);
+            }
+        };
 
         // trunk
         uint32_t cur[TILES][HR], nxt[TILES][HR];
         layer_regs<PREC, TILES, CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur, sv(2), samp);
+        gv(2, cur);
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             if (l - 1 == a.skip)
                 layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt, sv(2 + l), samp);
             else
                 layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt, sv(2 + l), samp);
+            gv(2 + l, nxt);
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -299,11 +308,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         if (a.n_sem) {
             uint32_t sh[TILES][GR];
             layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), samp);
+            gv(4 + a.D, sh);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[TILES][GR];
             layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), samp);
+            gv(5 + a.D, sh);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
         // next sample group's inputs: issued here so their HBM latency hides under the feature/views layers
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         }
         uint32_t g[TILES][GR];
         layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), samp);
+        gv(3 + a.D, g);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
 #if PNR_TRACE
         ++c.titer;
@@ -491,13 +503,18 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
+        auto gv = [&](int idx, auto& regs) {
+            if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], samp, c.hi, regs);
+        };
         uint32_t cur[HR], nxt[HR];
         pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), samp);
+        gv(2, cur);
         auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
             if (l - 1 == a.skip)
                 pp_layer_regs<CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, A, ex, in, out, sv(2 + l), samp);
             else
                 pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, A, in, dummy, out, sv(2 + l), samp);
+            gv(2 + l, out);
         };
 #if PNR_PP_UNROLL2
         // two layers per trip, cur -> nxt -> cur: no 64-register hand-over copy per layer (it sat in the L phase of every
@@ -522,11 +539,13 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         if (a.n_sem) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), samp);
+            gv(4 + a.D, sh);
             pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), samp);
+            gv(5 + a.D, sh);
             pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
         {
@@ -539,6 +558,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp, 0, c.hi, ed);   // ED: [S][32]
         uint32_t g[GR];
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), samp);
+        gv(3 + a.D, g);
         pp_layer_out<TRAIN, CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
 #if PNR_TRACE
         ++c.titer;
@@ -657,7 +677,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     a.clk = g_clk_buf;
-    if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
+    if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
     // fp32 parity mode: 4 waves x 1 tile, one wave per SIMD (its activations need ~300 registers)

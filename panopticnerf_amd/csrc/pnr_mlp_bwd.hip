@@ -24,32 +24,25 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 #endif
 
 // One backward layer.  in: NA B registers (k-segments concatenated).  out[t][OFF + fb*8 + p].
-// mask  : slot-ordered [S][NFB_OUT*32] activations whose ReLU gates this gradient (nullptr: linear)
+// gate  : the ReLU gate BITS of the layer's forward output ([S][NFB_OUT] dwords, pnr_train_layout; nullptr: linear):
+//         NFB_OUT/2 dwords per lane, loaded once per layer, instead of the 16 x NFB_OUT bytes of bf16 activations
 // store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient (nullptr: not stored)
 template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF>
 __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
-                                          const uint16_t* mask, uint16_t* store, const int (&samp)[TILES])
+                                          const uint16_t* gate, uint16_t* store, const int (&samp)[TILES])
 {
     constexpr int FBC = 2, G = 2;
     static_assert(NFB_OUT % FBC == 0 && NOUT >= OFF + NFB_OUT * 8, "bad backward layer geometry");
     uint32_t dummy[TILES][1];
+    uint32_t gw[TILES][NFB_OUT / 2];
+    if (gate) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) load_gates<NFB_OUT / 2>(gate, NFB_OUT * 32, samp[t], c.hi, gw[t]);
+    }
 #pragma unroll
     for (int cb = 0; cb < NFB_OUT / FBC; ++cb) {
         c.begin();
         const char* base = c.base();
-        u32x4 mk[FBC][TILES][2];
-        auto load_mask = [&]() {
-#pragma unroll
-            for (int b = 0; b < FBC; ++b)
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    const u32x4* mp = reinterpret_cast<const u32x4*>(
-                        slot_ptr(const_cast<uint16_t*>(mask), NFB_OUT * 32, samp[t] < 0 ? 0 : samp[t], cb * FBC + b, c.hi));
-                    mk[b][t][0] = mp[0];
-                    mk[b][t][1] = mp[1];
-                }
-        };
-        if (mask) load_mask();
         f32x16 acc[FBC][TILES];
 #pragma unroll
         for (int b = 0; b < FBC; ++b)
@@ -65,13 +58,8 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
             for (int t = 0; t < TILES; ++t) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
-                    float lo = acc[b][t][2 * p], hi = acc[b][t][2 * p + 1];
-                    if (mask) {
-                        const uint32_t m = mk[b][t][p >> 2][p & 3];
-                        if ((m & 0xffffu) == 0) lo = 0.0f;       // ReLU output is >= 0: zero bits <=> gate closed
-                        if ((m >> 16) == 0) hi = 0.0f;
-                    }
-                    out[t][OFF + fb * 8 + p] = pack_bf16(lo, hi);
+                    const uint32_t v = pack_bf16(acc[b][t][2 * p], acc[b][t][2 * p + 1]);
+                    out[t][OFF + fb * 8 + p] = gate ? gate_apply(v, gw[t][fb / 2], fb, p) : v;
                 }
                 if (store) store_slots(store, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][OFF + fb * 8]);
             }
@@ -135,7 +123,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
 
         // d g = W_rgb^T d rgb ; gate by g ; -> dY_views
         uint32_t dyv[TILES][GR];
-        layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.acts_off[3 + D], dys + a.dys_off[0], samp);
+        layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.gate_off[3 + D], dys + a.dys_off[0], samp);
         // d f = W_views[:, :W]^T dY_views  (feature_linear has no activation) -> dY_feature
         layer_bwd<TILES, CTX, GR, NFB, CATR, 0>(c, dyv, cat, nullptr, dys + a.dys_off[1], samp);
         if (a.n_sem) {
@@ -143,22 +131,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
 #pragma unroll
             for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &ds[0][b * 8]);
-            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.acts_off[4 + D], dys + a.dys_off[2], samp);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp);
         }
         if (a.n_inst) {
             uint32_t di[TILES][OBR];
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
 #pragma unroll
             for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &di[0][b * 8]);
-            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.acts_off[5 + D], dys + a.dys_off[3], samp);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
         uint32_t dy[TILES][HR], dn[TILES][HR];
-        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.acts_off[1 + D], dys + a.dys_off[3 + D], samp);
+        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp);
         // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
 #pragma unroll 1
         for (int l = D - 1; l >= 1; --l) {
-            layer_bwd<TILES, CTX, HR, NFB, HR, 0>(c, dy, dn, acts + a.acts_off[1 + l], dys + a.dys_off[3 + l], samp);
+            layer_bwd<TILES, CTX, HR, NFB, HR, 0>(c, dy, dn, acts + a.gate_off[1 + l], dys + a.dys_off[3 + l], samp);
 #pragma unroll
             for (int i = 0; i < HR; ++i) dy[0][i] = dn[0][i];
         }
@@ -212,7 +200,7 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.S = (int)(n_rays * n_samples); a.N = n_samples;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
-    pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off);
+    pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
     hipStream_t st = (hipStream_t)stream;
     return desc->W == 256 ? launch_bwd<256, PNR_BWD_WAVES>(a, st) : launch_bwd<128, PNR_BWD_WAVES>(a, st);
 }

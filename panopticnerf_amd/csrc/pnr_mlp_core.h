@@ -30,7 +30,7 @@ struct MlpArgs {
     uint16_t* acts; const float* d_raw; uint16_t* dys;
     unsigned long long* trace;      // PNR_TRACE builds: [8 waves][PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
     unsigned long long* clk;        // optional (bench): {shader cycles, 100 MHz ticks} of workgroup 0's first wave
-    int64_t acts_off[24], dys_off[24];
+    int64_t acts_off[24], dys_off[24], gate_off[24];     // pnr_train_layout (bf16 units)
 };
 
 // 16 consecutive slots (one 32-row block's share of lane (n,hi)) of a slot-ordered [S][width] bf16 tensor
@@ -46,6 +46,61 @@ __device__ __forceinline__ void store_slots(uint16_t* base, int width, int s, in
     a[0] = r8[0]; a[1] = r8[1]; a[2] = r8[2]; a[3] = r8[3];
     b[0] = r8[4]; b[1] = r8[5]; b[2] = r8[6]; b[3] = r8[7];
     p[0] = a; p[1] = b;
+}
+
+// ReLU gate bits of one 32-row block (8 packed bf16x2 registers, post-ReLU) into the lane's gate word of the block PAIR:
+// min(x, 1) per half leaves bit 0 / bit 16, shifted to bit 8*(fb&1) + p / 16 + 8*(fb&1) + p (pnr_train_layout).
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+__device__ __forceinline__ uint32_t gate_bits_or(uint32_t word, const uint32_t* out8, int fb)
+{
+    const u16x2 one = {1, 1};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, out8[p]), one));
+        word |= y << (8 * (fb & 1) + p);
+    }
+    return word;
+}
+// this lane's NW = width/64 gate dwords of sample s in a gate region of `width` features
+template <int NW>
+__device__ __forceinline__ void store_gates(uint16_t* region, int width, int s, int hi, const uint32_t (&w)[NW])
+{
+    if (s < 0) return;
+    uint32_t* p = reinterpret_cast<uint32_t*>(region) + (size_t)s * (width / 32) + hi * NW;
+    if constexpr (NW == 4) { u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; *reinterpret_cast<u32x4*>(p) = v; }
+    else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) p[i] = w[i];
+    }
+}
+template <int NW>
+__device__ __forceinline__ void load_gates(const uint16_t* region, int width, int s, int hi, uint32_t (&w)[NW])
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(region) + (size_t)(s < 0 ? 0 : s) * (width / 32) + hi * NW;
+    if constexpr (NW == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(p); w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3]; }
+    else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = p[i];
+    }
+}
+// gate bits of a whole (packed bf16, post-ReLU) layer output of NR = 8 * blocks registers
+template <int NR>
+__device__ __forceinline__ void save_gates(uint16_t* region, int s, int hi, const uint32_t (&regs)[NR])
+{
+    constexpr int NW = NR / 16;
+    uint32_t w[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = 0;
+#pragma unroll
+    for (int fb = 0; fb < NR / 8; ++fb) w[fb / 2] = gate_bits_or(w[fb / 2], &regs[fb * 8], fb);
+    store_gates<NW>(region, NR * 4, s, hi, w);
+}
+// packed bf16x2 gradient gated by the two gate bits of (block fb, register p) of gate word g
+__device__ __forceinline__ uint32_t gate_apply(uint32_t packed, uint32_t g, int fb, int p)
+{
+    const int sh = 8 * (fb & 1) + p;
+    const uint32_t mlo = (uint32_t)__builtin_amdgcn_sbfe((int)g, sh, 1), mhi = (uint32_t)__builtin_amdgcn_sbfe((int)g, 16 + sh, 1);
+    return packed & ((mlo & 0x0000ffffu) | (mhi & 0xffff0000u));
 }
 
 enum { MODE_RELU = 0, MODE_LINEAR = 1 };

@@ -96,7 +96,12 @@ static inline int pnr_seg_vl(int kind, int nfeat) { return kind == PNR_SEG_GX ? 
 //             [4+l] DY_l, l < D (W)  [4+D] total
 // Slot order of a width-n feature tensor: slot fb*32 + hi*16 + r <-> feature fb*32 + row(r,hi); of EX: slot
 // hi*32 + v <-> pnr_seg_col(GX, L, hi, v); of ED: slot hi*16 + v <-> pnr_seg_col(GD, L, hi, v).
-static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* acts_off, int64_t* dys_off)
+//   gate_off (optional, same indexing as acts_off; entries of tensors without a ReLU are -1): ONE BIT per element of every
+//             ReLU output -- X_1..X_D, G, SH_sem, SH_inst -- appended to the acts buffer (acts_off[6+D] = grand total).  The
+//             data-gradient pass gates with these (32 B per sample and 256-wide layer) instead of re-reading the bf16
+//             activations (512 B).  Per sample w/32 dwords: lane (n, hi) owns dwords hi*(w/64) .. ; dword j covers the
+//             32-row blocks 2j, 2j+1; bit 8*(fb&1) + p <-> slot fb*32 + hi*16 + 2p, bit 16 + 8*(fb&1) + p <-> slot .. + 2p + 1.
+static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* acts_off, int64_t* dys_off, int64_t* gate_off = nullptr)
 {
     int64_t o = 0;
     auto take = [&](int64_t w) { const int64_t r = o; o += w * S; o = (o + 7) & ~(int64_t)7; return r; };
@@ -107,6 +112,15 @@ static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* a
     acts_off[3 + d.D] = take(d.W / 2);
     acts_off[4 + d.D] = take(d.W / 2);
     acts_off[5 + d.D] = take(d.W / 2);
+    {
+        int64_t g[24];
+        for (int i = 0; i < 24; ++i) g[i] = -1;
+        for (int l = 0; l < d.D; ++l) g[2 + l] = take(d.W / 16);          // bf16 units: w bits = w/16 units per sample
+        g[3 + d.D] = take(d.W / 32);
+        g[4 + d.D] = take(d.W / 32);
+        g[5 + d.D] = take(d.W / 32);
+        if (gate_off) for (int i = 0; i < 24; ++i) gate_off[i] = g[i];
+    }
     acts_off[6 + d.D] = o;
     o = 0;
     dys_off[0] = take(d.W / 2);

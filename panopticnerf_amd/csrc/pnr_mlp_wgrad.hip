@@ -19,6 +19,7 @@
 //     and un-permutes slots into the nn.Linear layout, so no atomics and no host-side index maps are needed.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <type_traits>
 
 #include "pnr_common.h"
 #include "pnr_mlp_layout.h"
@@ -33,23 +34,22 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 
-// LDS ring: WG_NBUF buffers of WG_KT-sample tiles, WG_NBUF - 1 tiles requested ahead (counted vmcnt).  Measured at
-// 786 K samples (tools/train_profile.py, same box): 64 x 2 buffers 2.89 ms, 48 x 3: 3.19, 32 x 4: 3.61, 32 x 5: 3.61 --
-// deeper prefetch does not pay, smaller tiles cost: the kernel is not waiting for HBM latency.
+// LDS: two buffers of WG_KT-sample tile pairs (A = dY tile | B = X tile), the next pair requested while the current one
+// is consumed.  Measured at 786 K samples (tools/train_profile.py, same box) with the round-1 loop: 64 x 2 buffers 2.89 ms,
+// 48 x 3: 3.19, 32 x 4: 3.61 -- deeper prefetch of smaller tiles does not pay: the loop was not waiting for HBM latency but
+// for itself (every fragment read and MFMA sat behind a run-time shape test and its own s_waitcnt).  Hence the shape
+// specialisation and the explicit software pipeline below.
 #ifndef WG_KT
 #define WG_KT 64                    /* samples per LDS tile (a multiple of the 16-sample k-step) */
-#endif
-#ifndef WG_NBUF
-#define WG_NBUF 2
 #endif
 #ifndef WG_DMA_AUX
 #define WG_DMA_AUX 2                /* cache policy of the tile loads: 0 default, 2 nt (every byte is read once per job): -3 % */
 #endif
-#ifndef WG_SPREAD
-#define WG_SPREAD 0                 /* 1: the next tile's pieces are issued between the k-steps instead of en bloc: +30 % time */
+#ifndef WG_ISSUE_SPLIT
+#define WG_ISSUE_SPLIT 0            /* 1: the next tile's LDS-DMA pieces are issued between the k-steps instead of en bloc */
 #endif
 #define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
-static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && 2 * WG_NBUF * WG_TILE_BYTES <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
+static_assert(WG_KT % 16 == 0 && 4 * WG_TILE_BYTES <= 163840, "wgrad tile pair does not fit the 160 KiB LDS twice");
 #define WG_MAX_JOBS 24
 #define WG_BIAS_COLS 32             /* partial block: [ma][nb + 32], column nb = row sum (bias gradient) */
 
@@ -66,140 +66,230 @@ struct WgArgs {
 };
 
 // 16 B chunk swizzle of a tile row with `cpr` chunks: bits 2..3 (bit 2) of the chunk index are XORed with the row
-__device__ __forceinline__ int wg_swz(int row, int cpr) { return cpr >= 16 ? ((row & 3) << 2) : cpr == 8 ? (((row >> 1) & 1) << 2) : 0; }
+__host__ __device__ constexpr int wg_swz(int row, int cpr) { return cpr >= 16 ? ((row & 3) << 2) : cpr == 8 ? (((row >> 1) & 1) << 2) : 0; }
 
-__global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
+// How the 8 waves tile an (MB x NB)-block gradient: a WM x WN grid of waves, TM x TN blocks of 32 x 32 per wave.  As many
+// waves as the shape allows, then the fewest fragment reads per k-step (TM + TN).
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void pp_static_for_wg(F&& f)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [WG_NBUF][A tile | B tile]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int jb = blockIdx.x / a.n_slabs, slab = blockIdx.x - jb * a.n_slabs;
-    const int ma = a.job[jb].ma, nb = a.job[jb].nb;
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); pp_static_for_wg<N, F, I + 1>(static_cast<F&&>(f)); }
+}
+// N fragments: ds_read_b64_tr_b16 at addr[i] + OFF and + OFF + STEP (rows ks*16 and ks*16 + 4 of the tile)
+template <int OFF, int STEP, int N>
+__device__ __forceinline__ void wg_load_frags(const int (&addr)[N], bf16x8 (&f)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        i16x4 lo, hi4;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr[i]), "n"(OFF));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi4) : "v"(addr[i]), "n"(OFF + STEP));
+        f[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+template <int PENDING, int TM, int TN>
+__device__ __forceinline__ void wg_landed(bf16x8 (&fa)[TM], bf16x8 (&fb)[TN])
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[0]) : "n"(PENDING));
+#pragma unroll
+    for (int i = 1; i < TM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[j]));
+}
+struct WgGridT { int wm, wn; };
+constexpr WgGridT wg_grid(int MB, int NB)
+{
+    WgGridT best{1, 1};
+    int score = -1;
+    for (int wm = 1; wm <= 8 && wm <= MB; wm *= 2) {
+        int wn = 8 / wm < NB ? 8 / wm : NB;
+        const int sc = wm * wn * 100 - (MB / wm + NB / wn);
+        if (sc > score) { score = sc; best = WgGridT{wm, wn}; }
+    }
+    return best;
+}
+
+// One (job, slab) of shape MB x NB blocks: partial[ma][nb + 32] = sum over the slab's samples of dY^T [X | 1].
+template <int MB, int NB>
+__device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const int jb, const int slab, const int lane, const int wave)
+{
+    constexpr WgGridT G = wg_grid(MB, NB);
+    constexpr int WM = G.wm, WN = G.wn, TM = MB / WM, TN = NB / WN;
+    constexpr int cprA = MB * 4, cprB = NB * 4;                     // 16 B chunks per tile row
+    constexpr int rbA = cprA * 16, rbB = cprB * 16;                 // row bytes
+    constexpr int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB;
+    constexpr int NQ = (pieces + 7) / 8;                            // LDS-DMA pieces per wave and tile (at most)
+    constexpr int NKS = WG_KT / 16;
+
     const uint16_t* const Ag = a.dys + a.job[jb].a_off;
     const uint16_t* const Bg = a.acts + a.job[jb].b_off;
     const int s_begin = slab * a.slab;
     const int s_end = a.S < s_begin + a.slab ? a.S : s_begin + a.slab;
     const int ntiles = (s_end - s_begin + WG_KT - 1) / WG_KT;
-    const int cprA = ma >> 3, cprB = nb >> 3;                       // 16 B chunks per tile row
-    const int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64;
 
-    // ---- LDS-DMA of tile t into buffer buf: piece p of an operand covers 64 consecutive chunk positions
-    auto issue = [&](int t, int buf, int part = 0, int nparts = 1) {     // part / nparts: this wave's pieces split round-robin
+    // ---- LDS-DMA: piece p of an operand covers 64 consecutive 16 B chunk positions of its tile.  LDS-DMA writes LDS
+    // linearly, so the bank swizzle is applied on the SOURCE side: each lane fetches the chunk its position holds.
+    int pr[NQ], pc[NQ];                                             // tile row / byte offset in the row of this lane's chunk
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = wave + 8 * q;
+        const bool isA = p < piecesA;
+        const int pp = isA ? p : p - piecesA;
+        const int cpr = isA ? cprA : cprB;
+        const int lg = isA ? __builtin_ctz(cprA) : __builtin_ctz(cprB);
+        pr[q] = pp * (64 >> lg) + (lane >> lg);
+        pc[q] = ((lane & (cpr - 1)) ^ (isA ? wg_swz(pr[q], cprA) : wg_swz(pr[q], cprB))) * 16;
+    }
+    auto issue = [&](int t, int buf, int q0, int q1) {
         const int s0 = s_begin + t * WG_KT;
-        char* const dA = smem + buf * 2 * WG_TILE_BYTES;
-        for (int p = wave + 8 * part; p < piecesA + piecesB; p += 8 * nparts) {
+        char* const dst = smem + buf * 2 * WG_TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q < q0 || q >= q1) continue;
+            const int p = wave + 8 * q;
+            if (p >= pieces) continue;
             const bool isA = p < piecesA;
             const int pp = isA ? p : p - piecesA;
-            const int cpr = isA ? cprA : cprB;
-            const int lg = 31 - __builtin_clz(cpr);                 // cpr is a power of two
-            const int r = pp * (64 >> lg) + (lane >> lg);           // tile row of this lane's chunk position
-            const int c = (lane & (cpr - 1)) ^ wg_swz(r, cpr);      // global chunk that lives at this position
-            const int srow = s0 + r;
-            const char* src = srow < s_end ? reinterpret_cast<const char*>((isA ? Ag : Bg) + (int64_t)srow * (cpr * 8)) + c * 16
-                                           : reinterpret_cast<const char*>(a.zeros) + c * 16;
-            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dA + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
+            const int srow = s0 + pr[q];
+            const char* src = srow < s_end ? reinterpret_cast<const char*>(isA ? Ag : Bg) + (int64_t)srow * (isA ? rbA : rbB) + pc[q]
+                                           : reinterpret_cast<const char*>(a.zeros) + pc[q];
+            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dst + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
         }
     };
 
-    // ---- this wave's 32x32 tiles: row blocks 2*wm + {0,1}, column blocks 4*wn + {0..3}
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nMb = ma >> 5, nNb = nb >> 5;
+    // ---- this wave's blocks: rows wm*TM + i, columns wn*TN + j; its bias blocks: i = wn, wn + WN, ... (< TM)
+    const bool active = wave < WM * WN;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int al = lane & 15, gq = lane >> 4, hi = gq >> 1;
     const int rsub = 8 * hi + (al >> 2);                            // row within a 16-sample k-step (first half-read)
-    const int sxA = cprA >= 16 ? (rsub & 3) : cprA == 8 ? ((rsub >> 1) & 1) : 0;
-    const int sxB = cprB >= 16 ? (rsub & 3) : cprB == 8 ? ((rsub >> 1) & 1) : 0;
     const int inblk = (2 * (gq & 1) + ((al & 3) >> 1)) * 16 + (al & 1) * 8;    // byte offset inside the 64 B block row
-    const int rbA = cprA * 16, rbB = cprB * 16;                     // row bytes
-    int offA[2], offB[4];
+    const int sxA = wg_swz(rsub, cprA) >> 2, sxB = wg_swz(rsub, cprB) >> 2;
+    int offA[TM], offB[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) offA[i] = rsub * rbA + (((2 * wm + i) ^ sxA) << 6) + inblk;
+    for (int i = 0; i < TM; ++i) offA[i] = rsub * rbA + (((wm * TM + i) ^ sxA) << 6) + inblk;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) offB[j] = WG_TILE_BYTES + rsub * rbB + (((4 * wn + j) ^ sxB) << 6) + inblk;
+    for (int j = 0; j < TN; ++j) offB[j] = rsub * rbB + (((wn * TN + j) ^ sxB) << 6) + inblk;
 
-    f32x16 acc[2][4], bacc[2];
+    static_assert(TM <= WN || (TM == 1 && WN == 1), "one bias block per wave at most");
+    const int isel = wn;                                            // the row block whose bias (row sum) this wave accumulates
+    const bool has_bias = wn < TM;
+    f32x16 acc[TM][TN], bacc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[r] = 0.0f;
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    auto frag = [&](const char* tile, int off, int ks, int rb) -> bf16x8 {
-        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + off + (ks * 16) * rb));
-        const i16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(tile + off + (ks * 16 + 4) * rb));
-        const i16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
-    };
-
-    // this wave's LDS-DMA pieces per tile (the same for every tile of the job): what a counted vmcnt may leave in flight
-    const int total_pieces = piecesA + piecesB;
-    const int n_mine = wave < total_pieces ? (total_pieces - wave + 7) / 8 : 0;
-    auto wait_but = [&](int n) {        // s_waitcnt takes an immediate: a ladder over the possible piece counts
-#define PNR_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        switch (n) {
-            PNR_VM(1) PNR_VM(2) PNR_VM(3) PNR_VM(4) PNR_VM(5) PNR_VM(6) PNR_VM(7) PNR_VM(8) PNR_VM(9) PNR_VM(10) PNR_VM(11) PNR_VM(12)
-            PNR_VM(13) PNR_VM(14) PNR_VM(15) PNR_VM(16) PNR_VM(17) PNR_VM(18) PNR_VM(19) PNR_VM(20) PNR_VM(21) PNR_VM(22) PNR_VM(23) PNR_VM(24)
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    if (!active) {      // shapes with fewer than 8 wave tiles: the spare waves only help moving the tiles
+        issue(0, 0, 0, NQ);
+        for (int t = 0; t < ntiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1, 0, NQ);
         }
-#undef PNR_VM
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // Fragment reads are inline asm with hand-counted waits: behind the builtin, hipcc puts s_waitcnt vmcnt(0) in front of
+    // every LDS read that follows an LDS-DMA request (it cannot tell the buffers apart) and lgkmcnt(0) in front of every
+    // MFMA, which serialises request -> land -> read -> multiply per k-step.  ds_read_b64_tr_b16 hands a lane 4 consecutive
+    // samples of its feature; the reads at rows ks*16 and ks*16 + 4 make one k = 16 MFMA operand.
+    bf16x8 fa[2][TM], fb[2][TN];
+    int adA[TM], adB[TN];
+    auto load = [&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        wg_load_frags<ks * 16 * rbA, 4 * rbA, TM>(adA, fa[ks & 1]);
+        wg_load_frags<WG_TILE_BYTES + ks * 16 * rbB, 4 * rbB, TN>(adB, fb[ks & 1]);
     };
+    // the fragments of k-step ks have landed once at most PENDING younger reads are outstanding (LDS reads return in order)
+    auto landed = [&](auto ks_c, auto pending_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        wg_landed<decltype(pending_c)::value, TM, TN>(fa[ks & 1], fb[ks & 1]);
+    };
+    auto mma = [&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        bf16x8 fsel = fa[ks & 1][0];
 #pragma unroll
-    for (int d = 0; d < WG_NBUF - 1; ++d)
-        if (d < ntiles) issue(d, d);
+        for (int i = 1; i < TM; ++i) fsel = isel == i ? fa[ks & 1][i] : fsel;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+        if (has_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fsel, ones, bacc, 0, 0, 0);
+    };
+    constexpr int RD = 2 * (TM + TN);                               // ds_reads per k-step
+    static_assert(RD <= 15, "lgkmcnt is a 4-bit counter");
+
+    issue(0, 0, 0, NQ);
     int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed once only the pieces of the younger tiles already requested are outstanding (VMEM operations
-        // of a wave complete in order)
-        const int ahead = ntiles - 1 - t < WG_NBUF - 2 ? ntiles - 1 - t : WG_NBUF - 2;
-        wait_but(n_mine * ahead);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of tile t
         __syncthreads();                                            // tile t landed for everybody; everybody is done with tile t-1
-        const bool more = t + WG_NBUF - 1 < ntiles;
-        const int nbuf = buf == 0 ? WG_NBUF - 1 : buf - 1;          // tile t-1's buffer
-        if (more && !WG_SPREAD) issue(t + WG_NBUF - 1, nbuf);
-        const char* tile = smem + buf * 2 * WG_TILE_BYTES;
-        buf = buf + 1 == WG_NBUF ? 0 : buf + 1;
+        const bool more = t + 1 < ntiles;
 #pragma unroll
-        for (int ks = 0; ks < WG_KT / 16; ++ks) {
-            if (more && WG_SPREAD) issue(t + WG_NBUF - 1, nbuf, ks, WG_KT / 16);
-            bf16x8 fa[2], fb[4];
+        for (int i = 0; i < TM; ++i) adA[i] = offA[i] + buf * 2 * WG_TILE_BYTES;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (2 * wm + i < nMb) fa[i] = frag(tile, offA[i], ks, rbA);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * wn + j < nNb) fb[j] = frag(tile, offB[j], ks, rbB);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (2 * wm + i >= nMb) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * wn + j < nNb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                if (wn == 0) bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, bacc[i], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < TN; ++j) adB[j] = offB[j] + buf * 2 * WG_TILE_BYTES;
+        // software pipeline: the fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued; the next
+        // tile's LDS-DMA goes out behind the first fragment requests, so only those are exposed per tile
+        load(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !WG_ISSUE_SPLIT) issue(t + 1, buf ^ 1, 0, NQ);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_static_for_wg<NKS>([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            if constexpr (ks + 1 < NKS) {
+                load(std::integral_constant<int, ks + 1>{});
+                landed(ks_c, std::integral_constant<int, RD>{});
+            } else landed(ks_c, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WG_ISSUE_SPLIT && ks < NKS - 1)
+                if (more) issue(t + 1, buf ^ 1, ks * NQ / (NKS - 1), (ks + 1) * NQ / (NKS - 1));
+            mma(ks_c);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        buf ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- partial sums of this (job, slab): [ma][nb + 32] fp32, slot order on both axes
-    const int ldp = nb + WG_BIAS_COLS;
-    float* const P = a.partial + a.job[jb].p_off + (int64_t)slab * ma * ldp;
+    constexpr int ldp = NB * 32 + WG_BIAS_COLS;
+    float* const P = a.partial + a.job[jb].p_off + (int64_t)slab * (MB * 32) * ldp;
     const int n = lane & 31, hl = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (2 * wm + i >= nMb) continue;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (2 * wm + i) * 32 + pnr_row_of(r, hl);
+            const int row = (wm * TM + i) * 32 + pnr_row_of(r, hl);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * wn + j < nNb) P[(int64_t)row * ldp + (4 * wn + j) * 32 + n] = acc[i][j][r];
-            if (wn == 0 && n == 0) P[(int64_t)row * ldp + nb] = bacc[i][r];
+            for (int j = 0; j < TN; ++j) P[(int64_t)row * ldp + (wn * TN + j) * 32 + n] = acc[i][j][r];
+            if (has_bias && i == isel && n == 0) P[(int64_t)row * ldp + NB * 32] = bacc[r];
         }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][A tile | B tile]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int jb = blockIdx.x / a.n_slabs, slab = blockIdx.x - jb * a.n_slabs;
+    // region widths are 32, 64, 128 or 256 slots: one straight-line instance of the loop per shape
+    const int shape = (31 - __builtin_clz(a.job[jb].ma >> 5)) * 4 + (31 - __builtin_clz(a.job[jb].nb >> 5));
+    switch (shape) {
+#define WG_CASE(mb, nb) case (mb) * 4 + (nb): wg_body<1 << (mb), 1 << (nb)>(a, smem, jb, slab, lane, wave); break;
+        WG_CASE(0, 0) WG_CASE(0, 1) WG_CASE(0, 2) WG_CASE(0, 3)
+        WG_CASE(1, 0) WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3)
+        WG_CASE(2, 0) WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3)
+        WG_CASE(3, 0) WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3)
+#undef WG_CASE
     }
 }
 
@@ -347,10 +437,10 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_NBUF * WG_TILE_BYTES));
+        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 2 * WG_NBUF * WG_TILE_BYTES, st, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 4 * WG_TILE_BYTES, st, a);
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
     WgRedArgs r;
     memset(&r, 0, sizeof(r));
