@@ -57,7 +57,7 @@ template <int PREC, int TILES, class CTX, int KIND, int NA, int NB, int NFB_OUT,
 __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][NA],
                                            const uint32_t (&inB)[TILES][NB > 0 ? NB : 1],
                                            uint32_t (&out)[TILES][NOUT], uint16_t* save = nullptr,
-                                           const int* samp = nullptr)
+                                           const int* srow = nullptr)
 {
     constexpr int RPB = PrecT<PREC>::RPB;
     constexpr int KS = NA / 4 + NB / 4;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
 #endif
                         out[t][fb * RPB + p] = v;
                     }
-                    if (save) store_slots(save, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][fb * RPB]);
+                    if (save) store_slots(save, NFB_OUT * 32, srow[t], fb, c.hi, &out[t][fb * RPB]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void layer_regs(CTX& c, const uint32_t (&inA)[TILES][
                 }
             }
         }
-        c.finish();
+        c.finish(save && PREC == PNR_PREC_BF16 ? 2 * FBC * TILES : 0);
     }
 }
 
@@ -254,13 +254,16 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 
     // persistent loop: one group = WAVES * TILES tiles of 32 samples
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
-        int samp[TILES];
+        int samp[TILES], srow[TILES];      // sample of this lane (-1 past the end) / its row in the saved tensors (padded)
         float vd[TILES][3];
         uint32_t ex[TILES][GXR];
+        // the last tile of the group is the first to run out of samples
+        c.st_full = TRAIN;                  // saves are unmasked: the store count per chunk is exact
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             const int s = ((grp * WAVES + c.wave) * TILES + t) * 32 + n;
             samp[t] = s < a.S ? s : -1;
+            srow[t] = s;
             const float4 o4 = nextin[t].o4, d4 = nextin[t].d4;
             const float zz = nextin[t].zz;
             const float dx = o4.w, dy = d4.x, dz = d4.y;
@@ -271,13 +274,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
             vd[t][0] = dx / nrm; vd[t][1] = dy / nrm; vd[t][2] = dz / nrm;
             embed_lane<PREC, 5, 32, GXR>(px, py, pz, c.hi, ex[t]);
-            if constexpr (TRAIN) {
-                if (samp[t] >= 0) {   // EX: [S][64], slot = hi*32 + v
-                    u32x4* p = reinterpret_cast<u32x4*>(a.acts + a.acts_off[0] + (size_t)samp[t] * 64 + c.hi * 32);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { u32x4 v; v[0] = ex[t][4 * k]; v[1] = ex[t][4 * k + 1]; v[2] = ex[t][4 * k + 2]; v[3] = ex[t][4 * k + 3]; p[k] = v; }
-                }
-            }
+            if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow[t], c.hi, ex[t]);
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
         // ReLU gate bits of a layer output for the data-gradient pass (pnr_train_layout: gate_off)
@@ -290,14 +287,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 
         // trunk
         uint32_t cur[TILES][HR], nxt[TILES][HR];
-        layer_regs<PREC, TILES, CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur, sv(2), samp);
+        layer_regs<PREC, TILES, CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, ex, dummy, cur, sv(2), srow);
         gv(2, cur);
 #pragma unroll 1
         for (int l = 1; l < a.D; ++l) {
             if (l - 1 == a.skip)
-                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt, sv(2 + l), samp);
+                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, ex, cur, nxt, sv(2 + l), srow);
             else
-                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt, sv(2 + l), samp);
+                layer_regs<PREC, TILES, CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, cur, dummy, nxt, sv(2 + l), srow);
             gv(2 + l, nxt);
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
@@ -307,13 +304,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         // heads (h = cur stays live until the rgb/sigma block)
         if (a.n_sem) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), samp);
+            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), srow);
             gv(4 + a.D, sh);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), samp);
+            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
@@ -323,15 +320,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #pragma unroll
             for (int t = 0; t < TILES; ++t) nextin[t] = fetch(g2, t);
         }
-        layer_regs<PREC, TILES, CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt, sv(2 + a.D), samp);
+        layer_regs<PREC, TILES, CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, cur, dummy, nxt, sv(2 + a.D), srow);
         uint32_t ed[TILES][GDR];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             embed_lane<PREC, 2, 16, GDR>(vd[t][0], vd[t][1], vd[t][2], c.hi, ed[t]);
-            if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp[t], 0, c.hi, ed[t]);   // ED: [S][32]
+            if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, srow[t], 0, c.hi, ed[t]);   // ED: 32 slots
         }
         uint32_t g[TILES][GR];
-        layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), samp);
+        layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
 #if PNR_TRACE
@@ -358,7 +355,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
 __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
                                               const uint32_t (&inB)[NB > 0 ? NB : 1], uint32_t (&out)[NOUT],
-                                              uint16_t* save, int samp)
+                                              uint16_t* save, int srow)
 {
     constexpr int FBC0 = pnr_layer_fbc(KIND, PNR_PREC_BF16);
     constexpr int FBC = (NFB_OUT % FBC0 == 0) ? FBC0 : 1;      // mirrors pnr_build_plan
@@ -398,7 +395,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         for (int b = 0; b < FBC; ++b) {
             c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
             if (b >= PNR_PP_EPI_IN_M) epilogue(b);
-            if (save) store_slots(save, NFB_OUT * 32, samp, cb * FBC + b, c.hi, &out[(cb * FBC + b) * 8]);
+            if (save) store_slots(save, NFB_OUT * 32, srow, cb * FBC + b, c.hi, &out[(cb * FBC + b) * 8]);
         }
         if (PNR_PP_EARLY_BIAS && nxt_same) CH::bias_issue(c.next_bias_addr(), q);   // accumulators free: next chunk's bias, asynchronous
         c.refill_rest();
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int s0 = (grp * WAVES + c.wave) * 32 + n;
-        const int samp = s0 < a.S ? s0 : -1;
+        const int samp = s0 < a.S ? s0 : -1, srow = s0;
         float vd[3];
         uint32_t ex[GXR];
         {
@@ -493,13 +490,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
             vd[0] = dx / nrm; vd[1] = dy / nrm; vd[2] = dz / nrm;
             embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
-            if constexpr (TRAIN) {
-                if (samp >= 0) {   // EX: [S][64], slot = hi*32 + v
-                    u32x4* p = reinterpret_cast<u32x4*>(a.acts + a.acts_off[0] + (size_t)samp * 64 + c.hi * 32);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { u32x4 v; v[0] = ex[4 * k]; v[1] = ex[4 * k + 1]; v[2] = ex[4 * k + 2]; v[3] = ex[4 * k + 3]; p[k] = v; }
-                }
-            }
+            if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow, c.hi, ex);
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
@@ -507,13 +498,13 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], samp, c.hi, regs);
         };
         uint32_t cur[HR], nxt[HR];
-        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), samp);
+        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), srow);
         gv(2, cur);
         auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
             if (l - 1 == a.skip)
-                pp_layer_regs<CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, A, ex, in, out, sv(2 + l), samp);
+                pp_layer_regs<CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR>(c, A, ex, in, out, sv(2 + l), srow);
             else
-                pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, A, in, dummy, out, sv(2 + l), samp);
+                pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, A, in, dummy, out, sv(2 + l), srow);
             gv(2 + l, out);
         };
 #if PNR_PP_UNROLL2
@@ -538,13 +529,13 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #endif
         if (a.n_sem) {
             uint32_t sh[GR];
-            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), samp);
+            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), srow);
             gv(4 + a.D, sh);
             pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
         }
         if (a.n_inst) {
             uint32_t sh[GR];
-            pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), samp);
+            pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
             pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
         }
@@ -552,12 +543,12 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
             nextin = fetch(g2);
         }
-        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), samp);
+        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), srow);
         uint32_t ed[GDR];
         embed_lane<PNR_PREC_BF16, 2, 16, GDR>(vd[0], vd[1], vd[2], c.hi, ed);
-        if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, samp, 0, c.hi, ed);   // ED: [S][32]
+        if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, srow, 0, c.hi, ed);   // ED: 32 slots
         uint32_t g[GR];
-        pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), samp);
+        pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         pp_layer_out<TRAIN, CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
 #if PNR_TRACE

@@ -26,16 +26,16 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 // One backward layer.  in: NA B registers (k-segments concatenated).  out[t][OFF + fb*8 + p].
 // gate  : the ReLU gate BITS of the layer's forward output ([S][NFB_OUT] dwords, pnr_train_layout; nullptr: linear):
 //         NFB_OUT/2 dwords per lane, loaded once per layer, instead of the 16 x NFB_OUT bytes of bf16 activations
-// store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient (nullptr: not stored)
-template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF>
+// store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient
+template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF, bool GATED = true>
 __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
-                                          const uint16_t* gate, uint16_t* store, const int (&samp)[TILES])
+                                          const uint16_t* gate, uint16_t* store, const int (&samp)[TILES], const int (&srow)[TILES])
 {
     constexpr int FBC = 2, G = 2;
     static_assert(NFB_OUT % FBC == 0 && NOUT >= OFF + NFB_OUT * 8, "bad backward layer geometry");
     uint32_t dummy[TILES][1];
     uint32_t gw[TILES][NFB_OUT / 2];
-    if (gate) {
+    if constexpr (GATED) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) load_gates<NFB_OUT / 2>(gate, NFB_OUT * 32, samp[t], c.hi, gw[t]);
     }
@@ -50,7 +50,9 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.0f;
+        c.stamp(2);
         mma_chunk<PNR_PREC_BF16, TILES, FBC, G, NA, 0>(base + c.lane * 16, in, dummy, acc);
+        c.stamp(3);
 #pragma unroll
         for (int b = 0; b < FBC; ++b) {
             const int fb = cb * FBC + b;
@@ -59,12 +61,14 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const uint32_t v = pack_bf16(acc[b][t][2 * p], acc[b][t][2 * p + 1]);
-                    out[t][OFF + fb * 8 + p] = gate ? gate_apply(v, gw[t][fb / 2], fb, p) : v;
+                    out[t][OFF + fb * 8 + p] = GATED ? gate_apply(v, gw[t][fb / 2], fb, p) : v;
                 }
-                if (store) store_slots(store, NFB_OUT * 32, samp[t], fb, c.hi, &out[t][OFF + fb * 8]);
+                // (stores before the hand-over: moving them behind finish() -- so that its vmcnt(0) would not wait for this
+                // chunk's write acknowledgements -- measured +17 % time: the gradient registers stay live across the barrier)
+                store_slots(store, NFB_OUT * 32, srow[t], fb, c.hi, &out[t][OFF + fb * 8]);
             }
         }
-        c.finish();
+        c.finish(2 * FBC * TILES);
     }
 }
 
@@ -100,6 +104,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
 
     CTX c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
           (int)((threadIdx.x & 63) >> 5), 0, 0, {0, 0}, {0, 0}};
+#if PNR_TRACE
+    c.tr = reinterpret_cast<unsigned long long*>(smem + 2 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.titer = 0;
+#endif
     const int n = c.lane & 31;
     c.start();
     const int D = a.D;
@@ -107,58 +115,70 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
     uint16_t* const dys = a.dys;
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
-        int samp[TILES];
+        int samp[TILES], srow[TILES];       // sample (-1 past the end) / row in the saved tensors
         {
             const int s = ((grp * WAVES + c.wave) * TILES) * 32 + n;
             samp[0] = s < a.S ? s : -1;
+            srow[0] = s;
+            c.st_full = true;               // stores are unmasked (rows S..S_pad receive zeros): exact store count per chunk
         }
         uint32_t cat[TILES][CATR];
 #pragma unroll
         for (int i = 0; i < CATR; ++i) cat[0][i] = 0;
         uint32_t drs[TILES][8];
         load_draw<1>(a, samp[0], c.hi, 0, 4, drs[0]);
-        store_slots(dys + a.dys_off[4 + D], 32, samp[0], 0, c.hi, drs[0]);        // dY of [rgb, sigma] for the wgrad
+        store_slots(dys + a.dys_off[4 + D], 32, srow[0], 0, c.hi, drs[0]);        // dY of [rgb, sigma] for the wgrad
 #pragma unroll
         for (int i = 0; i < 8; ++i) cat[0][HR + i] = drs[0][i];
 
         // d g = W_rgb^T d rgb ; gate by g ; -> dY_views
         uint32_t dyv[TILES][GR];
-        layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.gate_off[3 + D], dys + a.dys_off[0], samp);
+        layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.gate_off[3 + D], dys + a.dys_off[0], samp, srow);
         // d f = W_views[:, :W]^T dY_views  (feature_linear has no activation) -> dY_feature
-        layer_bwd<TILES, CTX, GR, NFB, CATR, 0>(c, dyv, cat, nullptr, dys + a.dys_off[1], samp);
+        layer_bwd<TILES, CTX, GR, NFB, CATR, 0, false>(c, dyv, cat, nullptr, dys + a.dys_off[1], samp, srow);
         if (a.n_sem) {
             uint32_t ds[TILES][OBR];
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
 #pragma unroll
-            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &ds[0][b * 8]);
-            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp);
+            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &ds[0][b * 8]);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp, srow);
         }
         if (a.n_inst) {
             uint32_t di[TILES][OBR];
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
 #pragma unroll
-            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, samp[0], b, c.hi, &di[0][b * 8]);
-            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp);
+            for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &di[0][b * 8]);
+            layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
         uint32_t dy[TILES][HR], dn[TILES][HR];
-        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp);
+        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
         // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
 #pragma unroll 1
         for (int l = D - 1; l >= 1; --l) {
-            layer_bwd<TILES, CTX, HR, NFB, HR, 0>(c, dy, dn, acts + a.gate_off[1 + l], dys + a.dys_off[3 + l], samp);
+            layer_bwd<TILES, CTX, HR, NFB, HR, 0>(c, dy, dn, acts + a.gate_off[1 + l], dys + a.dys_off[3 + l], samp, srow);
 #pragma unroll
             for (int i = 0; i < HR; ++i) dy[0][i] = dn[0][i];
         }
+#if PNR_TRACE
+        ++c.titer;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if PNR_TRACE
+    __syncthreads();
+    if (blockIdx.x == 0 && a.trace) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 2 * a.slot_bytes);
+        for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
+    }
+#endif
 }
 
 template <int W, int WAVES>
 static int launch_bwd(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
-    const int lds_bytes = 2 * a.slot_bytes;
+    const int lds_bytes = 2 * a.slot_bytes + (PNR_TRACE ? WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
     PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_backward: weight double buffer of %d bytes exceeds the 160 KiB LDS", lds_bytes);
     const int per_group = 32 * WAVES;
     a.n_groups = (a.S + per_group - 1) / per_group;
@@ -201,6 +221,9 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
     pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
+#if PNR_TRACE
+    if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     hipStream_t st = (hipStream_t)stream;
     return desc->W == 256 ? launch_bwd<256, PNR_BWD_WAVES>(a, st) : launch_bwd<128, PNR_BWD_WAVES>(a, st);
 }

@@ -33,19 +33,40 @@ struct MlpArgs {
     int64_t acts_off[24], dys_off[24], gate_off[24];     // pnr_train_layout (bf16 units)
 };
 
-// 16 consecutive slots (one 32-row block's share of lane (n,hi)) of a slot-ordered [S][width] bf16 tensor
-__device__ __forceinline__ uint16_t* slot_ptr(uint16_t* base, int width, int s, int fb, int hi)
-{
-    return base + (size_t)s * width + fb * 32 + hi * 16;
-}
+#ifndef PNR_ABL_STORE
+#define PNR_ABL_STORE 0
+#endif
+// One 32-row block's share of lane (n, hi) -- 16 slots = chunks fb*4 + hi*2 + {0, 1} -- of padded sample row s into a
+// saved region (pnr_mlp_layout.h: the two chunks sit in neighbouring lines at the same position).  Unmasked: rows
+// S..S_pad are written as well.
 __device__ __forceinline__ void store_slots(uint16_t* base, int width, int s, int fb, int hi, const uint32_t* r8)
 {
-    if (s < 0) return;
-    u32x4* p = reinterpret_cast<u32x4*>(slot_ptr(base, width, s, fb, hi));
+#if PNR_ABL_STORE == 3          /* ablation: every workgroup writes the same 256 rows (L2-resident target, results invalid) */
+    s &= 255;
+#endif
+    u32x4* p = reinterpret_cast<u32x4*>(base + pnr_saved_chunk(width >> 3, s, fb * 4 + hi * 2));
     u32x4 a, b;
     a[0] = r8[0]; a[1] = r8[1]; a[2] = r8[2]; a[3] = r8[3];
     b[0] = r8[4]; b[1] = r8[5]; b[2] = r8[6]; b[3] = r8[7];
-    p[0] = a; p[1] = b;
+#if PNR_ABL_STORE == 1          /* ablation: no activation / gradient stores (results invalid) */
+    asm volatile("" :: "v"(a), "v"(b), "v"(p));
+#elif PNR_ABL_STORE == 2        /* nontemporal: 1.8 -> 3.0 ms (sc0 / sc1 / sc0 sc1 scopes: +-0 / +-0 / +8 %) */
+    __builtin_nontemporal_store(a, p); __builtin_nontemporal_store(b, p + 8);
+#else
+    p[0] = a; p[8] = b;
+#endif
+}
+
+// gamma(x) of lane (n, hi): 32 slots hi*32 + v = chunks hi*4 + k of a 64-slot saved region
+template <int NR>
+__device__ __forceinline__ void store_ex(uint16_t* base, int s, int hi, const uint32_t (&ex)[NR])
+{
+    static_assert(NR == 16, "bf16 gamma(x): 16 packed registers per lane");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32x4 v; v[0] = ex[4 * k]; v[1] = ex[4 * k + 1]; v[2] = ex[4 * k + 2]; v[3] = ex[4 * k + 3];
+        *reinterpret_cast<u32x4*>(base + pnr_saved_chunk(8, s, hi * 4 + k)) = v;
+    }
 }
 
 // ReLU gate bits of one 32-row block (8 packed bf16x2 registers, post-ReLU) into the lane's gate word of the block PAIR:
@@ -167,6 +188,7 @@ struct Ctx {
     int lane, wave, hi;
     int ci, slot;
     pnr_chunk_entry e1, e2;            // table entries of chunks ci+1, ci+2 (scalar loads, fetched a chunk early)
+    bool st_full = false;              // every lane of this wave holds a valid sample: its store count per chunk is exact
 #if PNR_TRACE
     unsigned long long* tr;            // LDS trace area of this wave: [PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
     int titer;
@@ -212,10 +234,17 @@ struct Ctx {
     __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
     __device__ __forceinline__ void begin() { stamp(0); issue(e1, slot ^ 1); stamp(1); }
     // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
-    __device__ __forceinline__ void finish()
+    // nst: activation / gradient store INSTRUCTIONS this wave issued since begin().  Vector-memory operations of a wave
+    // complete in order, so "at most nst outstanding" means the LDS-DMA pieces (older) have landed while the stores
+    // drain under the next chunk's MFMAs -- without it every chunk pays an HBM write acknowledgement (measured: 0.6 ms
+    // of the 1.8 ms training forward, 0.7 ms of the data-gradient pass).  A wave with invalid lanes may have skipped
+    // stores (execz), so it waits for everything.
+    __device__ __forceinline__ void finish(int nst = 0)
     {
         stamp(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (st_full && nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (st_full && nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(5);
         __syncthreads();
         stamp(6);

@@ -89,7 +89,15 @@ PNR_HD static inline int pnr_seg_col(int kind, int L, int hi, int v)
 // values per lane of a segment
 static inline int pnr_seg_vl(int kind, int nfeat) { return kind == PNR_SEG_GX ? 32 : kind == PNR_SEG_GD ? 16 : nfeat / 2; }
 
-// Training buffers (bf16 elements; every region is a slot-ordered [S][width] tensor, 16-byte aligned).
+// Training buffers (bf16 elements; every region is a slot-ordered [S_pad][width] tensor in the SAVED-TENSOR layout below).
+// Saved-tensor layout: the unit is the 16-byte chunk c = slot / 8 of sample s; a 128-byte line holds chunk c of the 8
+// samples of group s >> 3, lines are ordered [s >> 3][c], and inside a line sample s sits at position
+// (s & 7) ^ (4 * ((c >> 1) & 1)).  Why: (1) a wave's store instruction (32 samples x 2 half-waves, one chunk each) then
+// writes 8 FULL lines instead of touching 32 -- at [S][width] rows the training forward and the data-gradient pass spent
+// a third of their time in the texture-address unit (no-store ablation: 1.82 -> 1.25 ms and 1.81 -> 1.13 ms);
+// (2) k_wgrad's LDS-DMA copies 1 KiB pieces verbatim (8 lines, contiguous on both sides) and its transposing reads
+// (ds_read_b64_tr_b16: 16 lanes = 4 samples x 2 chunks) hit all 64 banks once per half-wave thanks to the XOR.
+// S_pad = S rounded up to 256 (a workgroup's samples): the kernels write the padding rows too (dY: zeros).
 //   acts_off: [0] EX (64)  [1] ED (32)  [2+l] X_{l+1}, l < D (W)  [2+D] F (W)  [3+D] G (W/2)
 //             [4+D] SH_sem (W/2)  [5+D] SH_inst (W/2)  [6+D] total
 //   dys_off : [0] DY_views (W/2)  [1] DY_feature (W)  [2] DY_sem0 (W/2)  [3] DY_inst0 (W/2)
@@ -101,10 +109,17 @@ static inline int pnr_seg_vl(int kind, int nfeat) { return kind == PNR_SEG_GX ? 
 //             data-gradient pass gates with these (32 B per sample and 256-wide layer) instead of re-reading the bf16
 //             activations (512 B).  Per sample w/32 dwords: lane (n, hi) owns dwords hi*(w/64) .. ; dword j covers the
 //             32-row blocks 2j, 2j+1; bit 8*(fb&1) + p <-> slot fb*32 + hi*16 + 2p, bit 16 + 8*(fb&1) + p <-> slot .. + 2p + 1.
-static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S, int64_t* acts_off, int64_t* dys_off, int64_t* gate_off = nullptr)
+PNR_HD static inline int64_t pnr_pad_samples(int64_t S) { return (S + 255) & ~(int64_t)255; }
+// element offset of chunk c (slots 8c..8c+7) of sample s in a saved region of cpr = width / 8 chunks per sample
+PNR_HD static inline int64_t pnr_saved_chunk(int cpr, int64_t s, int c)
 {
+    return (((s >> 3) * cpr + c) << 6) + ((((int)s & 7) ^ (((c >> 1) & 1) << 2)) << 3);
+}
+static inline void pnr_train_layout(const pnr_mlp_desc& d, int64_t S0, int64_t* acts_off, int64_t* dys_off, int64_t* gate_off = nullptr)
+{
+    const int64_t S = pnr_pad_samples(S0);
     int64_t o = 0;
-    auto take = [&](int64_t w) { const int64_t r = o; o += w * S; o = (o + 7) & ~(int64_t)7; return r; };
+    auto take = [&](int64_t w) { const int64_t r = o; o += w * S; o = (o + 63) & ~(int64_t)63; return r; };
     acts_off[0] = take(64);
     acts_off[1] = take(32);
     for (int l = 0; l < d.D; ++l) acts_off[2 + l] = take(d.W);

@@ -65,9 +65,6 @@ struct WgArgs {
     WgJob job[WG_MAX_JOBS];
 };
 
-// 16 B chunk swizzle of a tile row with `cpr` chunks: bits 2..3 (bit 2) of the chunk index are XORed with the row
-__host__ __device__ constexpr int wg_swz(int row, int cpr) { return cpr >= 16 ? ((row & 3) << 2) : cpr == 8 ? (((row >> 1) & 1) << 2) : 0; }
-
 // How the 8 waves tile an (MB x NB)-block gradient: a WM x WN grid of waves, TM x TN blocks of 32 x 32 per wave.  As many
 // waves as the shape allows, then the fewest fragment reads per k-step (TM + TN).
 template <int N, class F, int I = 0>
@@ -75,15 +72,15 @@ __device__ __forceinline__ void pp_static_for_wg(F&& f)
 {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); pp_static_for_wg<N, F, I + 1>(static_cast<F&&>(f)); }
 }
-// N fragments: ds_read_b64_tr_b16 at addr[i] + OFF and + OFF + STEP (rows ks*16 and ks*16 + 4 of the tile)
-template <int OFF, int STEP, int N>
-__device__ __forceinline__ void wg_load_frags(const int (&addr)[N], bf16x8 (&f)[N])
+// N fragments: ds_read_b64_tr_b16 at addr[i] + OFF (samples 0..3 of this lane's k-half) and addr2[i] + OFF (samples 4..7)
+template <int OFF, int N>
+__device__ __forceinline__ void wg_load_frags(const int (&addr)[N], const int (&addr2)[N], bf16x8 (&f)[N])
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         i16x4 lo, hi4;
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr[i]), "n"(OFF));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi4) : "v"(addr[i]), "n"(OFF + STEP));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi4) : "v"(addr2[i]), "n"(OFF));
         f[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 }
@@ -116,7 +113,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     constexpr WgGridT G = wg_grid(MB, NB);
     constexpr int WM = G.wm, WN = G.wn, TM = MB / WM, TN = NB / WN;
     constexpr int cprA = MB * 4, cprB = NB * 4;                     // 16 B chunks per tile row
-    constexpr int rbA = cprA * 16, rbB = cprB * 16;                 // row bytes
     constexpr int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB;
     constexpr int NQ = (pieces + 7) / 8;                            // LDS-DMA pieces per wave and tile (at most)
     constexpr int NKS = WG_KT / 16;
@@ -127,21 +123,12 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     const int s_end = a.S < s_begin + a.slab ? a.S : s_begin + a.slab;
     const int ntiles = (s_end - s_begin + WG_KT - 1) / WG_KT;
 
-    // ---- LDS-DMA: piece p of an operand covers 64 consecutive 16 B chunk positions of its tile.  LDS-DMA writes LDS
-    // linearly, so the bank swizzle is applied on the SOURCE side: each lane fetches the chunk its position holds.
-    int pr[NQ], pc[NQ];                                             // tile row / byte offset in the row of this lane's chunk
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int p = wave + 8 * q;
-        const bool isA = p < piecesA;
-        const int pp = isA ? p : p - piecesA;
-        const int cpr = isA ? cprA : cprB;
-        const int lg = isA ? __builtin_ctz(cprA) : __builtin_ctz(cprB);
-        pr[q] = pp * (64 >> lg) + (lane >> lg);
-        pc[q] = ((lane & (cpr - 1)) ^ (isA ? wg_swz(pr[q], cprA) : wg_swz(pr[q], cprB))) * 16;
-    }
+    // ---- LDS-DMA: a tile (WG_KT samples of a region) is contiguous in the saved-tensor layout (pnr_mlp_layout.h); it is
+    // copied verbatim, 1 KiB (8 lines) per wave instruction.  Rows past S exist (S_pad) and hold zeros in dys.
+    const char* const srcA = reinterpret_cast<const char*>(Ag) + lane * 16;
+    const char* const srcB = reinterpret_cast<const char*>(Bg) + lane * 16;
     auto issue = [&](int t, int buf, int q0, int q1) {
-        const int s0 = s_begin + t * WG_KT;
+        const int64_t g0 = (s_begin + t * WG_KT) >> 3;              // first 8-sample group of the tile
         char* const dst = smem + buf * 2 * WG_TILE_BYTES;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -150,25 +137,25 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             if (p >= pieces) continue;
             const bool isA = p < piecesA;
             const int pp = isA ? p : p - piecesA;
-            const int srow = s0 + pr[q];
-            const char* src = srow < s_end ? reinterpret_cast<const char*>(isA ? Ag : Bg) + (int64_t)srow * (isA ? rbA : rbB) + pc[q]
-                                           : reinterpret_cast<const char*>(a.zeros) + pc[q];
+            const char* src = (isA ? srcA + g0 * (cprA * 128) : srcB + g0 * (cprB * 128)) + pp * 1024;
             __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dst + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
         }
     };
 
-    // ---- this wave's blocks: rows wm*TM + i, columns wn*TN + j; its bias blocks: i = wn, wn + WN, ... (< TM)
+    // ---- this wave's blocks: rows wm*TM + i, columns wn*TN + j; its bias block: i = wn (< TM)
+    // Fragment addresses in a tile [8 sample groups][cpr lines][128 B]: a 16-lane group of ds_read_b64_tr_b16 covers
+    // [4 samples][16 features = 2 chunks]; lane a: sample a >> 2 of its k-half (hi), chunk blk*4 + 2*(gq&1) + ((a&3) >> 1),
+    // 8 B half a & 1.  The second read of a fragment takes samples +4: position ^ 4, i.e. address ^ 64.
     const bool active = wave < WM * WN;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int al = lane & 15, gq = lane >> 4, hi = gq >> 1;
-    const int rsub = 8 * hi + (al >> 2);                            // row within a 16-sample k-step (first half-read)
-    const int inblk = (2 * (gq & 1) + ((al & 3) >> 1)) * 16 + (al & 1) * 8;    // byte offset inside the 64 B block row
-    const int sxA = wg_swz(rsub, cprA) >> 2, sxB = wg_swz(rsub, cprB) >> 2;
+    const int cin = 2 * (gq & 1) + ((al & 3) >> 1);                 // chunk within the 32-feature block; (chunk >> 1) & 1 = gq & 1
+    const int pos = ((al >> 2) ^ ((gq & 1) << 2)) * 16 + (al & 1) * 8;
     int offA[TM], offB[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) offA[i] = rsub * rbA + (((wm * TM + i) ^ sxA) << 6) + inblk;
+    for (int i = 0; i < TM; ++i) offA[i] = (hi * cprA + (wm * TM + i) * 4 + cin) * 128 + pos;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) offB[j] = rsub * rbB + (((wn * TN + j) ^ sxB) << 6) + inblk;
+    for (int j = 0; j < TN; ++j) offB[j] = (hi * cprB + (wn * TN + j) * 4 + cin) * 128 + pos;
 
     static_assert(TM <= WN || (TM == 1 && WN == 1), "one bias block per wave at most");
     const int isel = wn;                                            // the row block whose bias (row sum) this wave accumulates
@@ -202,11 +189,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     // MFMA, which serialises request -> land -> read -> multiply per k-step.  ds_read_b64_tr_b16 hands a lane 4 consecutive
     // samples of its feature; the reads at rows ks*16 and ks*16 + 4 make one k = 16 MFMA operand.
     bf16x8 fa[2][TM], fb[2][TN];
-    int adA[TM], adB[TN];
+    int adA[TM], adB[TN], adA2[TM], adB2[TN];
     auto load = [&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
-        wg_load_frags<ks * 16 * rbA, 4 * rbA, TM>(adA, fa[ks & 1]);
-        wg_load_frags<WG_TILE_BYTES + ks * 16 * rbB, 4 * rbB, TN>(adB, fb[ks & 1]);
+        wg_load_frags<ks * 2 * cprA * 128, TM>(adA, adA2, fa[ks & 1]);              // k-step ks = sample groups 2ks, 2ks + 1
+        wg_load_frags<WG_TILE_BYTES + ks * 2 * cprB * 128, TN>(adB, adB2, fb[ks & 1]);
     };
     // the fragments of k-step ks have landed once at most PENDING younger reads are outstanding (LDS reads return in order)
     auto landed = [&](auto ks_c, auto pending_c) {
@@ -235,9 +222,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
         __syncthreads();                                            // tile t landed for everybody; everybody is done with tile t-1
         const bool more = t + 1 < ntiles;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) adA[i] = offA[i] + buf * 2 * WG_TILE_BYTES;
+        for (int i = 0; i < TM; ++i) { adA[i] = offA[i] + buf * 2 * WG_TILE_BYTES; adA2[i] = adA[i] ^ 64; }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) adB[j] = offB[j] + buf * 2 * WG_TILE_BYTES;
+        for (int j = 0; j < TN; ++j) { adB[j] = offB[j] + buf * 2 * WG_TILE_BYTES; adB2[j] = adB[j] ^ 64; }
         // software pipeline: the fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued; the next
         // tile's LDS-DMA goes out behind the first fragment requests, so only those are exposed per tile
         load(std::integral_constant<int, 0>{});

@@ -91,13 +91,41 @@ def _sum0(x):
     return torch.sum(x, 0, dtype=torch.float32)
 
 
+def pad_samples(S):
+    return (S + 255) // 256 * 256
+
+
+def saved_rows(buf, off, S, w):
+    """(S, w) slot-ordered rows of a region in the saved-tensor layout (pnr_mlp_layout.h: lines [s >> 3][chunk] of 8 samples x
+    16 B, sample s at position (s & 7) ^ (4 * ((chunk >> 1) & 1)))."""
+    Sp, cpr = pad_samples(S), w // 8
+    v = buf[off: off + Sp * w].view(Sp // 8, cpr, 8, 8)               # [group][chunk][position][element]
+    c = torch.arange(cpr, device=buf.device)
+    pos = torch.arange(8, device=buf.device)[None, :] ^ (((c >> 1) & 1) << 2)[:, None]      # [chunk][s & 7] -> position
+    rows = v[:, c[:, None], pos, :]                                     # [group][chunk][s & 7][element]
+    return rows.permute(0, 2, 1, 3).reshape(Sp, w)[:S]
+
+
+def fill_saved_rows(buf, off, S, w, rows):
+    """inverse of saved_rows; the padding rows S..S_pad are zeroed (the kernels write zeros / finite values there)."""
+    Sp, cpr = pad_samples(S), w // 8
+    full = torch.zeros((Sp, w), device=buf.device, dtype=buf.dtype)
+    full[:S] = rows
+    r = full.view(Sp // 8, 8, cpr, 8).permute(0, 2, 1, 3)               # [group][chunk][s & 7][element]
+    c = torch.arange(cpr, device=buf.device)
+    pos = torch.arange(8, device=buf.device)[None, :] ^ (((c >> 1) & 1) << 2)[:, None]
+    v = buf[off: off + Sp * w].view(Sp // 8, cpr, 8, 8)
+    v[:, c[:, None], pos, :] = r
+    return buf
+
+
 def weight_grads(nerf, desc, acts, dys, d_raw, S):
     """dict name -> fp32 gradient (nn.Linear layout) from the kernels' buffers."""
     dev = str(d_raw.device)
     D, W, H, C, K = nerf.D, nerf.W, nerf.W // 2, nerf.n_sem, nerf.n_inst
     ao, do = ops.train_layout(desc, S)
-    A = lambda i, w: acts[ao[i]: ao[i] + S * w].view(S, w)
-    Y = lambda i, w: dys[do[i]: do[i] + S * w].view(S, w)
+    A = lambda i, w: saved_rows(acts, ao[i], S, w)
+    Y = lambda i, w: saved_rows(dys, do[i], S, w)
     fW, fH = feat_slots(W, dev), feat_slots(H, dev)
     ex_idx, ed_idx = embed_slots(5, nerf.xyz_L, dev), embed_slots(2, nerf.dir_L, dev)
     EXn, EDn = 3 + 6 * nerf.xyz_L, 3 + 6 * nerf.dir_L

@@ -113,13 +113,16 @@ def test_wgrad_kernel_vs_plain_gemm(dev, S):
     nerf = net.nerf_0
     desc = nerf.desc("bf16")
     ao, do = ops.train_layout(desc, S)
-    acts = (torch.randn(ao[-1], device=dev) * 0.5).to(torch.bfloat16)
+    acts = (torch.randn(ao[-1], device=dev) * 0.5).to(torch.bfloat16)     # padding rows S..S_pad: any finite values
     dys = (torch.randn(do[-1], device=dev) * 0.5).to(torch.bfloat16)
+    widths = [nerf.W // 2, nerf.W, nerf.W // 2, nerf.W // 2] + [nerf.W] * nerf.D + [32, 64, 64]
+    for i, w in enumerate(widths):                                           # ... but zero dY there (k_mlp_bwd writes zeros)
+        wref.fill_saved_rows(dys, do[i], S, w, wref.saved_rows(dys, do[i], S, w).clone())
     shapes = {k: v.shape for k, v in nerf.state_dict().items()}
     gk = ops.mlp_wgrad(desc, acts, dys, S, shapes)
     D, W, H = nerf.D, nerf.W, nerf.W // 2
-    A = lambda i, w: acts[ao[i]: ao[i] + S * w].view(S, w).float()
-    Y = lambda i, w: dys[do[i]: do[i] + S * w].view(S, w).float()
+    A = lambda i, w: wref.saved_rows(acts, ao[i], S, w).float()
+    Y = lambda i, w: wref.saved_rows(dys, do[i], S, w).float()
     fW, fH = wref.feat_slots(W, str(dev)), wref.feat_slots(H, str(dev))
     f32s, f64s = wref.feat_slots(32, str(dev)), wref.feat_slots(64, str(dev))
     ex, ed = wref.embed_slots(5, nerf.xyz_L, str(dev)), wref.embed_slots(2, nerf.dir_L, str(dev))
