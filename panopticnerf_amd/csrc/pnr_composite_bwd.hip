@@ -47,6 +47,7 @@ template <int SUB>
 __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
 {
     constexpr int RPW = 64 / SUB;
+    constexpr int CB = 8;                   // channel rows in flight per lane
     const int lane = threadIdx.x & 63;
     const int N = a.N, nq4 = N >> 2;
     const int q = lane & (SUB - 1), g = lane / SUB;
@@ -115,13 +116,21 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
         auto lse = [&](int nch, int ch0, f4& mx, f4& den) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { mx.v[k] = -INFINITY; den.v[k] = 0.0f; }
-            for (int c = 0; c < nch; ++c) {
-                const f4 v = ld4(a.raw + (int64_t)(ch0 + c) * a.sc + s0, active);
+            // CB channel rows requested before the first is consumed: with 4 waves per SIMD and one 1 KiB load in flight per
+            // wave the pass ran at ~2 TB/s (4096 rays = 16 waves per CU)
+            for (int c0 = 0; c0 < nch; c0 += CB) {
+                f4 v[CB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float m2 = fmaxf(mx.v[k], v.v[k]);
-                    den.v[k] = den.v[k] * expf(mx.v[k] - m2) + expf(v.v[k] - m2);
-                    mx.v[k] = m2;
+                for (int j = 0; j < CB; ++j) v[j] = ld4(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc + s0, active);
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    if (c0 + j >= nch) break;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float m2 = fmaxf(mx.v[k], v[j].v[k]);
+                        den.v[k] = den.v[k] * expf(mx.v[k] - m2) + expf(v[j].v[k] - m2);
+                        mx.v[k] = m2;
+                    }
                 }
             }
         };
@@ -131,11 +140,17 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
         //   dL/dw_i += dot_i,   d x_{i,c} = w_i s_{i,c} (g_c - dot_i)
         f4 dot_s = {{0, 0, 0, 0}}, dot_i = {{0, 0, 0, 0}};
         auto gdot = [&](int nch, int ch0, const float* gp, const f4& mx, const f4& den, f4& dot) {
-            for (int c = 0; c < nch; ++c) {
-                const float gc = gp[rayc * nch + c];
-                const f4 v = ld4(a.raw + (int64_t)(ch0 + c) * a.sc + s0, active);
+            for (int c0 = 0; c0 < nch; c0 += CB) {
+                f4 v[CB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dot.v[k] = fmaf(gc, expf(v.v[k] - mx.v[k]) / den.v[k], dot.v[k]);
+                for (int j = 0; j < CB; ++j) v[j] = ld4(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc + s0, active);
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    if (c0 + j >= nch) break;
+                    const float gc = gp[rayc * nch + c0 + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dot.v[k] = fmaf(gc, expf(v[j].v[k] - mx.v[k]) / den.v[k], dot.v[k]);
+                }
             }
         };
         if (a.sem_mode && a.g_sem) gdot(a.C, 4, a.g_sem, mx_s, den_s, dot_s);
@@ -154,35 +169,49 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             st4(a.d_raw + (int64_t)c * a.sc + s0, dr, active);
         }
         const int CK = a.C + a.K;
-#pragma unroll 4
-        for (int c = 0; c < CK; ++c) {
-            const bool is_s = c < a.C;
-            const float* gp = is_s ? a.g_sem : a.g_inst;
-            const float gc = gp ? gp[rayc * (is_s ? a.C : a.K) + (is_s ? c : c - a.C)] : 0.0f;
-            const f4 r = ld4(a.raw + (int64_t)(4 + c) * a.sc + s0, active);
-            f4 dr;
+        for (int c0 = 0; c0 < CK; c0 += CB) {
+            f4 rb[CB];
+            float gcb[CB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (a.sem_mode && gp) {
-                    const float sc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
-                    dr.v[k] = w.v[k] * sc * (gc - (is_s ? dot_s.v[k] : dot_i.v[k]));
-                } else {
-                    G.v[k] = fmaf(gc, r.v[k], G.v[k]);
-                    dr.v[k] = w.v[k] * gc;
-                }
+            for (int j = 0; j < CB; ++j) {
+                const int c = c0 + j < CK ? c0 + j : CK - 1;
+                const bool is_s = c < a.C;
+                const float* gp = is_s ? a.g_sem : a.g_inst;
+                gcb[j] = gp ? gp[rayc * (is_s ? a.C : a.K) + (is_s ? c : c - a.C)] : 0.0f;
+                rb[j] = ld4(a.raw + (int64_t)(4 + c) * a.sc + s0, active);
             }
-            const float ce = is_s ? ces : cei;
-            if (ce != 0.0f) {
-                const int cc = is_s ? c : c - a.C;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int c = c0 + j;
+                if (c >= CK) break;
+                const bool is_s = c < a.C;
+                const float* gp = is_s ? a.g_sem : a.g_inst;
+                const float gc = gcb[j];
+                const f4 r = rb[j];
+                f4 dr;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int lab = is_s ? ls[k] : li[k];
-                    if (lab < 0 || lab >= (is_s ? a.C : a.K)) continue;
-                    const float pc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
-                    dr.v[k] += ce * (pc - (lab == cc ? 1.0f : 0.0f));
+                    if (a.sem_mode && gp) {
+                        const float sc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
+                        dr.v[k] = w.v[k] * sc * (gc - (is_s ? dot_s.v[k] : dot_i.v[k]));
+                    } else {
+                        G.v[k] = fmaf(gc, r.v[k], G.v[k]);
+                        dr.v[k] = w.v[k] * gc;
+                    }
                 }
+                const float ce = is_s ? ces : cei;
+                if (ce != 0.0f) {
+                    const int cc = is_s ? c : c - a.C;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int lab = is_s ? ls[k] : li[k];
+                        if (lab < 0 || lab >= (is_s ? a.C : a.K)) continue;
+                        const float pc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
+                        dr.v[k] += ce * (pc - (lab == cc ? 1.0f : 0.0f));
+                    }
+                }
+                st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
             }
-            st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
         }
 
         if (a.sem_mode) {
