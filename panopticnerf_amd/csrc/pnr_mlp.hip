@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
     }   // the refill issued past the last chunk
 #if PNR_TRACE
     __syncthreads();
-    if (blockIdx.x == 0 && a.trace) {
+    if (blockIdx.x == PNR_TRACE_WG && a.trace) {
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 2 * a.slot_bytes);
         for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
     }
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
     }
 #if PNR_TRACE
     __syncthreads();
-    if (blockIdx.x == 0 && a.trace) {
+    if (blockIdx.x == PNR_TRACE_WG && a.trace) {
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes);
         for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
     }
@@ -668,6 +668,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     a.clk = g_clk_buf;
+    if (!a.clk) if (const char* e = getenv("PNR_CLK_PTR")) a.clk = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostics (tools/clk_probe.py)
     if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);

@@ -19,6 +19,9 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 // 8 waves (two per SIMD) measured 7 % faster than 4 (one per SIMD) although the concatenated dH input (136 B registers)
 // makes hipcc spill ~160 dwords at the 256-register cap: the pass is HBM/latency-bound (masks in, dY out: ~9 KB/sample).
+#ifndef PNR_BWD_SLOTS
+#define PNR_BWD_SLOTS 2             /* LDS weight slots: the stream runs PNR_BWD_SLOTS - 1 chunks ahead (3: measured +-0) */
+#endif
 #ifndef PNR_BWD_WAVES
 #define PNR_BWD_WAVES 8
 #endif
@@ -27,11 +30,11 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 // gate  : the ReLU gate BITS of the layer's forward output ([S][NFB_OUT] dwords, pnr_train_layout; nullptr: linear):
 //         NFB_OUT/2 dwords per lane, loaded once per layer, instead of the 16 x NFB_OUT bytes of bf16 activations
 // store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient
-template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF, bool GATED = true>
+template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF, bool GATED = true, int FBC = PNR_BWD_FBC>
 __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
                                           const uint16_t* gate, uint16_t* store, const int (&samp)[TILES], const int (&srow)[TILES])
 {
-    constexpr int FBC = 2, G = 2;
+    constexpr int G = 4 / FBC;               // A-fragment read window: 2 * G * FBC * 4 registers
     static_assert(NFB_OUT % FBC == 0 && NOUT >= OFF + NFB_OUT * 8, "bad backward layer geometry");
     uint32_t dummy[TILES][1];
     uint32_t gw[TILES][NFB_OUT / 2];
@@ -94,7 +97,7 @@ __device__ __forceinline__ void load_draw(const MlpArgs& a, int s, int hi, int c
 template <int W, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
 {
-    using CTX = Ctx<WAVES, 4>;
+    using CTX = Ctx<WAVES, 4, PNR_BWD_SLOTS>;
     constexpr int TILES = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NFB = W / 32, HFB = W / 64;
@@ -105,10 +108,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
     CTX c{a, smem, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
           (int)((threadIdx.x & 63) >> 5), 0, 0, {0, 0}, {0, 0}};
 #if PNR_TRACE
-    c.tr = reinterpret_cast<unsigned long long*>(smem + 2 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.tr = reinterpret_cast<unsigned long long*>(smem + PNR_BWD_SLOTS * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
     c.titer = 0;
 #endif
     const int n = c.lane & 31;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (a.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     c.start();
     const int D = a.D;
     uint16_t* const acts = a.acts;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
         uint32_t dy[TILES][HR], dn[TILES][HR];
-        layer_bwd<TILES, CTX, CATR, NFB, HR, 0>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
+        layer_bwd<TILES, CTX, CATR, NFB, HR, 0, true, PNR_BWD_FBC_DH>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
         // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
 #pragma unroll 1
         for (int l = D - 1; l >= 1; --l) {
@@ -165,10 +170,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {     // mean shader clock of this launch: cycles / 100 MHz ticks
+        a.clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 #if PNR_TRACE
     __syncthreads();
-    if (blockIdx.x == 0 && a.trace) {
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 2 * a.slot_bytes);
+    if (blockIdx.x == PNR_TRACE_WG && a.trace) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + PNR_BWD_SLOTS * a.slot_bytes);
         for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
     }
 #endif
@@ -178,8 +187,8 @@ template <int W, int WAVES>
 static int launch_bwd(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
-    const int lds_bytes = 2 * a.slot_bytes + (PNR_TRACE ? WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
-    PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_backward: weight double buffer of %d bytes exceeds the 160 KiB LDS", lds_bytes);
+    const int lds_bytes = PNR_BWD_SLOTS * a.slot_bytes + (PNR_TRACE ? WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
+    PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_backward: weight slots of %d bytes exceed the 160 KiB LDS", lds_bytes);
     const int per_group = 32 * WAVES;
     a.n_groups = (a.S + per_group - 1) / per_group;
     auto kern = k_mlp_bwd<W, WAVES>;
@@ -221,6 +230,7 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
     pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
+    if (const char* e = getenv("PNR_CLK_PTR")) a.clk = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostics (tools/clk_probe.py)
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

@@ -36,6 +36,9 @@ struct MlpArgs {
 #ifndef PNR_ABL_STORE
 #define PNR_ABL_STORE 0
 #endif
+#ifndef PNR_ABL_NODMA
+#define PNR_ABL_NODMA 0
+#endif
 // One 32-row block's share of lane (n, hi) -- 16 slots = chunks fb*4 + hi*2 + {0, 1} -- of padded sample row s into a
 // saved region (pnr_mlp_layout.h: the two chunks sit in neighbouring lines at the same position).  Unmasked: rows
 // S..S_pad are written as well.
@@ -176,26 +179,36 @@ __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x1
 #ifndef PNR_TRACE_MASK
 #define PNR_TRACE_MASK 0xff
 #endif
+#ifndef PNR_TRACE_WG
+#define PNR_TRACE_WG 0          /* the traced workgroup and its traced iteration (sample group) */
+#endif
+#ifndef PNR_TRACE_ITER
+#define PNR_TRACE_ITER 2
+#endif
 #define PNR_TRACE_CHUNKS 48
 #define PNR_TRACE_STAMPS 8
 
-// ---- weight stream: two LDS slots; chunk c+1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
-template <int WAVES, int GDB_>
+// ---- weight stream: NSLOT LDS slots; chunk c + NSLOT - 1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
+// Two slots everywhere.  Three (two chunks ahead) were tried for the data-gradient pass on the suspicion that its chunk
+// hand-overs wait for weight pieces delayed behind the gradient stores: +-0 (profiles/README.md, round 2 training notes).
+template <int WAVES, int GDB_, int NSLOT = 2>
 struct Ctx {
     static constexpr int GDB = GDB_;   // A-fragment read-ahead (fragments per tile in flight)
+    static constexpr int DIST = NSLOT - 1;
     const MlpArgs& a;
     char* smem;
     int lane, wave, hi;
     int ci, slot;
-    pnr_chunk_entry e1, e2;            // table entries of chunks ci+1, ci+2 (scalar loads, fetched a chunk early)
-    bool st_full = false;              // every lane of this wave holds a valid sample: its store count per chunk is exact
+    pnr_chunk_entry e1, e2;            // table entries of chunks ci+DIST, ci+DIST+1 (scalar loads, fetched a chunk early)
+    bool st_full = false;
+    int n_last = 0;                    // NSLOT = 3: this wave's LDS-DMA pieces of the chunk requested in begin()              // every lane of this wave holds a valid sample: its store count per chunk is exact
 #if PNR_TRACE
     unsigned long long* tr;            // LDS trace area of this wave: [PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
     int titer;
     __device__ __forceinline__ void stamp(int k)
     {
         if (!((PNR_TRACE_MASK >> k) & 1)) return;       // single-stamp builds: a stamp costs an lgkmcnt(0) wait
-        if (blockIdx.x == 0 && titer == 2 && ci < PNR_TRACE_CHUNKS) {
+        if (blockIdx.x == PNR_TRACE_WG && titer == PNR_TRACE_ITER && ci < PNR_TRACE_CHUNKS) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) tr[ci * PNR_TRACE_STAMPS + k] = t;
         }
@@ -225,14 +238,25 @@ struct Ctx {
     __device__ __forceinline__ void start()
     {
         ci = 0; slot = 0;
-        issue(entry(0), 0);
-        e1 = entry(wrap(1));
-        e2 = entry(wrap(2));
+#pragma unroll
+        for (int k = 0; k < DIST; ++k) issue(entry(wrap(k)), k);
+        e1 = entry(wrap(DIST));
+        e2 = entry(wrap(wrap(DIST) + 1));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     __device__ __forceinline__ const char* base() const { return smem + slot * a.slot_bytes; }
-    __device__ __forceinline__ void begin() { stamp(0); issue(e1, slot ^ 1); stamp(1); }
+    __device__ __forceinline__ void begin()
+    {
+        stamp(0);
+        int sl = slot + DIST;
+        if (sl >= NSLOT) sl -= NSLOT;
+#if !PNR_ABL_NODMA              /* ablation: the weight stream stops after start() (results invalid) */
+        issue(e1, sl);
+#endif
+        if constexpr (NSLOT > 2) n_last = wave < (int)e1.nfrag ? ((int)e1.nfrag - wave + WAVES - 1) / WAVES : 0;
+        stamp(1);
+    }
     // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
     // nst: activation / gradient store INSTRUCTIONS this wave issued since begin().  Vector-memory operations of a wave
     // complete in order, so "at most nst outstanding" means the LDS-DMA pieces (older) have landed while the stores
@@ -242,16 +266,28 @@ struct Ctx {
     __device__ __forceinline__ void finish(int nst = 0)
     {
         stamp(4);
-        if (st_full && nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (st_full && nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NSLOT > 2) {
+            // chunk ci+1 must have landed; the pieces of chunk ci+2 (requested in this chunk's begin()) and the stores may fly on
+            const int allow = n_last + (st_full ? nst : 0);
+#define PNR_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            switch (allow) {
+                PNR_VM(1) PNR_VM(2) PNR_VM(3) PNR_VM(4) PNR_VM(5) PNR_VM(6) PNR_VM(7) PNR_VM(8) PNR_VM(9) PNR_VM(10) PNR_VM(11) PNR_VM(12)
+                PNR_VM(13) PNR_VM(14) PNR_VM(15) PNR_VM(16)
+                default: if (allow > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+#undef PNR_VM
+        } else {
+            if (st_full && nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (st_full && nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         stamp(5);
         __syncthreads();
         stamp(6);
-        slot ^= 1;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
         ci = wrap(ci + 1);
         e1 = e2;
-        e2 = entry(wrap(wrap(ci + 1) + 1));
+        e2 = entry(wrap(wrap(wrap(ci + DIST)) + 1));
     }
 };
 

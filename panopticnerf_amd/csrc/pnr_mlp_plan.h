@@ -90,7 +90,12 @@ struct PnrBLayer {
     int nseg;
     int seg_kind[4], seg_slots[4];
     int nks;                // k-steps per 32-row block
+    int fbc;                // 32-row blocks per chunk
 };
+// blocks per chunk of a backward layer: 2, except the 34-k-step dH layer (its two-block chunk would be 68 KiB and
+// three weight slots -- k_mlp_bwd prefetches two chunks ahead -- would not fit the LDS)
+#define PNR_BWD_FBC 2
+#define PNR_BWD_FBC_DH 1
 struct PnrBPlan {
     std::vector<PnrBLayer> layers;
     std::vector<PnrChunk> chunks;
@@ -104,6 +109,7 @@ static inline void pnr_build_bwd_plan(const pnr_mlp_desc& d, PnrBPlan& plan)
     auto add = [&](int kind, int index, int rows, std::initializer_list<std::pair<int, int>> segs) {
         PnrBLayer L;
         L.kind = kind; L.index = index; L.rows = rows; L.n_fb = rows / 32; L.nseg = 0; L.nks = 0;
+        L.fbc = kind == PNR_B_DH ? PNR_BWD_FBC_DH : PNR_BWD_FBC;
         for (auto& sg : segs) { L.seg_kind[L.nseg] = sg.first; L.seg_slots[L.nseg] = sg.second; L.nks += sg.second / 16; ++L.nseg; }
         plan.layers.push_back(L);
     };
@@ -118,9 +124,9 @@ static inline void pnr_build_bwd_plan(const pnr_mlp_desc& d, PnrBPlan& plan)
     int off = 0, mx = 0;
     for (size_t li = 0; li < plan.layers.size(); ++li) {
         const PnrBLayer& L = plan.layers[li];
-        for (int fb = 0; fb < L.n_fb; fb += 2) {
+        for (int fb = 0; fb < L.n_fb; fb += L.fbc) {
             PnrChunk c;
-            c.layer = (int)li; c.fb = fb; c.nfb = 2; c.off_frag = off; c.nfrag = 2 * L.nks;
+            c.layer = (int)li; c.fb = fb; c.nfb = L.fbc; c.off_frag = off; c.nfrag = L.fbc * L.nks;
             off += c.nfrag;
             if (c.nfrag > mx) mx = c.nfrag;
             plan.chunks.push_back(c);

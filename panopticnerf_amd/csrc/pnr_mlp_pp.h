@@ -107,7 +107,7 @@ struct CtxPP {
     __device__ __forceinline__ void stamp(int k)
     {
         if (!((PNR_TRACE_MASK >> k) & 1)) return;
-        if (blockIdx.x == 0 && titer == 2 && ci < PNR_TRACE_CHUNKS) {
+        if (blockIdx.x == PNR_TRACE_WG && titer == PNR_TRACE_ITER && ci < PNR_TRACE_CHUNKS) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) tr[ci * PNR_TRACE_STAMPS + k] = t;
         }
