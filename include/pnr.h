@@ -119,13 +119,17 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
 
 /* ---- a9 (training): forward that also saves what the backward needs, the data-gradient pass, and the
  * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
- *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output,
- *          one slot-ordered [S][width] region per tensor (S = n_rays*n_samples);
+ *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output, one
+ *          slot-ordered region of S_pad x width per tensor (S = n_rays*n_samples, S_pad = S rounded up to 256), followed by
+ *          one gate BIT per element of every ReLU output (what pnr_mlp_backward reads);
  *   dys  : bf16, dys_off[D+7] elements -- every layer's pre-activation gradient dY, same layout (plus the output
  *          layers' dY = d_raw in bf16: [rgb,sigma] in 32 slots, semantic and instance logits in 64 slots each), written by
- *          pnr_mlp_backward for the weight-gradient GEMMs dW = dY^T X (plain S-reduction GEMMs, done by the caller);
+ *          pnr_mlp_backward (rows S..S_pad: zeros) for pnr_mlp_wgrad's dW = dY^T X;
  *   d_raw: (4+n_sem+n_inst, S) channel-major fp32 (pnr_composite_backward's output).
- * Slot order (csrc/pnr_mlp_layout.h): slot fb*32 + hi*16 + r <-> feature fb*32 + (r&3) + 8*(r>>2) + 4*hi. */
+ * Slot order (csrc/pnr_mlp_layout.h): slot fb*32 + hi*16 + r <-> feature fb*32 + (r&3) + 8*(r>>2) + 4*hi.
+ * Saved-tensor layout of a region (csrc/pnr_mlp_layout.h, pnr_saved_chunk): the 16-byte chunk c = slot/8 of sample s lives
+ * in the 128-byte line [s >> 3][c] at position (s & 7) ^ (4 * ((c >> 1) & 1)) -- a wave's store writes full lines and a
+ * 64-sample tile is one contiguous block for the weight-gradient kernel.  The buffers are opaque to callers. */
 int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples, int64_t* acts_off_host /* D+7 */,
                          int64_t* dys_off_host /* D+8 */);
 int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

@@ -4,19 +4,22 @@
 // the data-gradient pass (dys: dY) leave in HBM (pnr_train_layout).  No reference file exists in the mount
 // (SURVEY.md 0); the arithmetic is what autograd does for nn.Linear.
 //
-// Both MFMA operands are needed k-major per lane (8 consecutive SAMPLES of one feature) while memory is
-// feature-major ([sample][feature]), so both go through LDS and come back through gfx950's transpose read:
-//   * a workgroup owns one job (a (dY region, X region) pair) and one slab of samples; it streams KT = 64-sample
-//     tiles of both regions into LDS by LDS-DMA (1 KiB per wave instruction, double buffered, one barrier per tile);
+// Both MFMA operands are needed k-major per lane (8 consecutive SAMPLES of one feature), so both go through LDS and
+// come back through gfx950's transpose read:
+//   * a workgroup owns one job (a (dY region, X region) pair) and one slab of samples; it copies KT = 64-sample
+//     tiles of both regions into LDS by LDS-DMA, verbatim: in the saved-tensor layout (pnr_mlp_layout.h) a tile is one
+//     contiguous block (1 KiB = 8 lines per wave instruction, double buffered, one barrier per tile);
 //   * ds_read_b64_tr_b16 hands a lane 4 consecutive samples of its feature; a 16-lane group addresses a
-//     [4 samples][16 features] block (lane a: sample a>>2, features 4(a&3)..), two reads make one MFMA operand;
-//   * those reads touch 4 rows x 64 B per half-wave, which is conflict-free only if the 4 rows sit in different
-//     64 B bank groups: the 16 B chunks of a row are XOR-swizzled with the row index.  LDS-DMA writes LDS
-//     linearly, so the swizzle is applied on the SOURCE side (each lane fetches the chunk its LDS position holds);
-//   * 8 waves x (2 x 4) 32x32 tiles cover a 256 x 256 gradient; db comes from one more MFMA per row block against
-//     an all-ones operand (the kernel is HBM-bound: ~13.7 KB per sample over all jobs, ~1.3 MFLOP);
+//     [4 samples][2 chunks of 8 features] block = two half-lines, two reads make one MFMA operand; the layout's XOR of the
+//     sample position with bit 1 of the chunk index puts the four groups of a half-wave on all 64 banks once;
+//   * one straight-line instance of the loop per job shape (wg_body<MB, NB>), fragment reads as inline asm with
+//     hand-counted waits and an explicit software pipeline -- see the note at the reads;
+//   * db comes from one more MFMA per row block against an all-ones operand (the kernel is HBM-bound: ~13.2 KB per
+//     sample over all jobs, ~1.3 MFLOP);
 //   * every (job, slab) writes its partial sums; k_wgrad_reduce adds the slabs in a fixed order (deterministic)
 //     and un-permutes slots into the nn.Linear layout, so no atomics and no host-side index maps are needed.
+// Contract: rows S..S_pad of every dys region hold zeros and of every acts region finite values (the kernels that write
+// them do so); no row masks here.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <type_traits>
@@ -45,6 +48,9 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 #ifndef WG_DMA_AUX
 #define WG_DMA_AUX 2                /* cache policy of the tile loads: 0 default, 2 nt (every byte is read once per job): -3 % */
 #endif
+#ifndef WG_SLAB_MAJOR
+#define WG_SLAB_MAJOR 0           /* 1: the jobs of one slab side by side (re-reads of shared regions from cache): measured +12 % time */
+#endif
 #ifndef WG_ISSUE_SPLIT
 #define WG_ISSUE_SPLIT 0            /* 1: the next tile's LDS-DMA pieces are issued between the k-steps instead of en bloc */
 #endif
@@ -59,7 +65,7 @@ struct WgJob {
     int ma, nb;                     // region widths in slots: 32, 64, 128 or 256
 };
 struct WgArgs {
-    const uint16_t* acts; const uint16_t* dys; const uint16_t* zeros;   // zeros: >= 512 B of zeros (tile rows past the slab)
+    const uint16_t* acts; const uint16_t* dys; const uint16_t* zeros;   // zeros: unused since the saved-tensor layout (padding rows exist)
     float* partial;
     int S, slab, n_slabs, n_jobs;
     WgJob job[WG_MAX_JOBS];
@@ -267,7 +273,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][A tile | B tile]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if WG_SLAB_MAJOR
+    // slab-major: the jobs of one slab run side by side, so the regions several jobs read (h = X_D: feature, alpha, sem0,
+    // inst0; gamma(x): layers 0 and skip+1; dY_views, d[rgb, sigma]: twice each) are re-read while still cached
+    const int slab = blockIdx.x / a.n_jobs, jb = blockIdx.x - slab * a.n_jobs;
+#else
     const int jb = blockIdx.x / a.n_slabs, slab = blockIdx.x - jb * a.n_slabs;
+#endif
     // region widths are 32, 64, 128 or 256 slots: one straight-line instance of the loop per shape
     const int shape = (31 - __builtin_clz(a.job[jb].ma >> 5)) * 4 + (31 - __builtin_clz(a.job[jb].nb >> 5));
     switch (shape) {
