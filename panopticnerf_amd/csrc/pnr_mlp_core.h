@@ -119,12 +119,12 @@ __device__ __forceinline__ void save_gates(uint16_t* region, int s, int hi, cons
     for (int fb = 0; fb < NR / 8; ++fb) w[fb / 2] = gate_bits_or(w[fb / 2], &regs[fb * 8], fb);
     store_gates<NW>(region, NR * 4, s, hi, w);
 }
-// packed bf16x2 gradient gated by the two gate bits of (block fb, register p) of gate word g
+// packed bf16x2 gradient gated by the two gate bits of (block fb, register p) of gate word g: each half times its bit
+// (shift, and, v_pk_mul_lo_u16 -- two instructions fewer per register than building an and-mask from sign-extended bits)
 __device__ __forceinline__ uint32_t gate_apply(uint32_t packed, uint32_t g, int fb, int p)
 {
-    const int sh = 8 * (fb & 1) + p;
-    const uint32_t mlo = (uint32_t)__builtin_amdgcn_sbfe((int)g, sh, 1), mhi = (uint32_t)__builtin_amdgcn_sbfe((int)g, 16 + sh, 1);
-    return packed & ((mlo & 0x0000ffffu) | (mhi & 0xffff0000u));
+    const uint32_t bits = (g >> (8 * (fb & 1) + p)) & 0x00010001u;
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, packed) * __builtin_bit_cast(u16x2, bits));
 }
 
 enum { MODE_RELU = 0, MODE_LINEAR = 1 };

@@ -48,6 +48,9 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 #ifndef WG_DMA_AUX
 #define WG_DMA_AUX 2                /* cache policy of the tile loads: 0 default, 2 nt (every byte is read once per job): -3 % */
 #endif
+#ifndef WG_SLAB
+#define WG_SLAB 8192
+#endif
 #ifndef WG_SLAB_MAJOR
 #define WG_SLAB_MAJOR 0           /* 1: the jobs of one slab side by side (re-reads of shared regions from cache): measured +12 % time */
 #endif
@@ -341,7 +344,7 @@ static int wg_slab(int64_t S)
 {
     // samples per slab: enough slabs to fill the GPU a few times over, few enough to keep the partials small
     // (measured at 786 K samples: 2048 / 4096 / 8192 / 16384 / 32768 samples per slab -> 3.28 / 2.97 / 2.79 / 2.96 / 3.18 ms)
-    int slab = 8192;
+    int slab = WG_SLAB;
     while (slab > 1024 && S / slab < 24) slab >>= 1;
     return slab;
 }
