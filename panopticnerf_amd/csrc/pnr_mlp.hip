@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         auto gv = [&](int idx, auto& regs) {
             if constexpr (TRAIN && PREC == PNR_PREC_BF16) {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) save_gates(a.acts + a.gate_off[idx], samp[t], c.hi, regs[t]);
+                for (int t = 0; t < TILES; ++t) save_gates(a.acts + a.gate_off[idx], srow[t], c.hi, regs[t]);
             }
         };
 
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
         auto gv = [&](int idx, auto& regs) {
-            if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], samp, c.hi, regs);
+            if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], srow, c.hi, regs);
         };
         uint32_t cur[HR], nxt[HR];
         pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), srow);

@@ -89,8 +89,8 @@ __device__ __forceinline__ uint32_t gate_bits_or(uint32_t word, const uint32_t* 
 template <int NW>
 __device__ __forceinline__ void store_gates(uint16_t* region, int width, int s, int hi, const uint32_t (&w)[NW])
 {
-    if (s < 0) return;
-    uint32_t* p = reinterpret_cast<uint32_t*>(region) + (size_t)s * (width / 32) + hi * NW;
+    uint32_t* p = reinterpret_cast<uint32_t*>(region)      // unmasked: padded sample rows S..S_pad are written too (the whole buffer is defined)
+        + (size_t)s * (width / 32) + hi * NW;
     if constexpr (NW == 4) { u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; *reinterpret_cast<u32x4*>(p) = v; }
     else {
 #pragma unroll

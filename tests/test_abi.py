@@ -103,3 +103,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libpnr.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+@pytest.mark.parametrize("S", [1, 255, 256, 1000, 786432])
+def test_train_layout_is_padded_line_aligned_and_ordered(S):
+    """pnr_mlp_train_layout (host arithmetic only): every region of the training buffers starts on a 128-byte line, holds
+    S_pad = ceil(S / 256) * 256 rows of its width, regions do not overlap, and the acts total leaves room for the gate bits
+    (one bit per element of X_1..X_D, G, SH_sem, SH_inst) behind the last bf16 region -- what include/pnr.h documents."""
+    desc = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+    ao, do = ops.train_layout(desc, S)
+    D, W, H = 8, 256, 128
+    Sp = (S + 255) // 256 * 256
+    aw = [64, 32] + [W] * D + [W, H, H, H]
+    assert len(ao) == D + 7 and len(do) == D + 8
+    for offs, widths in ((ao, aw), (do, [H, W, H, H] + [W] * D + [32, 64, 64])):
+        for i, w in enumerate(widths):
+            assert offs[i] % 64 == 0, (i, offs[i])                  # bf16 elements: 64 = one 128-byte line
+            assert offs[i + 1] - offs[i] >= Sp * w if i + 1 < len(widths) else offs[-1] - offs[i] >= Sp * w
+    gate_bits = Sp * (D * W + 3 * H)
+    assert ao[-1] - (ao[5 + D] + Sp * H) >= gate_bits // 16         # bits -> bf16 units
+    assert do[-1] == do[D + 6] + Sp * 64

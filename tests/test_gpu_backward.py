@@ -287,3 +287,64 @@ def test_training_step_is_graph_capturable(dev):
     assert losses_g == losses_e, (losses_g, losses_e)
     for (n, a), b in zip(net_e.named_parameters(), net_g.parameters()):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("S_rays", [(37, 24), (16, 64)])      # 888 samples (ragged: S_pad = 1024) and 1024 (S = S_pad)
+def test_saved_tensors_layout_gates_and_padding(dev, S_rays):
+    """The training buffers as include/pnr.h documents them: read back through the saved-tensor layout (tests/_wgrad_ref.
+    saved_rows) and the slot maps, every trunk layer's saved output is relu(W x + b) of the saved layer before it (bf16
+    tolerance); the gate bits are exactly [X > 0]; the padding rows S..S_pad of every dY region are zero after
+    pnr_mlp_backward and of every acts region finite."""
+    from panopticnerf_amd import make_network
+    import _wgrad_ref as wref
+    from types import SimpleNamespace as NS
+    R, N = S_rays
+    S = R * N
+    torch.manual_seed(S)
+    net = make_network(NS(num_classes=6, num_instances=5)).to(dev).train()
+    nerf = net.nerf_0
+    D, W, H = nerf.D, nerf.W, nerf.W // 2
+    rng = np.random.default_rng(S)
+    rays = torch.tensor(_rays(rng, R)).to(dev)
+    z = ops.stratified(rays, N)
+    desc, img = net.packed(0, dev)
+    raw, acts = ops.mlp_forward_train(desc, img, rays, z)
+    ao, do = ops.train_layout(desc, S)
+    Sp = wref.pad_samples(S)
+    fW = wref.feat_slots(W, str(dev))
+    inv = wref._inverse(fW, W)
+    X = [wref.saved_rows(acts, ao[2 + l], S, W).float().index_select(1, inv) for l in range(D)]     # feature order
+    sd = {k: v.detach().float() for k, v in nerf.state_dict().items()}
+    bf = lambda t: t.to(torch.bfloat16).float()
+    for l in range(1, D):
+        if l - 1 == nerf.skip:
+            continue                                   # the skip layer also takes gamma(x): covered by the gradient tests
+        w, b = bf(sd["pts_linears.%d.weight" % l]), sd["pts_linears.%d.bias" % l]
+        ref = bf(torch.relu(X[l - 1] @ w.t() + b))
+        err = (X[l] - ref).abs().max().item()
+        assert err <= 2e-2 * max(1.0, ref.abs().max().item()), (l, err)
+    # gate bits: dword j of lane (n, hi) covers blocks 2j, 2j+1; bit 8*(fb&1)+p <-> slot fb*32+hi*16+2p, +16 <-> 2p+1
+    abuf = acts.view(torch.int16)
+    gate_base = ao[5 + D] + Sp * H                     # the gate regions follow the last acts region, in layout order
+    assert gate_base % 64 == 0
+    words = abuf[gate_base: gate_base + Sp * (W // 16)].view(torch.int32).view(Sp, W // 32)[:S].to(torch.int64) & 0xffffffff
+    Xs = wref.saved_rows(acts, ao[2], S, W).float()    # X_1 in slot order
+    for fb in (0, 3, W // 32 - 1):
+        for hi in (0, 1):
+            for p in (0, 5, 7):
+                wd = words[:, hi * (W // 64) + fb // 2]
+                lo = (wd >> (8 * (fb & 1) + p)) & 1
+                hi_bit = (wd >> (16 + 8 * (fb & 1) + p)) & 1
+                s0 = fb * 32 + hi * 16 + 2 * p
+                assert torch.equal(lo.bool(), Xs[:, s0] > 0) and torch.equal(hi_bit.bool(), Xs[:, s0 + 1] > 0), (fb, hi, p)
+    assert torch.isfinite(acts[: ao[5 + D] + Sp * H].float()).all()
+    # backward: zero padding rows in every dY region
+    _, img_b = net.packed_bwd(0, dev)
+    d_raw = torch.randn_like(raw)
+    dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
+    widths = [H, W, H, H] + [W] * D + [32, 64, 64]
+    for i, w in enumerate(widths):
+        full = dys[do[i]: do[i] + Sp * w]
+        rows = wref.saved_rows(dys, do[i], Sp, w)       # all S_pad rows
+        assert torch.count_nonzero(rows[S:]) == 0, i
+        assert torch.isfinite(full.float()).all()
