@@ -340,7 +340,8 @@ def main():
             flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-            roofline = {"kernel": "k_mlp_fused (%s level, %d rays x %d samples, %dx%d MLP)" % ("fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
+            kname = "k_mlp_pp" if (ops.mlp_variant() >= 1 and args.precision == "bf16") else "k_mlp_fused"
+            roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", Rc, args.config),
                         "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
@@ -441,8 +442,9 @@ def main():
                           "roofline": {"bound": "mfma", "flop_per_sample_fwd_bwd": 3 * fwd_flops,
                                        "achieved": round(3 * fwd_flops * S_step / tdt / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(3 * fwd_flops * S_step / tdt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                       "note": "whole step per rank incl. losses, Adam and host launch gaps; the saved activations "
-                                               "+ dY regions move ~2*(%d+%d) B/sample through HBM (DESIGN.md 7)" % (
+                                       "note": "whole step per rank incl. losses, Adam and host launch gaps; HBM-side the step writes "
+                                               "%d B/sample of saved activations (+ 1 gate bit per ReLU output) and %d B/sample of dY, "
+                                               "and k_wgrad reads both back (DESIGN.md 7)" % (
                                                    2 * (64 + 32 + (c["D"] + 1) * c["W"] + 3 * (c["W"] // 2)),
                                                    2 * ((c["D"] + 1) * c["W"] + 3 * (c["W"] // 2) + 160))}}
         except Exception as e:      # noqa: BLE001

@@ -323,6 +323,13 @@ def time_mlp_forward_clk(desc, packed, rays, z, raw, iters):
     return float(ms.value), float(mhz.value)
 
 
+def mlp_variant(variant=None):
+    """Which form of the fused bf16 MLP pnr_mlp_forward launches: 0 lock-step (k_mlp_fused), 1 ping-pong (k_mlp_pp) for
+    inference launches (default), 2 ping-pong for the training forward as well.  Returns the setting in force BEFORE the
+    call; variant=None only queries."""
+    return int(_lib.load().pnr_mlp_set_variant(-1 if variant is None else int(variant)))
+
+
 def probe_mfma_peak(random_operands, iters=20000, device=None):
     """(TFLOP/s, shader MHz) a register-only bf16 MFMA loop sustains on this device (pnr_probe_mfma_peak) -- bench only."""
     dev = torch.device(device if device is not None else "cuda")
