@@ -254,7 +254,8 @@ struct PPChunk {
     {
         pp_static_for<FBC * 4>([&](auto J) {
             constexpr int b = J / 4, m = J % 4;
-            pp_lds_read<BIAS_OFF + b * 128 + m * 32>(q[b][m], ba);
+            if constexpr (PNR_PP_ABL & 8) { q[b][m] = f32x4{0, 0, 0, 0}; (void)ba; }      // ablation: no bias reads (results invalid)
+            else pp_lds_read<BIAS_OFF + b * 128 + m * 32>(q[b][m], ba);
         });
     }
     // ... and, at the end of L: drain every LDS read of the phase (this is the memory half of the pairing: the partner
