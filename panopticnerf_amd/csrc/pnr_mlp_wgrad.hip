@@ -68,7 +68,7 @@ struct WgJob {
     int ma, nb;                     // region widths in slots: 32, 64, 128 or 256
 };
 struct WgArgs {
-    const uint16_t* acts; const uint16_t* dys; const uint16_t* zeros;   // zeros: unused since the saved-tensor layout (padding rows exist)
+    const uint16_t* acts; const uint16_t* dys;
     float* partial;
     int S, slab, n_slabs, n_jobs;
     WgJob job[WG_MAX_JOBS];
@@ -402,7 +402,7 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     pl.partial_floats = po;
 }
 
-#define WG_ZERO_BYTES 1024
+#define WG_ZERO_BYTES 1024          /* head of the workspace, unused since the saved-tensor layout (kept: the partials stay 1 KiB in) */
 
 PNR_EXPORT int64_t pnr_mlp_wgrad_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_samples)
 {
@@ -430,10 +430,9 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
         PNR_REQUIRE(pl.red[i].out, "pnr_mlp_wgrad: a weight-gradient pointer of grads_dev is null");
     PNR_REQUIRE(grads_dev->alpha_b && grads_dev->rgb_b && grads_dev->feature_b && grads_dev->views_b,
                 "pnr_mlp_wgrad: a bias-gradient pointer of grads_dev is null");
-    PNR_HIP(hipMemsetAsync(workspace, 0, WG_ZERO_BYTES, st));
     WgArgs a;
     memset(&a, 0, sizeof(a));
-    a.acts = (const uint16_t*)acts; a.dys = (const uint16_t*)dys; a.zeros = (const uint16_t*)workspace;
+    a.acts = (const uint16_t*)acts; a.dys = (const uint16_t*)dys;
     a.partial = (float*)((char*)workspace + WG_ZERO_BYTES);
     a.S = (int)n_samples; a.slab = pl.slab; a.n_slabs = pl.n_slabs; a.n_jobs = pl.n;
     for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
