@@ -57,8 +57,12 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 #ifndef WG_ISSUE_SPLIT
 #define WG_ISSUE_SPLIT 0            /* 1: the next tile's LDS-DMA pieces are issued between the k-steps instead of en bloc */
 #endif
+#ifndef WG_NBUF
+#define WG_NBUF 2                   /* LDS ring: tile pairs resident; WG_NBUF - 1 requested ahead.  After the rewrite, same box:
+                                       64 x 2: 1.98 ms, 32 x 4: 2.00-2.11, 32 x 5: 2.04-2.11, 16 x 8: 2.75-2.80 */
+#endif
 #define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
-static_assert(WG_KT % 16 == 0 && 4 * WG_TILE_BYTES <= 163840, "wgrad tile pair does not fit the 160 KiB LDS twice");
+static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && WG_NBUF * 2 * WG_TILE_BYTES <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
 #define WG_MAX_JOBS 24
 #define WG_BIAS_COLS 32             /* partial block: [ma][nb + 32], column nb = row sum (bias gradient) */
 
@@ -182,12 +186,30 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
+    // tile t has landed once only this wave's pieces of the younger tiles already requested are outstanding (vector-memory
+    // operations of a wave complete in order); s_waitcnt takes an immediate: a ladder over the possible counts
+    int n_mine = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) n_mine += (wave + 8 * q < pieces) ? 1 : 0;
+    auto landed_tile = [&](int t) {
+        const int ahead = ntiles - 1 - t < WG_NBUF - 2 ? ntiles - 1 - t : WG_NBUF - 2;
+#define PNR_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        switch (n_mine * ahead) {
+            PNR_VM(1) PNR_VM(2) PNR_VM(3) PNR_VM(4) PNR_VM(5) PNR_VM(6) PNR_VM(7) PNR_VM(8) PNR_VM(9) PNR_VM(10) PNR_VM(11) PNR_VM(12)
+            PNR_VM(13) PNR_VM(14) PNR_VM(15) PNR_VM(16) PNR_VM(17) PNR_VM(18) PNR_VM(19) PNR_VM(20) PNR_VM(21) PNR_VM(22) PNR_VM(23) PNR_VM(24)
+            PNR_VM(25) PNR_VM(26) PNR_VM(27) PNR_VM(28) PNR_VM(29) PNR_VM(30) PNR_VM(31) PNR_VM(32)
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+#undef PNR_VM
+    };
     if (!active) {      // shapes with fewer than 8 wave tiles: the spare waves only help moving the tiles
-        issue(0, 0, 0, NQ);
+#pragma unroll
+        for (int d = 0; d < WG_NBUF - 1; ++d)
+            if (d < ntiles) issue(d, d, 0, NQ);
         for (int t = 0; t < ntiles; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed_tile(t);
             __syncthreads();
-            if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1, 0, NQ);
+            if (t + WG_NBUF - 1 < ntiles) issue(t + WG_NBUF - 1, (t + WG_NBUF - 1) % WG_NBUF, 0, NQ);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -224,12 +246,15 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     constexpr int RD = 2 * (TM + TN);                               // ds_reads per k-step
     static_assert(RD <= 15, "lgkmcnt is a 4-bit counter");
 
-    issue(0, 0, 0, NQ);
+#pragma unroll
+    for (int d = 0; d < WG_NBUF - 1; ++d)
+        if (d < ntiles) issue(d, d, 0, NQ);
     int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of tile t
+        landed_tile(t);                                             // this wave's pieces of tile t
         __syncthreads();                                            // tile t landed for everybody; everybody is done with tile t-1
-        const bool more = t + 1 < ntiles;
+        const bool more = t + WG_NBUF - 1 < ntiles;
+        const int nbuf = buf == 0 ? WG_NBUF - 1 : buf - 1;          // tile t-1's buffer takes tile t + WG_NBUF - 1
 #pragma unroll
         for (int i = 0; i < TM; ++i) { adA[i] = offA[i] + buf * 2 * WG_TILE_BYTES; adA2[i] = adA[i] ^ 64; }
 #pragma unroll
@@ -238,7 +263,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
         // tile's LDS-DMA goes out behind the first fragment requests, so only those are exposed per tile
         load(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !WG_ISSUE_SPLIT) issue(t + 1, buf ^ 1, 0, NQ);
+        if (more && !WG_ISSUE_SPLIT) issue(t + WG_NBUF - 1, nbuf, 0, NQ);
         __builtin_amdgcn_sched_barrier(0);
         pp_static_for_wg<NKS>([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value;
@@ -248,11 +273,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             } else landed(ks_c, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (WG_ISSUE_SPLIT && ks < NKS - 1)
-                if (more) issue(t + 1, buf ^ 1, ks * NQ / (NKS - 1), (ks + 1) * NQ / (NKS - 1));
+                if (more) issue(t + WG_NBUF - 1, nbuf, ks * NQ / (NKS - 1), (ks + 1) * NQ / (NKS - 1));
             mma(ks_c);
             __builtin_amdgcn_sched_barrier(0);
         });
-        buf ^= 1;
+        buf = buf + 1 == WG_NBUF ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -438,10 +463,10 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_TILE_BYTES));
+        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NBUF * 2 * WG_TILE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), 4 * WG_TILE_BYTES, st, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), WG_NBUF * 2 * WG_TILE_BYTES, st, a);
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
     WgRedArgs r;
     memset(&r, 0, sizeof(r));
