@@ -301,19 +301,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #pragma unroll
                 for (int i = 0; i < HR; ++i) cur[t][i] = nxt[t][i];
         }
-        // heads (h = cur stays live until the rgb/sigma block)
-        if (a.n_sem) {
-            uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), srow);
-            gv(4 + a.D, sh);
-            layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
-        }
-        if (a.n_inst) {
-            uint32_t sh[TILES][GR];
-            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), srow);
-            gv(5 + a.D, sh);
-            layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
-        }
         // next sample group's inputs: issued here so their HBM latency hides under the feature/views layers
         {
             const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
@@ -331,6 +318,19 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
+        // panoptic heads, after the appearance branch (plan order; h = cur stays live to the end)
+        if (a.n_sem) {
+            uint32_t sh[TILES][GR];
+            layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), srow);
+            gv(4 + a.D, sh);
+            layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_sem, 4, samp);
+        }
+        if (a.n_inst) {
+            uint32_t sh[TILES][GR];
+            layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), srow);
+            gv(5 + a.D, sh);
+            layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+        }
 #if PNR_TRACE
         ++c.titer;
 #endif
@@ -527,18 +527,6 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             for (int i = 0; i < HR; ++i) cur[i] = nxt[i];       // (32 v_pk_mov_b32 instead of these 64 v_mov_b32: +-0 measured)
         }
 #endif
-        if (a.n_sem) {
-            uint32_t sh[GR];
-            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), srow);
-            gv(4 + a.D, sh);
-            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
-        }
-        if (a.n_inst) {
-            uint32_t sh[GR];
-            pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
-            gv(5 + a.D, sh);
-            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
-        }
         {
             const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
             nextin = fetch(g2);
@@ -551,6 +539,19 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         pp_layer_out<TRAIN, CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
+        // panoptic heads, after the appearance branch (plan order)
+        if (a.n_sem) {
+            uint32_t sh[GR];
+            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), srow);
+            gv(4 + a.D, sh);
+            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
+        }
+        if (a.n_inst) {
+            uint32_t sh[GR];
+            pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
+            gv(5 + a.D, sh);
+            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+        }
 #if PNR_TRACE
         ++c.titer;
 #endif

@@ -47,6 +47,11 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         else if (i - 1 == d.skip) add(PNR_L_TRUNK, i, d.W, PNR_SEG_GX, 0, PNR_SEG_FEAT, d.W);
         else add(PNR_L_TRUNK, i, d.W, PNR_SEG_FEAT, d.W);
     }
+    // appearance first, panoptic heads last: sigma (hence every sample's compositing weight) is known before the logit
+    // blocks are produced, which is what lets the fused inference epilogue reduce them over the ray on the fly
+    add(PNR_L_FEATURE, 0, d.W, PNR_SEG_FEAT, d.W);
+    add(PNR_L_VIEWS, 0, d.W / 2, PNR_SEG_FEAT, d.W, PNR_SEG_GD, 0);
+    add(PNR_L_RGBSIGMA, 0, 4, PNR_SEG_FEAT, d.W / 2, PNR_SEG_FEAT, d.W);
     if (d.n_sem) {
         add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
         add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.head_W);
@@ -55,9 +60,6 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
         add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.head_W);
     }
-    add(PNR_L_FEATURE, 0, d.W, PNR_SEG_FEAT, d.W);
-    add(PNR_L_VIEWS, 0, d.W / 2, PNR_SEG_FEAT, d.W, PNR_SEG_GD, 0);
-    add(PNR_L_RGBSIGMA, 0, 4, PNR_SEG_FEAT, d.W / 2, PNR_SEG_FEAT, d.W);
     int off = 0, mx = 0;
     for (size_t li = 0; li < plan.layers.size(); ++li) {
         const PnrLayer& L = plan.layers[li];

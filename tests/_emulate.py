@@ -111,14 +111,14 @@ def emulate(img_u8, pts, viewdirs):
     for l in range(1, D):
         h = layer([ex, h], W, True) if l - 1 == skip else layer([h], W, True)
     raw = np.zeros((n, 4 + n_sem + n_inst), np.float32)
+    f = layer([h], W, False)                      # plan order: appearance branch first, panoptic heads last
+    g = layer([f, ed], W // 2, True)
+    raw[:, 0:4] = layer([g, h], 4, False, to_regs=False)
     if n_sem:
         sh = layer([h], W // 2, True)
         raw[:, 4:4 + n_sem] = layer([sh], n_sem, False, to_regs=False)
     if n_inst:
         sh = layer([h], W // 2, True)
         raw[:, 4 + n_sem:] = layer([sh], n_inst, False, to_regs=False)
-    f = layer([h], W, False)
-    g = layer([f, ed], W // 2, True)
-    raw[:, 0:4] = layer([g, h], 4, False, to_regs=False)
     assert state["ci"] == im.n_chunks, (state["ci"], im.n_chunks)
     return raw

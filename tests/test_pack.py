@@ -40,14 +40,14 @@ def test_image_header_and_sizes():
     img = ops.pack_mlp(desc, net.nerf_0.state_dict())
     im = PackedImage(img)
     assert img.numel() == _lib.load().pnr_mlp_packed_bytes(ctypes.byref(desc))
-    # bf16 chunks hold 4 (layer 0) / 2 (hidden) row blocks: trunk 2 + 7*4, sem 2+2, inst 2+1, feature 4, views 2, rgb/sigma 1
-    assert im.n_chunks == 30 + 4 + 3 + 4 + 2 + 1
+    # bf16 chunks hold 4 (layer 0) / 2 (hidden) row blocks: trunk 2 + 7*4, feature 4, views 2, rgb/sigma 1, sem 2+2, inst 2+1
+    assert im.n_chunks == 30 + 4 + 2 + 1 + 4 + 3
     assert im.max_frags == 41      # skip-layer chunk: 2 blocks x (4 gamma(x) + 16 h) k-steps + bias
     assert int(im.table[:, 1].sum()) * 1024 + im.data_off == img.numel()
     # fp32 image: twice the k-steps
     d32 = ops.make_desc(n_sem=45, n_inst=32, precision="fp32")
     im32 = PackedImage(ops.pack_mlp(d32, net.nerf_0.state_dict()))
-    assert im32.n_chunks == 64 + 6 + 5 + 8 + 4 + 1 and im32.max_frags == 49     # fp32: one block per chunk
+    assert im32.n_chunks == 64 + 8 + 4 + 1 + 6 + 5 and im32.max_frags == 49     # fp32: one block per chunk
 
 
 def test_pack_rejects_missing_parameters():
