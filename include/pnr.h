@@ -117,6 +117,21 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
                     int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
                     int64_t raw_stride_c, void* stream);
 
+/* ---- a5 + a6 fused (inference): evaluate the network and composite in ONE pass -- the raw image (4 + n_sem + n_inst floats per
+ * sample) never goes to HBM.  The fused MLP's epilogue reduces every 32-sample tile to one record (csrc/pnr_mlp_fuse.h:
+ * transmittance factor, weighted sums of 1, z, sigmoid(rgb), the logits and the fixed fields: 20 B per sample instead of
+ * 324 at 45 / 32 heads) and a second small kernel finishes each ray from its n_samples / 32 records.  Replaces the pair
+ * pnr_mlp_forward + pnr_composite (same reference rows: render_rays' network call + raw2outputs, /root/reference/README.md:13
+ * points to the branch that holds them) under: bf16, logits compositing (sem_mode 0), no sigma noise, n_samples a
+ * multiple of 32 in [32, 256], n_sem + n_inst <= 128.  Results equal the two-kernel path to fp32 rounding (the sums are
+ * associated per tile).  Outputs as pnr_composite's (any may be null; fix_* need their labels); weights (R,N) optional.
+ * workspace: pnr_mlp_forward_composite_workspace_bytes(desc, n_rays, n_samples, weights != null) device bytes. */
+int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights);
+int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                              int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
+                              int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
+                              float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream);
+
 /* ---- a9 (training): forward that also saves what the backward needs, the data-gradient pass, and the
  * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
  *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output, one

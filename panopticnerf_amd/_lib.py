@@ -63,6 +63,9 @@ SIGNATURES = {
     "pnr_mlp_backward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_f, c_i64, c_int, c_f]),
     "pnr_mlp_wgrad_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
     "pnr_mlp_wgrad": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, ctypes.POINTER(MlpParamsHost), c_f, c_f]),
+    "pnr_mlp_forward_composite_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64, c_int, c_int]),
+    "pnr_mlp_forward_composite": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
+                                          c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "pnr_common.h"
+#include "pnr_lane_ops.h"
 
 struct CompositeArgs {
     const float* raw; int64_t stride_s, stride_c;
@@ -53,43 +54,6 @@ __device__ __forceinline__ f4 load4(const float* __restrict__ raw, int64_t ss, i
         for (int k = 0; k < 4; ++k) o.v[k] = p[k * ss];
     }
     return o;
-}
-
-// x + x[lane ^ D] without touching LDS where DPP can do it: quad_perm for D = 1, 2; row_half_mirror /
-// row_mirror for D = 4, 8 (a lane is paired with a lane of the OTHER half of its 8 / 16 group, which is all
-// a sum butterfly needs); ds_swizzle for D = 16; ds_bpermute (via __shfl_xor) only for D = 32.
-template <int D>
-__device__ __forceinline__ float xor_add(float x)
-{
-    const int xi = __float_as_int(x);
-    int yi;
-    if constexpr (D == 1) yi = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true);
-    else if constexpr (D == 2) yi = __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xF, 0xF, true);
-    else if constexpr (D == 4) yi = __builtin_amdgcn_mov_dpp(xi, 0x141, 0xF, 0xF, true);
-    else if constexpr (D == 8) yi = __builtin_amdgcn_mov_dpp(xi, 0x140, 0xF, 0xF, true);
-    else if constexpr (D == 16) yi = __builtin_amdgcn_ds_swizzle(xi, 0x401F);
-    else yi = __shfl_xor(xi, 32, 64);
-    return x + __int_as_float(yi);
-}
-
-template <int SUB>
-__device__ __forceinline__ float group_sum(float x)
-{
-    if constexpr (SUB > 1) x = xor_add<1>(x);
-    if constexpr (SUB > 2) x = xor_add<2>(x);
-    if constexpr (SUB > 4) x = xor_add<4>(x);
-    if constexpr (SUB > 8) x = xor_add<8>(x);
-    if constexpr (SUB > 16) x = xor_add<16>(x);
-    if constexpr (SUB > 32) x = xor_add<32>(x);
-    return x;
-}
-
-template <int SUB, int NB>
-__device__ __forceinline__ void group_sum_batch(float (&r)[NB])
-{
-#define PNR_STEP(D) if constexpr (SUB > D) { _Pragma("unroll") for (int j = 0; j < NB; ++j) r[j] = xor_add<D>(r[j]); }
-    PNR_STEP(1) PNR_STEP(2) PNR_STEP(4) PNR_STEP(8) PNR_STEP(16) PNR_STEP(32)
-#undef PNR_STEP
 }
 
 __device__ __forceinline__ float dot4(const f4& w, const f4& v)
@@ -567,5 +531,69 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
     if (ch_major) { if (sem_mode) launch_composite<true, true>(sub, grid, lds, st, a); else launch_composite<true, false>(sub, grid, lds, st, a); }
     else { if (sem_mode) launch_composite<false, true>(sub, grid, lds, st, a); else launch_composite<false, false>(sub, grid, lds, st, a); }
     PNR_CHECK_LAUNCH("pnr_composite");
+    return PNR_OK;
+}
+
+
+// ------------------------------------------------------------------------------- second half of the fused path
+// k_composite_combine: finishes every ray from the N / 32 per-tile records the fused MLP epilogue wrote (pnr_mlp_fuse.h):
+//   out_c = sum_k T_k S_c(k),  T_k = prod_{k' < k} Q_k';   weights_i = T_{i / 32} lw_i.
+// One wave per ray, lane = record column; ~20 B per sample of traffic instead of the raw image's 324 B.
+struct CombineArgs {
+    const float* rec; int rec_floats; const float* lw;
+    int64_t R; int N, C, K, white_bkgd, has_fix_s, has_fix_i;
+    float *rgb, *depth, *acc, *weights, *sem, *inst, *fix_sem, *fix_inst;
+};
+
+__global__ __launch_bounds__(256) void k_composite_combine(CombineArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (ray >= a.R) return;
+    const int T = a.N >> 5, RF = a.rec_floats, C = a.C, K = a.K;
+    const float* rec = a.rec + ray * T * RF;
+    float Tk[8];
+    float t = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        Tk[k] = t;
+        if (k < T) t *= rec[k * RF];
+    }
+    float accv = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < T) accv = fmaf(Tk[k], rec[k * RF + 1], accv);
+    for (int c = 1 + lane; c < 6 + 2 * (C + K); c += 64) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < T) v = fmaf(Tk[k], rec[k * RF + c], v);
+        if (c == 1) { if (a.acc) a.acc[ray] = v; }
+        else if (c == 2) { if (a.depth) a.depth[ray] = v; }
+        else if (c < 6) { if (a.rgb) a.rgb[ray * 3 + (c - 3)] = a.white_bkgd ? v + (1.0f - accv) : v; }
+        else if (c < 6 + C) { if (a.sem) a.sem[ray * C + (c - 6)] = v; }
+        else if (c < 6 + C + K) { if (a.inst) a.inst[ray * K + (c - 6 - C)] = v; }
+        else if (c < 6 + 2 * C + K) { if (a.fix_sem && a.has_fix_s) a.fix_sem[ray * C + (c - 6 - C - K)] = v; }
+        else { if (a.fix_inst && a.has_fix_i) a.fix_inst[ray * K + (c - 6 - 2 * C - K)] = v; }
+    }
+    if (a.weights) {
+        for (int i = lane; i < a.N; i += 64) {
+            float tk = Tk[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) tk = (i >> 5) == k ? Tk[k] : tk;
+            a.weights[ray * a.N + i] = tk * a.lw[ray * a.N + i];
+        }
+    }
+}
+
+int pnr_composite_combine_launch(const float* rec, int rec_floats, const float* lw, int64_t R, int N, int C, int K, int white_bkgd,
+                                 int has_fix_s, int has_fix_i, float* rgb, float* depth, float* acc, float* weights, float* sem,
+                                 float* inst, float* fix_sem, float* fix_inst, hipStream_t st)
+{
+    CombineArgs a;
+    a.rec = rec; a.rec_floats = rec_floats; a.lw = lw; a.R = R; a.N = N; a.C = C; a.K = K; a.white_bkgd = white_bkgd;
+    a.has_fix_s = has_fix_s; a.has_fix_i = has_fix_i;
+    a.rgb = rgb; a.depth = depth; a.acc = acc; a.weights = weights; a.sem = sem; a.inst = inst; a.fix_sem = fix_sem; a.fix_inst = fix_inst;
+    const int64_t blocks = (R + 3) / 4;
+    hipLaunchKernelGGL(k_composite_combine, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    PNR_CHECK_LAUNCH("pnr_mlp_forward_composite (combine)");
     return PNR_OK;
 }

@@ -36,6 +36,7 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
 #include "pnr_mlp_pp.h"
+#include "pnr_mlp_fuse.h"
 #ifndef PNR_OPT_EAGER_EPI
 #define PNR_OPT_EAGER_EPI 1
 #endif
@@ -403,9 +404,11 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
     }
 }
 
-template <bool TRAIN, class CTX, int NA, int NB>
+// FUSE: the block is not stored; it is reduced into the tile's compositing record (pnr_mlp_fuse.h), all in the L phase
+template <bool TRAIN, bool FUSE, class CTX, int NA, int NB>
 __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
-                                             const uint32_t (&inB)[NB > 0 ? NB : 1], int n_out, int ch_base, int samp)
+                                             const uint32_t (&inB)[NB > 0 ? NB : 1], int n_out, int ch_base, int samp,
+                                             FuseState* st = nullptr, uint32_t* hist = nullptr)
 {
     using CH = PPChunk<1, NA, NB>;
     const int nfb = (n_out + 31) >> 5;
@@ -434,14 +437,17 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
             c.pending_stores = cnt;
         }
 #else
-        if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
+        if constexpr (FUSE) {
+            if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, c.a.N, acc[0], hist);
+            else fuse_logits(*st, c.hi, c.lane & 31, fb, n_out, 6 + (ch_base - 4), acc[0]);
+        } else if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
         c.refill_rest();
 #endif
         c.advance();
     }
 }
 
-template <int W, bool TRAIN>
+template <int W, bool TRAIN, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 {
     constexpr int WAVES = 8;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 
     uint32_t dummy[1] = {0};
     u32x4 A[CTX::P];
-    struct SampleIn { float4 o4, d4; float zz; };
+    struct SampleIn { float4 o4, d4; float zz, zn; };
     auto fetch = [&](int grp) {
         const int s = (grp * WAVES + c.wave) * 32 + n;
         const int sl = s < a.S ? s : a.S - 1;
@@ -471,9 +477,13 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         in.o4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8);
         in.d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
         in.zz = a.z[sl];
+        in.zn = FUSE ? a.z[sl + 1 < a.S ? sl + 1 : sl] : 0.0f;     // z of the next sample (used inside a ray only)
         return in;
     };
     SampleIn nextin = fetch(blockIdx.x < a.n_groups ? blockIdx.x : 0);
+    // FUSE: this wave's bbox-prior histogram (C + K <= 128 bins) behind the three weight slots
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(smem + 3 * a.slot_bytes) + c.wave * 128;
+    FuseState fst;
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int s0 = (grp * WAVES + c.wave) * 32 + n;
@@ -491,6 +501,11 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             vd[0] = dx / nrm; vd[1] = dy / nrm; vd[2] = dz / nrm;
             embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
             if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow, c.hi, ex);
+            if constexpr (FUSE) {
+                // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off -> the same value as nrm
+                fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.lw = 0.0f;
+                fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
+            }
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
@@ -538,19 +553,19 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         uint32_t g[GR];
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
-        pp_layer_out<TRAIN, CTX, GR, HR>(c, A, g, cur, 4, 0, samp);
+        pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst, hist);
         // panoptic heads, after the appearance branch (plan order)
         if (a.n_sem) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), srow);
             gv(4 + a.D, sh);
-            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp);
+            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp, &fst, hist);
         }
         if (a.n_inst) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
-            pp_layer_out<TRAIN, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp, &fst, hist);
         }
 #if PNR_TRACE
         ++c.titer;
@@ -570,15 +585,15 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #endif
 }
 
-template <int W, bool TRAIN>
+template <int W, bool TRAIN, bool FUSE = false>
 static int launch_mlp_pp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
-    const int lds_bytes = 3 * a.slot_bytes + (PNR_TRACE ? 8 * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
+    const int lds_bytes = 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0) + (PNR_TRACE ? 8 * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
     PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_forward: three weight slots of %d bytes exceed the 160 KiB LDS", a.slot_bytes);
     PNR_REQUIRE(a.n_chunks >= 4, "pnr_mlp_forward: network too small for the weight stream");
     a.n_groups = (a.S + 255) / 256;
-    auto kern = k_mlp_pp<W, TRAIN>;
+    auto kern = k_mlp_pp<W, TRAIN, FUSE>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -693,6 +708,61 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
                                int64_t raw_stride_c, void* stream)
 {
     return mlp_forward_impl(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, nullptr, stream);
+}
+
+int pnr_composite_combine_launch(const float* rec, int rec_floats, const float* lw, int64_t R, int N, int C, int K, int white_bkgd,
+                                 int has_fix_s, int has_fix_i, float* rgb, float* depth, float* acc, float* weights, float* sem,
+                                 float* inst, float* fix_sem, float* fix_inst, hipStream_t st);
+
+// workspace of pnr_mlp_forward_composite: one record per 32-sample tile (padded to whole 256-sample groups) and, when the
+// per-sample weights are wanted, one float per sample
+PNR_EXPORT int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights)
+{
+    if (pnr_mlp_validate(desc) != PNR_OK || n_rays < 0 || n_samples < 32 || (n_samples & 31)) return -1;
+    const int64_t S = n_rays * n_samples, tiles = (S + 255) / 256 * 8;
+    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + (want_weights ? S * 4 : 0) + 256;
+}
+
+// a5 + a6 fused (inference, bf16, logits compositing, N % 32 == 0): the maps of every ray without the raw image round trip.
+// label_sem / label_inst (R*N int32, -1 = none) and their fix_* outputs are optional; any output may be null.
+PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                         int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
+                                         int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
+                                         float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_composite: bf16 only");
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 32 && n_samples <= 256 && (n_samples & 31) == 0,
+                "pnr_mlp_forward_composite: n_samples=%d must be a multiple of 32 in [32,256]", n_samples);
+    PNR_REQUIRE(desc->n_sem + desc->n_inst <= 128, "pnr_mlp_forward_composite: n_sem + n_inst <= 128");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(packed && rays && z && workspace, "pnr_mlp_forward_composite: null pointer");
+    PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_forward_composite: R*N exceeds 2^31");
+    PNR_REQUIRE((((uintptr_t)rays | (uintptr_t)packed | (uintptr_t)workspace) & 15) == 0,
+                "pnr_mlp_forward_composite: rays / packed / workspace must be 16-byte aligned");
+    PNR_REQUIRE((!fix_sem || label_sem) && (!fix_inst || label_inst), "pnr_mlp_forward_composite: fix_* outputs need their labels");
+    PnrPlan plan;
+    pnr_build_plan(*desc, plan);
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.data = (const uint8_t*)packed + plan.data_off;
+    a.table = (const pnr_chunk_entry*)((const uint8_t*)packed + plan.table_off);
+    a.n_chunks = (int)plan.chunks.size();
+    a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
+    a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples;
+    a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.rec_floats = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
+    a.rec = (float*)workspace;
+    const int64_t tiles = ((int64_t)a.S + 255) / 256 * 8;
+    a.lw = weights ? a.rec + tiles * a.rec_floats : nullptr;
+    a.lab_s = fix_sem ? label_sem : nullptr;
+    a.lab_i = fix_inst ? label_inst : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    rc = desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
+    if (rc != PNR_OK) return rc;
+    return pnr_composite_combine_launch(a.rec, a.rec_floats, a.lw, n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd,
+                                        a.lab_s != nullptr, a.lab_i != nullptr, rgb, depth, acc, weights, sem, inst, fix_sem, fix_inst, st);
 }
 
 PNR_EXPORT int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

@@ -390,6 +390,49 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
     return out
 
 
+def fused_supported(desc, n_samples, sem_mode=0, noise=None):
+    """Can pnr_mlp_forward_composite take this level?  bf16, logits compositing, no sigma noise, N a multiple of 32."""
+    return (desc.precision == _lib.PREC_BF16 and int(sem_mode) == 0 and noise is None and n_samples % 32 == 0
+            and 32 <= n_samples <= 256 and desc.n_sem + desc.n_inst <= 128)
+
+
+@_on_device
+def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True):
+    """Rows a5 + a6 in one pass (inference): the fused MLP reduces every 32-sample tile to one compositing record in its
+    epilogue and k_composite_combine finishes the rays -- the raw image (324 B per sample at 45 / 32 heads) is never
+    written.  Same dict as composite().  Sums are associated per tile, so results equal mlp_forward + composite to fp32
+    rounding (not bit for bit)."""
+    rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
+    label_sem = _chk(label_sem, "label_sem", torch.int32)
+    label_inst = _chk(label_inst, "label_inst", torch.int32)
+    R, N = z.shape
+    n_sem, n_inst = desc.n_sem, desc.n_inst
+    dev = z.device
+    lib = _lib.load()
+    nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, int(bool(want_weights)))
+    if nbytes < 0:
+        raise RuntimeError("pnr_mlp_forward_composite: unsupported geometry (n_samples=%d must be a multiple of 32)" % N)
+    ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"rgb": torch.empty((R, 3), **f32), "depth": torch.empty((R,), **f32), "acc": torch.empty((R,), **f32)}
+    if want_weights:
+        out["weights"] = torch.empty((R, N), **f32)
+    if n_sem:
+        out["semantic"] = torch.empty((R, n_sem), **f32)
+        if label_sem is not None:
+            out["fix_semantic"] = torch.empty((R, n_sem), **f32)
+    if n_inst:
+        out["instance"] = torch.empty((R, n_inst), **f32)
+        if label_inst is not None:
+            out["fix_instance"] = torch.empty((R, n_inst), **f32)
+    g = out.get
+    _lib.check(lib.pnr_mlp_forward_composite(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(label_sem), _p(label_inst),
+                                             int(bool(white_bkgd)), _p(out["rgb"]), _p(out["depth"]), _p(out["acc"]),
+                                             _p(g("weights")), _p(g("semantic")), _p(g("instance")), _p(g("fix_semantic")),
+                                             _p(g("fix_instance")), _p(ws), _stream()), "pnr_mlp_forward_composite")
+    return out
+
+
 @_on_device
 def composite_backward(raw, z, rays, n_sem, n_inst, grads, noise=None, label_sem=None, label_inst=None,
                        ce_sem=None, ce_inst=None, sem_mode=0):

@@ -16,6 +16,8 @@ output keys, level l in {0 (coarse), 1 (fine)}:
              rgb_l (B,N_rays,3) depth_l acc_l (B,N_rays) weights_l z_vals_l (B,N_rays,N_l)
              semantic_l / fix_semantic_l (B,N_rays,C), instance_l / fix_instance_l (B,N_rays,K)
 """
+import os
+
 import torch
 
 from . import ops
@@ -39,6 +41,9 @@ class Renderer:
         self.max_hits = _get(cfg, "max_hits", 8)
         self.sem_mode = {"none": 0, "logits": 0, "softmax": 1}[_get(cfg, "semantic_activation", "none")]
         self.keep_weights = _get(cfg, "keep_weights", True)
+        # inference levels run the fused MLP + compositing pass where it applies (bf16, logits compositing, N % 32 == 0);
+        # cfg.fuse_composite = False (or PNR_FUSE=0) keeps the two-kernel path with the raw image in HBM
+        self.fuse = bool(_get(cfg, "fuse_composite", os.environ.get("PNR_FUSE", "1") != "0"))
         self.strict_hits = bool(_get(cfg, "strict_hits", False))
         if self.N_importance > 0 and getattr(net, "nerf_1", None) is None and not getattr(net, "share_coarse_fine", False):
             raise ValueError("make_renderer: cfg asks for a fine pass (N_importance / cascade_samples = %d) but the network "
@@ -75,9 +80,13 @@ class Renderer:
                 out = _train.level_train(self, lv, rays, zz, ls, li, noise)
             else:
                 desc, img = net.packed(lv, dev)
-                raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
                 need_w = self.keep_weights or (lv == 0 and Nf > 0)
-                out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
+                if self.fuse and ops.fused_supported(desc, zz.shape[1], self.sem_mode, noise):
+                    # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite)
+                    out = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w)
+                else:
+                    raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
+                    out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
             for k, v in out.items():
                 ret[f"{k}_{lv}"] = v
             ret[f"z_vals_{lv}"] = zz

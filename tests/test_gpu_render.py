@@ -145,10 +145,20 @@ def test_render_full_frame_properties(dev):
         assert (out[f"fix_semantic_{lv}"].sum(-1) <= out[f"acc_{lv}"] + 1e-4).all()
     # chunk independence / idempotence: any subset of rays rendered alone gives the same maps
     idx = torch.arange(0, 376 * 1408, 1409)
-    sub = rend.render({"rays": rays[idx][None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)})
+    sb = {"rays": rays[idx][None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        sub = rend.render(sb)
     for k in ("rgb_1", "depth_1", "semantic_1", "instance_1", "fix_semantic_1", "z_vals_1"):
         a = out[k].reshape(-1, *out[k].shape[2:])[idx.to(dev)]
         assert torch.equal(a, sub[k][0]), k
+    # the differentiable path (grad enabled: training forward + k_composite, the raw image in HBM) against the fused inference
+    # pass: same coarse maps to fp32 rounding (the per-ray sums are associated differently), fine maps to ~1e-3 (the fine
+    # samples follow the coarse weights' last bits and gamma() amplifies them)
+    trn = rend.render(sb)
+    assert torch.equal(trn["z_vals_0"], sub["z_vals_0"])
+    for k in ("rgb_0", "depth_0", "semantic_0", "fix_semantic_0", "weights_0"):
+        assert float((trn[k] - sub[k]).abs().max()) <= 4e-6 * max(1.0, float(sub[k].abs().max())), k
+    assert float(torch.quantile((trn["rgb_1"] - sub["rgb_1"]).abs().flatten(), 0.99)) < 5e-3
     # and the subset agrees with the oracle (bf16 emulation) where it can afford to run
     ref = to.render_rays(params, oc, rays[idx], 64, 128, box=box, box_ids=ids, emulate_bf16=True)
     assert (sub["rgb_1"][0].cpu() - ref["rgb_1"]).abs().max() < 2e-2

@@ -407,3 +407,75 @@ def test_mlp_pingpong_equals_lockstep_bit_for_bit(dev, R, N, train):
                 assert torch.equal(got[1], want[1]), rep
     finally:
         lib.pnr_mlp_set_variant(prev)
+
+
+# ----------------------------------------------------------------------------- a5 + a6 fused: no raw image round trip
+@pytest.mark.parametrize("heads", [(45, 32), (6, 0), (0, 0)])
+@pytest.mark.parametrize("R,N,labels,white", [(510, 192, True, False), (512, 64, True, True), (37, 32, False, False),
+                                              (129, 256, True, False), (1, 96, False, True)])
+def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, heads):
+    """pnr_mlp_forward_composite (per-tile records in the MLP's epilogue + k_composite_combine) against pnr_mlp_forward +
+    pnr_composite on the same inputs: every map, the per-sample weights and the fixed (bbox-prior) fields.  The two paths
+    associate the per-ray sums differently (per 32-sample tile, then over tiles), so they agree to fp32 rounding: 2e-6 of
+    the map's scale; the fixed fields additionally round through 2^-30 fixed point per tile.  Ragged sample counts (R*N not a
+    multiple of 256), one ray, several tiles per ray, labels on and off, white background."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K)).to(dev)
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    desc, img = net.packed(1, dev, "bf16")
+    ls = li = None
+    if labels and (C or K):
+        g = torch.Generator(device=dev).manual_seed(1)
+        hit = torch.rand((R, N), device=dev, generator=g) < 0.3
+        if C:
+            ls = torch.where(hit, torch.randint(0, C, (R, N), device=dev, generator=g), -1).int()
+        if K:
+            li = torch.where(hit, torch.randint(0, K, (R, N), device=dev, generator=g), -1).int()
+    assert ops.fused_supported(desc, N)
+    raw = ops.mlp_forward(desc, img, rays, z, channel_major=True)
+    want = ops.composite(raw, z, rays, C, K, True, None, ls, li, 0, white, True)
+    for rep in range(2):
+        got = ops.mlp_forward_composite(desc, img, rays, z, ls, li, white, True)
+        assert set(got) == set(want)
+        for k in want:
+            scale = max(1.0, float(want[k].abs().max()))
+            err = float((got[k] - want[k]).abs().max())
+            assert err <= (4e-6 if k.startswith("fix_") else 2e-6) * scale * (N // 32), (k, err, scale, rep)
+    # without the weights / labels the other outputs are unchanged
+    lean = ops.mlp_forward_composite(desc, img, rays, z, None, None, white, False)
+    assert "weights" not in lean and "fix_semantic" not in lean
+    assert torch.equal(lean["rgb"], got["rgb"]) and torch.equal(lean["depth"], got["depth"])
+
+
+def test_fused_path_is_what_the_renderer_runs_and_can_be_switched_off(dev):
+    """Renderer.render (inference, bf16) takes the fused pass by default; cfg.fuse_composite = False keeps mlp_forward +
+    composite.  Both give the same maps to fp32 rounding, identical z (the coarse weights feed sample_pdf: a weight that
+    differs in the last bit may move a fine sample across a bin edge, so z_vals_1 is compared by fraction)."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network, make_renderer
+    cfg = dict(N_samples=64, N_importance=128, num_classes=7, num_instances=4, precision="bf16", chunk_size=4096)
+    torch.manual_seed(3)
+    net = make_network(NS(**cfg)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[::1033][:500].contiguous().to(dev)
+    box, ids = synthetic.random_boxes(16, 7, 4)
+    batch = {"rays": rays[None], "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        a = make_renderer(NS(**cfg), net).render(batch)
+        b = make_renderer(NS(fuse_composite=False, **cfg), net).render(batch)
+    assert torch.equal(a["z_vals_0"], b["z_vals_0"])
+    for k in ("rgb_0", "depth_0", "acc_0", "semantic_0", "instance_0", "fix_semantic_0", "fix_instance_0", "weights_0"):
+        x, y = a[k][0], b[k][0]
+        assert float((x - y).abs().max()) <= 4e-6 * max(1.0, float(y.abs().max())), k
+    # the fine samples are a continuous function of the coarse weights: last-bit differences there move them by ~1e-6 of the
+    # ray length, which gamma() amplifies 2^9-fold -- the fine maps agree to ~1e-3, not to rounding
+    # (a few samples sit where the coarse CDF is flat and jump with the last bit of a weight: judged by fraction)
+    assert float(((a["z_vals_1"] - b["z_vals_1"]).abs() > 1e-3).float().mean()) < 1e-3
+    for k in ("rgb_1", "acc_1", "semantic_1", "instance_1", "fix_semantic_1", "fix_instance_1"):
+        x, y = a[k][0], b[k][0]
+        assert float(torch.quantile((x - y).abs().flatten(), 0.99)) <= 5e-3 * max(1.0, float(y.abs().max())), k
