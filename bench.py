@@ -329,8 +329,20 @@ def main():
             desc, img = net.packed(top, dev)
             ch = 4 + N_SEM + N_INST
             raw = ops.alloc_raw(ch, Rc * N_TOP, dev)   # as Renderer allocates it
-            ops.time_mlp_forward(desc, img, rc, z, raw, 1)
-            ms, kernel_mhz = ops.time_mlp_forward_clk(desc, img, rc, z, raw, 5)
+            ops.time_mlp_forward(desc, img, rc, z, raw, 1)                  # fills raw for the compositing measurements below
+            # the launch the step actually runs: with the fused compositing epilogue where the renderer uses it
+            fused = bool(getattr(rend, "fuse", False)) and ops.fused_supported(desc, N_TOP, rend.sem_mode, None)
+            if fused:
+                fls = fli = None
+                if c["bbox"]:
+                    fh = ops.bbox_hits(rc, box, cfg.max_hits if hasattr(cfg, "max_hits") else 8)
+                    fls, fli = ops.sample_labels(z, fh[0], fh[1], fh[2], ids)
+                    fls, fli = (fls if N_SEM else None), (fli if N_INST else None)
+                need_w = bool(rend.keep_weights or not N_F)
+                ops.time_mlp_forward_composite_clk(desc, img, rc, z, fls, fli, need_w, 1)
+                ms, kernel_mhz = ops.time_mlp_forward_composite_clk(desc, img, rc, z, fls, fli, need_w, 5)
+            else:
+                ms, kernel_mhz = ops.time_mlp_forward_clk(desc, img, rc, z, raw, 5)
             # what the matrix pipe of THIS device sustains (register-only MFMA loop): with constant operands, and with
             # random operands that change from MFMA to MFMA (the toggle rate of real data: the chip lowers its clock)
             pk_const, mhz_const = ops.probe_mfma_peak(False, 12000, dev)
@@ -340,7 +352,8 @@ def main():
             flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-            kname = "k_mlp_pp" if (ops.mlp_variant() >= 1 and args.precision == "bf16") else "k_mlp_fused"
+            kname = ("k_mlp_pp<fused compositing epilogue>" if fused else
+                     "k_mlp_pp" if (ops.mlp_variant() >= 1 and args.precision == "bf16") else "k_mlp_fused")
             roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", Rc, args.config),

@@ -132,6 +132,13 @@ int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, cons
                               int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
                               float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream);
 
+/* bench only: mean ms per fused MLP launch of pnr_mlp_forward_composite (without the combine kernel) over `iters` launches, and
+ * the mean shader clock during the last one (scratch: >= 16 device bytes). */
+int pnr_time_mlp_forward_composite_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                       int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
+                                       int want_weights, void* workspace, int iters, void* scratch, float* ms_out_host,
+                                       float* mhz_out_host, void* stream);
+
 /* ---- a9 (training): forward that also saves what the backward needs, the data-gradient pass, and the
  * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
  *   acts : bf16, pnr_mlp_train_layout's acts_off[D+6] elements -- gamma(x), gamma(d) and every layer's output, one

@@ -66,6 +66,8 @@ SIGNATURES = {
     "pnr_mlp_forward_composite_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64, c_int, c_int]),
     "pnr_mlp_forward_composite": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
                                           c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_time_mlp_forward_composite_clk": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int, c_f, c_int,
+                                                   c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,

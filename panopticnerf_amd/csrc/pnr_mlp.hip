@@ -723,28 +723,23 @@ PNR_EXPORT int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc*
     return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + (want_weights ? S * 4 : 0) + 256;
 }
 
-// a5 + a6 fused (inference, bf16, logits compositing, N % 32 == 0): the maps of every ray without the raw image round trip.
-// label_sem / label_inst (R*N int32, -1 = none) and their fix_* outputs are optional; any output may be null.
-PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                         int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
-                                         int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
-                                         float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream)
+// the fused MLP launch alone (records + optional local weights into `workspace`); `a` is returned for the combine step
+static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z, int64_t n_rays,
+                            int n_samples, const int32_t* label_sem, const int32_t* label_inst, int want_weights,
+                            void* workspace, void* stream, MlpArgs& a)
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_composite: bf16 only");
-    PNR_REQUIRE(n_rays >= 0 && n_samples >= 32 && n_samples <= 256 && (n_samples & 31) == 0,
+    PNR_REQUIRE(n_rays >= 1 && n_samples >= 32 && n_samples <= 256 && (n_samples & 31) == 0,
                 "pnr_mlp_forward_composite: n_samples=%d must be a multiple of 32 in [32,256]", n_samples);
     PNR_REQUIRE(desc->n_sem + desc->n_inst <= 128, "pnr_mlp_forward_composite: n_sem + n_inst <= 128");
-    if (n_rays == 0) return PNR_OK;
     PNR_REQUIRE(packed && rays && z && workspace, "pnr_mlp_forward_composite: null pointer");
     PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 31) - 4096, "pnr_mlp_forward_composite: R*N exceeds 2^31");
     PNR_REQUIRE((((uintptr_t)rays | (uintptr_t)packed | (uintptr_t)workspace) & 15) == 0,
                 "pnr_mlp_forward_composite: rays / packed / workspace must be 16-byte aligned");
-    PNR_REQUIRE((!fix_sem || label_sem) && (!fix_inst || label_inst), "pnr_mlp_forward_composite: fix_* outputs need their labels");
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
-    MlpArgs a;
     memset(&a, 0, sizeof(a));
     a.data = (const uint8_t*)packed + plan.data_off;
     a.table = (const pnr_chunk_entry*)((const uint8_t*)packed + plan.table_off);
@@ -755,14 +750,64 @@ PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* p
     a.rec_floats = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
     a.rec = (float*)workspace;
     const int64_t tiles = ((int64_t)a.S + 255) / 256 * 8;
-    a.lw = weights ? a.rec + tiles * a.rec_floats : nullptr;
-    a.lab_s = fix_sem ? label_sem : nullptr;
-    a.lab_i = fix_inst ? label_inst : nullptr;
+    a.lw = want_weights ? a.rec + tiles * a.rec_floats : nullptr;
+    a.lab_s = label_sem; a.lab_i = label_inst;
+    a.clk = g_clk_buf;
     hipStream_t st = (hipStream_t)stream;
-    rc = desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
+    return desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
+}
+
+// a5 + a6 fused (inference, bf16, logits compositing, N % 32 == 0): the maps of every ray without the raw image round trip.
+// label_sem / label_inst (R*N int32, -1 = none) and their fix_* outputs are optional; any output may be null.
+PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                         int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
+                                         int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
+                                         float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream)
+{
+    PNR_REQUIRE(n_rays >= 0, "pnr_mlp_forward_composite: bad size");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE((!fix_sem || label_sem) && (!fix_inst || label_inst), "pnr_mlp_forward_composite: fix_* outputs need their labels");
+    MlpArgs a;
+    int rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, fix_sem ? label_sem : nullptr, fix_inst ? label_inst : nullptr,
+                              weights != nullptr, workspace, stream, a);
     if (rc != PNR_OK) return rc;
     return pnr_composite_combine_launch(a.rec, a.rec_floats, a.lw, n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd,
-                                        a.lab_s != nullptr, a.lab_i != nullptr, rgb, depth, acc, weights, sem, inst, fix_sem, fix_inst, st);
+                                        a.lab_s != nullptr, a.lab_i != nullptr, rgb, depth, acc, weights, sem, inst, fix_sem, fix_inst,
+                                        (hipStream_t)stream);
+}
+
+// bench only: mean ms per FUSED MLP launch (the kernel the inference step runs; the combine kernel is not included) and the
+// mean shader clock during the last one (scratch: >= 16 device bytes)
+PNR_EXPORT int pnr_time_mlp_forward_composite_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
+                                                  int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
+                                                  int want_weights, void* workspace, int iters, void* scratch, float* ms_out_host,
+                                                  float* mhz_out_host, void* stream)
+{
+    PNR_REQUIRE(iters >= 1 && ms_out_host && mhz_out_host && scratch && n_rays >= 1, "pnr_time_mlp_forward_composite_clk: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    PNR_HIP(hipEventCreate(&e0));
+    PNR_HIP(hipEventCreate(&e1));
+    g_clk_buf = (unsigned long long*)scratch;
+    PNR_HIP(hipEventRecord(e0, st));
+    int rc = PNR_OK;
+    for (int i = 0; i < iters && rc == PNR_OK; ++i) {
+        MlpArgs a;
+        rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, label_sem, label_inst, want_weights, workspace, stream, a);
+    }
+    g_clk_buf = nullptr;
+    if (rc != PNR_OK) return rc;
+    PNR_HIP(hipEventRecord(e1, st));
+    PNR_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out_host = ms / (float)iters;
+    unsigned long long h[2] = {0, 1};
+    PNR_HIP(hipMemcpy(h, scratch, sizeof(h), hipMemcpyDeviceToHost));
+    *mhz_out_host = h[1] ? (float)(100.0 * (double)h[0] / (double)h[1]) : 0.0f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PNR_OK;
 }
 
 PNR_EXPORT int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

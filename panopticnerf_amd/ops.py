@@ -323,6 +323,24 @@ def time_mlp_forward_clk(desc, packed, rays, z, raw, iters):
     return float(ms.value), float(mhz.value)
 
 
+@_on_device
+def time_mlp_forward_composite_clk(desc, packed, rays, z, label_sem=None, label_inst=None, want_weights=False, iters=5):
+    """(mean ms per FUSED MLP launch -- pnr_mlp_forward_composite without its combine kernel --, mean shader MHz) -- bench only."""
+    rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
+    label_sem = _chk(label_sem, "label_sem", torch.int32)
+    label_inst = _chk(label_inst, "label_inst", torch.int32)
+    R, N = z.shape
+    lib = _lib.load()
+    nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, int(bool(want_weights)))
+    ws = torch.empty(int(nbytes), device=z.device, dtype=torch.uint8)
+    ms, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    scratch = torch.zeros(4, device=z.device, dtype=torch.int64)
+    _lib.check(lib.pnr_time_mlp_forward_composite_clk(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(label_sem), _p(label_inst),
+                                                      int(bool(want_weights)), _p(ws), int(iters), _p(scratch), ctypes.byref(ms),
+                                                      ctypes.byref(mhz), _stream()), "pnr_time_mlp_forward_composite_clk")
+    return float(ms.value), float(mhz.value)
+
+
 def mlp_variant(variant=None):
     """Which form of the fused bf16 MLP pnr_mlp_forward launches: 0 lock-step (k_mlp_fused), 1 ping-pong (k_mlp_pp) for
     inference launches (default), 2 ping-pong for the training forward as well.  Returns the setting in force BEFORE the
