@@ -1,3 +1,11 @@
 #!/bin/bash
-for v in r4 r5 r8; do echo "== test $v"; PNR_LIB_PATH=build/ab/libpnr_$v.so timeout 300 python -m pytest tests/test_gpu_backward.py -x -q -m gpu -k "wgrad or mlp_backward" 2>&1 | grep -E "passed|failed|error|Error|assert" | head -5; done
-for v in r2 r4 r5 r8 r2 r4 r5 r8; do echo "== $v"; PNR_LIB_PATH=build/ab/libpnr_$v.so timeout 200 python tools/train_profile.py 2>&1 | grep -E "pnr_mlp_wgrad"; done
+# one bench line per BASELINE config on the final head (fused inference pass where it applies)
+mkdir -p gpurun_out/r02i
+for c in 1 2 3 4; do
+  timeout 200 python bench.py --config $c --steps 5 --warmup 2 --cpu-seconds 0 --train-steps 0 2>/dev/null | tail -1 > gpurun_out/r02i/bench_config$c.json
+  python - <<P
+import json
+d=json.loads(open("gpurun_out/r02i/bench_config$c.json").read())
+print($c, d["value"], d["ms_per_step"], d["roofline"]["kernel"][:60], d["roofline"]["frac"], d.get("roofline_composite",{}).get("frac"))
+P
+done
