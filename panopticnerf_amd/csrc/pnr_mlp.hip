@@ -371,9 +371,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         if (cb == 0 || !PNR_PP_EARLY_BIAS) CH::bias_issue(c.bias_addr(), q);
         f32x16 acc[FBC];
         CH::bias_finish(q, acc);                                // waits for every LDS read of the phase
-        c.barrier();                                            // L -> M
-        c.stamp(2);
-        CH::mma(c.frag_addr(), A, inA, inB, acc);
+        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });      // L -> M (barrier inside, see mma)
         auto epilogue = [&](int b) {
             const int fb = cb * FBC + b;
 #pragma unroll
@@ -416,9 +414,7 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
     for (int fb = 0; fb < nfb; ++fb) {
         f32x16 acc[1];
         CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
-        c.barrier();
-        c.stamp(2);
-        CH::mma(c.frag_addr(), A, inA, inB, acc);
+        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
         c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
         c.refill_begin();
         c.refill_one();

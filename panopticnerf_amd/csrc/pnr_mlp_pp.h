@@ -81,6 +81,9 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #endif
 // timing-only ablations (A/B builds; results are wrong): 1 = no refill pieces, 2 = no fragment reads inside the MFMA loop
 // 1: the first fragments of a layer's 2nd, 3rd, ... chunk are read right after the previous chunk's M -> L barrier
+#ifndef PNR_PP_HEAD
+#define PNR_PP_HEAD 0        /* MFMAs of a chunk issued before its L -> M barrier (soft hand-over of the matrix pipe) */
+#endif
 #ifndef PNR_PP_EARLY
 #define PNR_PP_EARLY 1
 #endif
@@ -285,16 +288,31 @@ struct PPChunk {
     }
 
     // M: the chunk's MFMAs, one wave alone on its SIMD's matrix pipe.
+    // PNR_PP_HEAD > 0 (soft hand-over): the first HEAD MFMAs are issued BEFORE the L -> M barrier, at low priority.  The chunk's
+    // weights landed two phases ago and were covered by a barrier then (the L phase already reads its bias and first
+    // fragments), so only the pipe hand-over hangs on this barrier: the partner group's last MFMAs keep priority, and these
+    // fill its gaps and the ~100 cycles the barrier itself takes.
+    template <class BARRIER>
     __device__ __forceinline__ static void mma(uint32_t fa, u32x4 (&A)[P], const uint32_t (&inA)[NA],
-                                               const uint32_t (&inB)[NB > 0 ? NB : 1], f32x16 (&acc)[FBC])
+                                               const uint32_t (&inB)[NB > 0 ? NB : 1], f32x16 (&acc)[FBC], BARRIER&& barrier)
     {
+        constexpr int HEAD = PNR_PP_HEAD < NF / 2 ? PNR_PP_HEAD : NF / 2;
+        if constexpr (HEAD == 0) {
+            barrier();
 #if PNR_PP_PRIO
-        __builtin_amdgcn_s_setprio(PNR_PP_PRIO);
+            __builtin_amdgcn_s_setprio(PNR_PP_PRIO);
 #endif
+        }
         pp_static_for<NF>([&](auto I) {
             constexpr int i = I;
             constexpr int ks = i / FBC, b = i % FBC;
             constexpr int younger = (NF - 1 - i) < (P - 2) ? (NF - 1 - i) : (P - 2);
+            if constexpr (HEAD > 0 && i == HEAD) {
+                barrier();
+#if PNR_PP_PRIO
+                __builtin_amdgcn_s_setprio(PNR_PP_PRIO);
+#endif
+            }
             pp_wait<younger>(A[i % P]);
             if constexpr (ks < KSA) acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inA[4 * ks], acc[b]);
             else acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inB[4 * (ks - KSA)], acc[b]);

@@ -1,11 +1,3 @@
 #!/bin/bash
-# one bench line per BASELINE config on the final head (fused inference pass where it applies)
-mkdir -p gpurun_out/r02i
-for c in 1 2 3 4; do
-  timeout 200 python bench.py --config $c --steps 5 --warmup 2 --cpu-seconds 0 --train-steps 0 2>/dev/null | tail -1 > gpurun_out/r02i/bench_config$c.json
-  python - <<P
-import json
-d=json.loads(open("gpurun_out/r02i/bench_config$c.json").read())
-print($c, d["value"], d["ms_per_step"], d["roofline"]["kernel"][:60], d["roofline"]["frac"], d.get("roofline_composite",{}).get("frac"))
-P
-done
+for v in h4 h8; do echo "== test $v"; PNR_LIB_PATH=build/ab/libpnr_$v.so timeout 300 python -m pytest tests/test_gpu_stages.py -x -q -m gpu -k "pingpong or fused_mlp" 2>&1 | grep -E "passed|failed|error|Error|assert" | head -5; done
+python tools/mlp_variants.py h0:1 h2:1 h4:1 h8:1 h0:1 h2:1 h4:1 h8:1 2>&1 | grep -v amdgpu.ids
