@@ -1,0 +1,30 @@
+"""Same-box A/B of libpnr builds on the FUSED fine-level MLP launch (65536 rays x 192 samples, 45 / 32 heads, scene labels), one
+process per build.  usage: python tools/fused_ab.py name1 name2 ...   (names under build/ab/, or 'default')"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from types import SimpleNamespace as NS
+from panopticnerf_amd import make_network, ops, synthetic
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = make_network(NS(N_importance=128, num_classes=45, num_instances=32)).eval()
+synthetic.trained_like_(net)
+net = net.to(dev)
+rays = synthetic.camera_rays()[:65536].to(dev)
+z = ops.stratified(rays, 192)
+desc, img = net.packed(1, dev)
+box, ids = (t.to(dev) for t in synthetic.random_boxes(64, 45, 32))
+h = ops.bbox_hits(rays, box, 8)
+ls, li = ops.sample_labels(z, h[0], h[1], h[2], ids)
+ops.time_mlp_forward_composite_clk(desc, img, rays, z, ls, li, False, 2)
+r = [ops.time_mlp_forward_composite_clk(desc, img, rays, z, ls, li, False, 5) for _ in range(3)]
+ms, mhz = min(r)
+print("%%-10s fused launch %%8.3f ms at %%5.0f MHz" %% (sys.argv[1], ms, mhz), flush=True)
+''' % ROOT
+for name in sys.argv[1:]:
+    env = dict(os.environ)
+    if name != "default":
+        env["PNR_LIB_PATH"] = os.path.join(ROOT, "build", "ab", "libpnr_%s.so" % name)
+    subprocess.run([sys.executable, "-c", CHILD, name], env=env, check=False)
