@@ -81,6 +81,62 @@ def composite(raw, z, rays, C, K, noise=None, label_sem=None, label_inst=None, s
     return out
 
 
+def composite_by_tiles(raw, z, rays, C, K, tile=32, label_sem=None, label_inst=None, white_bkgd=False):
+    """The factorisation the fused inference pass uses (csrc/pnr_mlp_fuse.h + k_composite_combine), restated with plain loops:
+    every `tile` consecutive samples of a ray are reduced on their own to a record
+        Q = prod (1 - alpha + 1e-10),   S_c = sum lw_i v_ci   with   lw_i = alpha_i prod_{j < i in tile} (1 - alpha_j + 1e-10),
+    and the ray is finished from its records:  out_c = sum_k T_k S_c(k),  T_k = prod_{k' < k} Q_k',  weights_i = T_k lw_i.
+    Must equal composite() (logits mode) up to rounding: tests/test_oracle.py checks it, so the GPU test that compares the
+    fused kernels with k_composite rests on a CPU statement of WHY the two agree.  raw (R,N,4+C+K) sample-major."""
+    raw = np.asarray(raw, np.float64)
+    z = np.asarray(z, np.float64)
+    rays = np.asarray(rays, np.float64)
+    R, N = z.shape
+    assert N % tile == 0
+    out = dict(rgb=np.zeros((R, 3)), depth=np.zeros(R), acc=np.zeros(R), weights=np.zeros((R, N)),
+               semantic=np.zeros((R, C)), instance=np.zeros((R, K)),
+               fix_semantic=np.zeros((R, C)), fix_instance=np.zeros((R, K)))
+    for r in range(R):
+        dn = np.sqrt((rays[r, 3:6] ** 2).sum())
+        records = []
+        for k in range(N // tile):                       # ---- what one wave of the MLP does for its tile
+            rec = dict(Q=1.0, acc=0.0, depth=0.0, rgb=np.zeros(3), sem=np.zeros(C), inst=np.zeros(K), fs=np.zeros(C),
+                       fi=np.zeros(K), lw=np.zeros(tile))
+            for j in range(tile):
+                i = k * tile + j
+                dist = (z[r, i + 1] - z[r, i]) if i + 1 < N else 1e10      # z of the next sample: also across the tile edge
+                alpha = 1.0 - np.exp(-max(raw[r, i, 3], 0.0) * dist * dn)
+                lw = alpha * rec["Q"]
+                rec["Q"] *= (1.0 - alpha + 1e-10)
+                rec["lw"][j] = lw
+                rec["acc"] += lw
+                rec["depth"] += lw * z[r, i]
+                rec["rgb"] += lw / (1.0 + np.exp(-raw[r, i, 0:3]))
+                if C:
+                    rec["sem"] += lw * raw[r, i, 4:4 + C]
+                    if label_sem is not None and 0 <= label_sem[r, i] < C:
+                        rec["fs"][label_sem[r, i]] += lw
+                if K:
+                    rec["inst"] += lw * raw[r, i, 4 + C:4 + C + K]
+                    if label_inst is not None and 0 <= label_inst[r, i] < K:
+                        rec["fi"][label_inst[r, i]] += lw
+            records.append(rec)
+        T = 1.0                                            # ---- what k_composite_combine does for the ray
+        for k, rec in enumerate(records):
+            out["acc"][r] += T * rec["acc"]
+            out["depth"][r] += T * rec["depth"]
+            out["rgb"][r] += T * rec["rgb"]
+            out["semantic"][r] += T * rec["sem"]
+            out["instance"][r] += T * rec["inst"]
+            out["fix_semantic"][r] += T * rec["fs"]
+            out["fix_instance"][r] += T * rec["fi"]
+            out["weights"][r, k * tile:(k + 1) * tile] = T * rec["lw"]
+            T *= rec["Q"]
+        if white_bkgd:
+            out["rgb"][r] += 1.0 - out["acc"][r]
+    return out
+
+
 def sample_pdf(z, weights, Nf, u=None):
     """Coarse z (R,Nc), coarse weights (R,Nc) -> z_samples (R,Nf), inds (R,Nf)."""
     z = np.asarray(z, np.float64)

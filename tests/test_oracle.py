@@ -293,3 +293,25 @@ def test_panoptic_quality_oracle_known_answer():
     t2 = no.panoptic_quality_terms(pr2, gt, 2)
     # gt 1000 vs pred 1000 (5 px): inter 3, union 5 -> .6 TP; gt 1001 vs pred 1002 (1 valid px): inter 1, union 3 -> FN, FP
     assert np.allclose(t2[1], [0.6, 1, 1, 1])
+
+
+@pytest.mark.parametrize("N,tile", [(32, 32), (64, 32), (96, 32), (64, 8), (24, 4)])
+def test_tile_factorisation_equals_the_scan(N, tile):
+    """The fused inference pass (csrc/pnr_mlp_fuse.h) composites per 32-sample tile and finishes the ray from the tile records.
+    The numpy restatement of that factorisation must reproduce the plain scan -- every map, the per-sample weights and the
+    fixed fields, also with opaque samples (alpha = 1 up to the 1e-10), empty space (sigma <= 0) and a white background."""
+    rng = np.random.default_rng(N * 100 + tile)
+    R, C, K = 7, 5, 3
+    raw = rng.normal(0, 1.5, (R, N, 4 + C + K))
+    raw[:, :, 3] = rng.normal(0.2, 1.0, (R, N))
+    raw[0, :, 3] = -1.0                      # an empty ray
+    raw[1, N // 3, 3] = 1e4                  # an opaque sample: everything behind it carries weight ~1e-10
+    rays = np.concatenate([rng.normal(0, 1, (R, 3)), rng.normal(0, 1, (R, 3)), np.full((R, 1), 0.5), np.full((R, 1), 30.0)], 1)
+    z = no.stratified(rays, N, t_rand=rng.random((R, N)))
+    ls = np.where(rng.random((R, N)) < 0.4, rng.integers(0, C, (R, N)), -1)
+    li = np.where(ls >= 0, rng.integers(0, K, (R, N)), -1)
+    for white in (False, True):
+        a = no.composite(raw, z, rays, C, K, None, ls, li, 0, white)
+        b = no.composite_by_tiles(raw, z, rays, C, K, tile, ls, li, white)
+        for k in a:
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-12, atol=1e-13, err_msg=k)
