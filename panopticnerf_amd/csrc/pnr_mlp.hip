@@ -36,6 +36,9 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
 #include "pnr_mlp_pp.h"
+#ifndef PNR_FUSE_TRANSPOSED
+#define PNR_FUSE_TRANSPOSED 1      /* fused epilogue: logit blocks computed transposed (operands swapped), see PPChunk::mma<SWAP> */
+#endif
 #include "pnr_mlp_fuse.h"
 #ifndef PNR_OPT_EAGER_EPI
 #define PNR_OPT_EAGER_EPI 1
@@ -413,8 +416,14 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
 #pragma unroll 1
     for (int fb = 0; fb < nfb; ++fb) {
         f32x16 acc[1];
-        CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
-        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
+        const bool logits_t = FUSE && PNR_FUSE_TRANSPOSED && ch_base != 0;      // wave-uniform
+        if (logits_t) {
+            CH::prologue_swapped(c.frag_addr(), c.bias_addr() - c.hi * 16, c.lane, A, acc);
+            CH::template mma<true>(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
+        } else {
+            CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
+            CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
+        }
         c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
         c.refill_begin();
         c.refill_one();
@@ -435,6 +444,7 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
 #else
         if constexpr (FUSE) {
             if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, c.a.N, acc[0], hist);
+            else if (PNR_FUSE_TRANSPOSED) fuse_logits_t(*st, c.hi, c.lane, fb, n_out, 6 + (ch_base - 4), acc[0]);
             else fuse_logits(*st, c.hi, c.lane & 31, fb, n_out, 6 + (ch_base - 4), acc[0]);
         } else if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
         c.refill_rest();

@@ -21,6 +21,7 @@
 __host__ __device__ static inline int pnr_fuse_record_floats(int C, int K) { return (6 + 2 * (C + K) + 3) & ~3; }
 
 struct FuseState {
+    float lws[32];     // the tile's 32 local weights as wave-uniform values (v_readlane of lw): the logit blocks multiply by them
     float lw;          // this lane's sample weight inside its tile (both half-waves hold their sample n = lane & 31)
     float zz, zn, dn;  // z of the sample, z of the ray's next sample, |d|
     int samp;          // sample index or -1
@@ -56,6 +57,8 @@ __device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int h
     tile_scan(f, n, excl, q);
     const float lw = alpha * excl;
     st.lw = lw;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) st.lws[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), k));
     const bool lo = hi == 0;
     float r[5];
     r[0] = lo ? lw : 0.0f;
@@ -99,4 +102,21 @@ __device__ __forceinline__ void fuse_logits(FuseState& st, int hi, int n, int fb
     for (int k = 1; k < 16; ++k) v = (n == k) ? r[k] : v;
     const int row = fb * 32 + pnr_row_of(n & 15, hi);
     if (n < 16 && row < n_out) st.rec[rec_base + row] = v;
+}
+
+// a 32-channel logit block computed TRANSPOSED (PPChunk::mma<SWAP>: lane = channel fb*32 + (lane & 31), register r = sample
+// row(r, hi)): the weighted sum over the tile's samples is 16 FMAs against the wave-uniform weights (both halves' row sets are
+// evaluated, the lane keeps its own), one exchange between the half-waves, and one contiguous 128-byte store
+__device__ __forceinline__ void fuse_logits_t(FuseState& st, int hi, int lane, int fb, int n_out, int rec_base, const f32x16& acc)
+{
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s0 = fmaf(st.lws[pnr_row_of(r, 0)], acc[r], s0);
+        s1 = fmaf(st.lws[pnr_row_of(r, 1)], acc[r], s1);
+    }
+    float s = hi ? s1 : s0;
+    s += __shfl_xor(s, 32, 64);
+    const int ch = fb * 32 + (lane & 31);
+    if (hi == 0 && ch < n_out) st.rec[rec_base + ch] = s;
 }

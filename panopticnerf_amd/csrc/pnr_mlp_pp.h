@@ -279,6 +279,19 @@ struct PPChunk {
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // transposed product (SWAP): every register of lane j starts at the bias of output channel j = lane & 31.
+    // ba0: LDS address of the chunk's slot (no lane part); FBC == 1.
+    __device__ __forceinline__ static void prologue_swapped(uint32_t fa, uint32_t ba0, int lane, u32x4 (&A)[P], f32x16 (&acc)[FBC])
+    {
+        static_assert(FBC == 1, "transposed output blocks are single-block chunks");
+        first_frags(fa, A);
+        float bj;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bj) : "v"(ba0 + (uint32_t)(lane & 31) * 4u), "n"(BIAS_OFF));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bj));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = bj;
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __device__ __forceinline__ static void prologue(uint32_t fa, uint32_t ba, u32x4 (&A)[P], f32x16 (&acc)[FBC])
     {
         f32x4 q[FBC][4];
@@ -292,7 +305,12 @@ struct PPChunk {
     // weights landed two phases ago and were covered by a barrier then (the L phase already reads its bias and first
     // fragments), so only the pipe hand-over hangs on this barrier: the partner group's last MFMAs keep priority, and these
     // fill its gaps and the ~100 cycles the barrier itself takes.
-    template <class BARRIER>
+    // SWAP: the fragment is the MFMA's B operand and the activations its A operand.  A weight fragment (lane = output row, 8
+    // consecutive k) IS the B-operand image of the transposed weights (lane = output column, 8 consecutive k), and the
+    // activation registers (lane = sample, 8 consecutive k) ARE an A operand with rows = samples: the product comes out
+    // transposed -- lane = output channel, register r = sample row(r, hi) -- which is what the fused compositing epilogue
+    // wants for the logit blocks (the weighted sum over the samples becomes 16 FMAs per lane instead of 16 butterflies).
+    template <bool SWAP = false, class BARRIER>
     __device__ __forceinline__ static void mma(uint32_t fa, u32x4 (&A)[P], const uint32_t (&inA)[NA],
                                                const uint32_t (&inB)[NB > 0 ? NB : 1], f32x16 (&acc)[FBC], BARRIER&& barrier)
     {
@@ -314,7 +332,13 @@ struct PPChunk {
 #endif
             }
             pp_wait<younger>(A[i % P]);
-            if constexpr (ks < KSA) acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inA[4 * ks], acc[b]);
+            if constexpr (SWAP) {
+                const uint32_t* act = ks < KSA ? &inA[4 * (ks < KSA ? ks : 0)] : &inB[4 * (ks >= KSA ? ks - KSA : 0)];
+                u32x4 av;
+                av[0] = act[0]; av[1] = act[1]; av[2] = act[2]; av[3] = act[3];
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, A[i % P]),
+                                                                  acc[b], 0, 0, 0);
+            } else if constexpr (ks < KSA) acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inA[4 * ks], acc[b]);
             else acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inB[4 * (ks - KSA)], acc[b]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (i + P - 1 < NF && !(PNR_PP_ABL & 2)) {
