@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 
     uint32_t dummy[1] = {0};
     u32x4 A[CTX::P];
-    struct SampleIn { float4 o4, d4; float zz, zn; };
+    struct SampleIn { float4 o4, d4; float zz, zn; int ls, li; };
     auto fetch = [&](int grp) {
         const int s = (grp * WAVES + c.wave) * 32 + n;
         const int sl = s < a.S ? s : a.S - 1;
@@ -484,6 +484,10 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         in.d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
         in.zz = a.z[sl];
         in.zn = FUSE ? a.z[sl + 1 < a.S ? sl + 1 : sl] : 0.0f;     // z of the next sample (used inside a ray only)
+        // bbox-prior labels of the sample: requested a whole sample group ahead like the rest (loaded inside the epilogue they
+        // cost an HBM round trip in an L phase the partner's short output-layer M phase cannot cover)
+        in.ls = (FUSE && a.lab_s) ? a.lab_s[sl] : -1;
+        in.li = (FUSE && a.lab_i) ? a.lab_i[sl] : -1;
         return in;
     };
     SampleIn nextin = fetch(blockIdx.x < a.n_groups ? blockIdx.x : 0);
@@ -510,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (FUSE) {
                 // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off -> the same value as nrm
                 fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.lw = 0.0f;
+                fst.ls = nextin.ls; fst.li = nextin.li;
                 fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
             }
         }

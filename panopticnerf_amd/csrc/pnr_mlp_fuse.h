@@ -25,6 +25,7 @@ struct FuseState {
     float lw;          // this lane's sample weight inside its tile (both half-waves hold their sample n = lane & 31)
     float zz, zn, dn;  // z of the sample, z of the ray's next sample, |d|
     int samp;          // sample index or -1
+    int ls, li;        // bbox-prior labels of the sample (-1: none), fetched with the sample's inputs
     float* rec;        // this tile's record
 };
 
@@ -79,8 +80,8 @@ __device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int h
         for (int c = lane; c < CK; c += 64) hist[c] = 0;
         if (lo && valid) {
             const uint32_t fx = (uint32_t)(lw * PNR_FUSE_FIX_SCALE + 0.5f);
-            if (want_s) { const int l = a.lab_s[st.samp]; if (l >= 0 && l < C) atomicAdd(&hist[l], fx); }
-            if (want_i) { const int l = a.lab_i[st.samp]; if (l >= 0 && l < K) atomicAdd(&hist[C + l], fx); }
+            if (want_s) { const int l = st.ls; if (l >= 0 && l < C) atomicAdd(&hist[l], fx); }
+            if (want_i) { const int l = st.li; if (l >= 0 && l < K) atomicAdd(&hist[C + l], fx); }
         }
         float* fixrec = st.rec + 6 + CK;
         for (int c = lane; c < CK; c += 64)
