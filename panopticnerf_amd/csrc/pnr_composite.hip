@@ -258,11 +258,6 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
 #ifndef CMP2_UB
 #define CMP2_UB 8
 #endif
-template <int CTRL>
-__device__ __forceinline__ float dpp_or(float x, float identity)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, 0xF, 0xF, false));
-}
 
 template <int L, int M4, bool SOFTMAX>
 __global__ __launch_bounds__(256) void k_composite2(CompositeArgs a)

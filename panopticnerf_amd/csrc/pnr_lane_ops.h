@@ -39,3 +39,10 @@ __device__ __forceinline__ void group_sum_batch(float (&r)[NB])
     PNR_STEP(1) PNR_STEP(2) PNR_STEP(4) PNR_STEP(8) PNR_STEP(16) PNR_STEP(32)
 #undef PNR_STEP
 }
+
+// DPP move with an identity for lanes whose source is out of range (row_shr / row_shl / wave_shr ...): no LDS involved
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_or(float x, float identity)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}

@@ -29,18 +29,20 @@ struct FuseState {
     float* rec;        // this tile's record
 };
 
-// exclusive prefix product over the 32 lanes of a half-wave (both halves hold the same data), and the total
+// exclusive prefix product over the 32 lanes of a half-wave (both halves hold the same data), and the total.  All DPP:
+// row_shr 1, 2, 4, 8 scan each 16-lane row, row_bcast15 carries row 0's total into row 1 (and row 2's into row 3); the
+// __shfl_up form of this scan was a chain of six LDS-crossbar round trips in an L phase that a short M phase cannot cover.
 __device__ __forceinline__ void tile_scan(float f, int n, float& excl, float& total)
 {
     float x = f;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        const float y = __shfl_up(x, d, 32);
-        if (n >= d) x *= y;
-    }
-    excl = __shfl_up(x, 1, 32);
+    x *= dpp_or<0x111>(x, 1.0f);                 // row_shr:1
+    x *= dpp_or<0x112>(x, 1.0f);                 // row_shr:2
+    x *= dpp_or<0x114>(x, 1.0f);                 // row_shr:4
+    x *= dpp_or<0x118>(x, 1.0f);                 // row_shr:8   -> inclusive product inside each row of 16
+    x *= dpp_or<0x142, 0xA>(x, 1.0f);            // row_bcast15 into rows 1 and 3 -> inclusive product over the 32 lanes
+    excl = dpp_or<0x138>(x, 1.0f);               // wave_shr:1 (lane 32 receives lane 31: overwritten below)
     if (n == 0) excl = 1.0f;
-    total = __shfl(x, 31, 32);
+    total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
 }
 
 // the rgb / sigma block (rows 0..2 rgb, row 3 sigma: registers 0..3 of the hi = 0 half): weights of the tile, Q, acc, depth, rgb,
