@@ -110,3 +110,24 @@ def test_bbox_invariants(seed, M, mh, scale):
     assert np.array_equal(ls >= 0, inside) and np.array_equal(li >= 0, inside)
     if M:
         assert set(np.unique(ls)) <= set(ids[:, 0]) | {-1}
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 6), st.sampled_from([2, 4, 8]), st.integers(0, 2 ** 31 - 1))
+def test_compositing_factorises_over_tiles(n_tiles, tile, seed):
+    """For ANY split of a ray into equal tiles, per-tile records (transmittance factor + locally weighted sums) recombine to the
+    plain front-to-back scan: the identity the fused MLP + compositing pass rests on (np_oracle.composite_by_tiles)."""
+    from oracle import np_oracle as no
+    rng = np.random.default_rng(seed)
+    N, R, C, K = n_tiles * tile, 3, 4, 2
+    raw = rng.normal(0, 2.0, (R, N, 4 + C + K))
+    raw[:, :, 3] = rng.normal(0.0, 3.0, (R, N))          # about half the samples are empty (sigma <= 0)
+    rays = np.concatenate([rng.normal(0, 1, (R, 3)), rng.normal(0, 1, (R, 3)) + 0.1, np.full((R, 1), 0.5), np.full((R, 1), 20.0)], 1)
+    z = no.stratified(rays, N, t_rand=rng.random((R, N)))
+    ls = np.where(rng.random((R, N)) < 0.5, rng.integers(0, C, (R, N)), -1)
+    li = np.where(rng.random((R, N)) < 0.5, rng.integers(0, K, (R, N)), -1)
+    a = no.composite(raw, z, rays, C, K, None, ls, li, 0, False)
+    b = no.composite_by_tiles(raw, z, rays, C, K, tile, ls, li, False)
+    for k in a:
+        np.testing.assert_allclose(b[k], a[k], rtol=1e-11, atol=1e-12, err_msg=k)
+    assert np.all(b["weights"] >= 0) and np.all(b["weights"].sum(-1) <= 1 + 1e-9)
