@@ -123,3 +123,27 @@ def test_train_layout_is_padded_line_aligned_and_ordered(S):
     gate_bits = Sp * (D * W + 3 * H)
     assert ao[-1] - (ao[5 + D] + Sp * H) >= gate_bits // 16         # bits -> bf16 units
     assert do[-1] == do[D + 6] + Sp * 64
+
+
+def test_fused_pass_eligibility_and_workspace_arithmetic():
+    """Host-side rules of the fused MLP + compositing pass: ops.fused_supported mirrors what pnr_mlp_forward_composite accepts
+    (bf16, logits compositing, no sigma noise, N a multiple of 32 in [32, 256], C + K <= 128), and the workspace is one record of
+    6 + 2 (C + K) floats (padded to 4) per 32-sample tile of whole 256-sample groups, plus one float per sample for the weights."""
+    lib = _lib.load()
+    d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+    assert ops.fused_supported(d, 192) and ops.fused_supported(d, 32) and ops.fused_supported(d, 256)
+    assert not ops.fused_supported(d, 100) and not ops.fused_supported(d, 16) and not ops.fused_supported(d, 288)
+    assert not ops.fused_supported(d, 192, sem_mode=1) and not ops.fused_supported(d, 192, noise=torch.zeros(1))
+    assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "fp32"), 192)
+    assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 100, 60, 128, "bf16"), 192)
+    ws = lib.pnr_mlp_forward_composite_workspace_bytes
+    rec = (6 + 2 * 77 + 3) // 4 * 4
+    assert rec == 160
+    for R, N in ((1, 32), (37, 192), (65536, 192), (510, 64)):
+        S = R * N
+        tiles = (S + 255) // 256 * 8
+        assert ws(ctypes.byref(d), R, N, 0) == tiles * rec * 4 + 256
+        assert ws(ctypes.byref(d), R, N, 1) == tiles * rec * 4 + S * 4 + 256
+    assert ws(ctypes.byref(d), 10, 100, 0) == -1 and ws(ctypes.byref(d), 10, 16, 0) == -1
+    d0 = ops.make_desc(4, 128, -1, 10, 4, 0, 0, 64, "bf16")
+    assert ws(ctypes.byref(d0), 8, 32, 0) == 8 * 8 * 4 + 256          # no heads: 6 floats padded to 8
