@@ -1,6 +1,7 @@
-"""CPU check of the ping-pong MLP's hand-counted LDS waits (pnr_mlp_pp.h): compile pnr_mlp.hip to gfx950 assembly (hipcc
-cross-compiles without a GPU) and run tools/check_lds_pending.py over every kernel in it -- no instruction may read or
-overwrite the destination of an LDS read that the lgkmcnt waits have not covered yet."""
+"""CPU check of the hand-counted LDS waits of the ping-pong MLP (pnr_mlp_pp.h, pnr_mlp_fuse.h) and of k_wgrad's software pipeline
+(pnr_mlp_wgrad.hip): compile the sources to gfx950 assembly (hipcc cross-compiles without a GPU) and run
+tools/check_lds_pending.py over every kernel -- no instruction may read or overwrite the destination of an LDS read that the
+lgkmcnt waits have not covered yet, on ANY path through the kernel's branches (check_cfg follows the control flow)."""
 import os
 import subprocess
 import sys
@@ -21,6 +22,40 @@ def test_lint_detects_a_read_before_its_wait():
     assert len(lint.check(clobber)) == 1 and "overwrites" in lint.check(clobber)[0][2]
 
 
+def test_cfg_walk_sees_hazards_across_branches_and_ignores_other_paths():
+    # the read at the loop bottom is consumed at the loop top without a wait: invisible in program order
+    loop = ["k:", "s_waitcnt lgkmcnt(0)", ".L1:", "v_mov_b32_e32 v20, v4", "ds_read_b128 v[4:7], v1", "s_cbranch_scc1 .L1",
+            "s_waitcnt lgkmcnt(0)", "s_endpgm"]
+    assert lint.check(loop) == [] and any("reads" in f[2] for f in lint.check_cfg(loop))
+    fine = ["k:", ".L1:", "ds_read_b128 v[4:7], v1", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v20, v4", "s_cbranch_scc1 .L1", "s_endpgm"]
+    assert lint.check_cfg(fine) == []
+    # a read on a path that branches away must not count against a block laid out behind it
+    other = ["k:", "s_cbranch_scc1 .LB", "ds_read_b128 v[4:7], v1", "s_branch .LC", ".LB:", "v_mov_b32_e32 v5, v0", "s_endpgm",
+             ".LC:", "s_waitcnt lgkmcnt(0)", "s_endpgm"]
+    assert len(lint.check(other)) == 1 and lint.check_cfg(other) == []
+    # a loop that only issues reads terminates (the pending list is capped where lgkmcnt saturates)
+    spin = ["k:", ".L1:", "ds_read_b128 v[4:7], v1", "s_cbranch_scc1 .L1", "s_waitcnt lgkmcnt(0)", "s_endpgm"]
+    assert all("overwrites" in f[2] for f in lint.check_cfg(spin))
+
+
+def _asm(tmp_path, name):
+    src = os.path.join(ROOT, "panopticnerf_amd", "csrc", name)
+    out = tmp_path / (name + ".s")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.dirname(src), "-Wno-unused-function", "-Wno-unused-command-line-argument", "-S", "--cuda-device-only",
+           "-o", str(out), src]
+    subprocess.check_call(cmd)
+    return open(out).read().split("\n")
+
+
+def test_wgrad_kernel_never_touches_a_pending_lds_destination(tmp_path):
+    text = _asm(tmp_path, "pnr_mlp_wgrad.hip")
+    assert sum(l.strip().startswith("ds_read_b64_tr_b16") for l in text) > 200 and any("s_waitcnt lgkmcnt(12)" in l for l in text)
+    flags = lint.check_cfg(text)
+    assert flags == [], flags[:5]
+
+
 def test_mlp_kernels_never_touch_a_pending_lds_destination(tmp_path):
     src = os.path.join(ROOT, "panopticnerf_amd", "csrc", "pnr_mlp.hip")
     out = tmp_path / "pnr_mlp.s"
@@ -31,5 +66,5 @@ def test_mlp_kernels_never_touch_a_pending_lds_destination(tmp_path):
     subprocess.check_call(cmd)
     text = open(out).read().split("\n")
     assert any("k_mlp_pp" in l for l in text) and sum(l.strip().startswith("ds_read_b128") for l in text) > 500
-    flags = lint.check(text)
+    flags = lint.check(text) + lint.check_cfg(text)
     assert flags == [], flags[:5]
