@@ -130,4 +130,4 @@ def test_compositing_factorises_over_tiles(n_tiles, tile, seed):
     b = no.composite_by_tiles(raw, z, rays, C, K, tile, ls, li, False)
     for k in a:
         np.testing.assert_allclose(b[k], a[k], rtol=1e-11, atol=1e-12, err_msg=k)
-    assert np.all(b["weights"] >= 0) and np.all(b["weights"].sum(-1) <= 1 + 1e-9)
+    assert np.all(b["weights"] >= 0) and np.all(b["weights"].sum(-1) <= 1 + 1e-7)      # (the 1e-10 per factor lets the sum exceed 1 by ~N e-10)
