@@ -464,7 +464,8 @@ def main():
             train_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
     cpu_baseline = None
-    if rank == 0 and (args.cpu_seconds > 0 or args.cpu1_seconds > 0):
+    # the CPU legs run at N = 1 only (rank 0 would otherwise keep N - 1 idle ranks waiting, on host cores the other ranks share)
+    if rank == 0 and world == 1 and (args.cpu_seconds > 0 or args.cpu1_seconds > 0):
         rays_c = rays.cpu()
         box_c, ids_c = (None, None) if box is None else (box.cpu(), ids.cpu())
 
