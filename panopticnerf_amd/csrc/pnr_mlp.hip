@@ -165,6 +165,40 @@ __device__ __forceinline__ void layer_out(CTX& c, const uint32_t (&inA)[TILES][N
     }
 }
 
+// sin and cos of x for the bf16 encoding: Cody-Waite reduction by pi/2 in two exact-product FMAs (k = rint(x * 2/pi);
+// the FMA does not round k * C1, so the difference is rounded once: |error| < 1e-7 for |x| up to ~1e6) and the two degree-7 / 8
+// minimax polynomials on [-pi/4, pi/4].  ~24 VALU instructions, no branch.  libm's sincosf carries a Payne-Hanek path
+// (21 v_mad_u64_u32 per call site) that a wave executes as soon as ONE lane's argument is large -- at the half-wave's
+// base band 2^5 every scene coordinate beyond ~3 m is -- and the six calls per sample group sat, fully exposed, in L
+// phases whose partner group has nothing to multiply (group start, first views chunk: ~4 % of the fine-level launch).
+// Absolute error <= 2e-7, doubled per octave by the recurrences that follow: far below the bf16 rounding (2^-9).
+// The fp32 parity mode keeps libm's sincosf at every band.
+#ifndef PNR_EMBED_FAST_SINCOS
+#define PNR_EMBED_FAST_SINCOS 1
+#endif
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
+{
+#if PNR_EMBED_FAST_SINCOS
+    const float kf = __builtin_rintf(x * 0.636619772367581343f);
+    float r = fmaf(-kf, 1.57079637050628662109375f, x);            // fl(pi/2)
+    r = fmaf(-kf, -4.371139000186241e-08f, r);                      // pi/2 - fl(pi/2)
+    const int k = (int)kf;
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(r2, sp, -1.6666654611e-1f);
+    const float sn = fmaf(r * r2, sp, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(r2, cp, 4.166664568298827e-2f);
+    cp = fmaf(r2, cp, -0.5f);
+    const float cs = fmaf(r2, cp, 1.0f);
+    const float so = (k & 1) ? cs : sn, co = (k & 1) ? sn : cs;
+    s = __uint_as_float(__float_as_uint(so) ^ ((uint32_t)(k & 2) << 30));
+    c = __uint_as_float(__float_as_uint(co) ^ ((uint32_t)((k + 1) & 2) << 30));
+#else
+    sincosf(x, &s, &c);
+#endif
+}
+
 // gamma() of one 3-vector into this lane's share of the lane vector (pnr_mlp_layout.h).
 // NF = frequency bands per half-wave (5 for xyz, 2 for view directions); NV = values per lane.
 template <int PREC, int NF, int NV, int NREG>
@@ -182,7 +216,7 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float s, co;
-            sincosf(pp[a] * base, &s, &co);
+            sincos_cw(pp[a] * base, s, co);
             v[2 + a] = s; v[2 + 3 + a] = co;
 #pragma unroll
             for (int fp = 1; fp < NF; ++fp) {
@@ -245,7 +279,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
     auto fetch = [&](int grp, int t) {
         const int s = ((grp * WAVES + c.wave) * TILES + t) * 32 + n;
         const int sl = s < a.S ? s : a.S - 1;
-        const int ray = sl / a.N;
+        const int ray = pnr_div_magic(sl, a.n_magic, a.n_shift);
         SampleIn in;
         in.o4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8);
         in.d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
@@ -374,7 +408,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         if (cb == 0 || !PNR_PP_EARLY_BIAS) CH::bias_issue(c.bias_addr(), q);
         f32x16 acc[FBC];
         CH::bias_finish(q, acc);                                // waits for every LDS read of the phase
-        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });      // L -> M (barrier inside, see mma)
+        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });      // L -> M (barrier inside, see mma)
         auto epilogue = [&](int b) {
             const int fb = cb * FBC + b;
 #pragma unroll
@@ -419,15 +453,16 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
         const bool logits_t = FUSE && PNR_FUSE_TRANSPOSED && ch_base != 0;      // wave-uniform
         if (logits_t) {
             CH::prologue_swapped(c.frag_addr(), c.bias_addr() - c.hi * 16, c.lane, A, acc);
-            CH::template mma<true>(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
+            CH::template mma<true>(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });
         } else {
             CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
-            CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.barrier(); c.stamp(2); });
+            CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });
         }
         c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
         c.refill_begin();
         c.refill_one();
 #if PNR_PP_STORES_LAST
+        static_assert(!FUSE, "PNR_PP_STORES_LAST: two-kernel path only (the fused kernel has no raw stores)");
         // Every piece first, then the stores, and the NUMBER of store instructions this wave issues is handed to the next
         // m_done(): VMEM operations of a wave complete in order, so `s_waitcnt vmcnt(#stores)` there covers the pieces
         // without waiting for the stores' HBM write acknowledgements (which take longer than two phases).
@@ -443,7 +478,7 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
         }
 #else
         if constexpr (FUSE) {
-            if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, c.a.N, acc[0], hist);
+            if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, acc[0], hist);
             else if (PNR_FUSE_TRANSPOSED) fuse_logits_t(*st, c.hi, c.lane, fb, n_out, 6 + (ch_base - 4), acc[0]);
             else fuse_logits(*st, c.hi, c.lane & 31, fb, n_out, 6 + (ch_base - 4), acc[0]);
         } else if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
@@ -463,8 +498,11 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
     constexpr int HR = NFB * 8, GR = HFB * 8, GXR = 16, GDR = 8;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     CTX c{a, smem, (int)(threadIdx.x & 63), wave, (int)((threadIdx.x & 63) >> 5), wave >= WAVES / 2 ? 1 : 0, 0, 0, 0u, 0u, {0, 0}};
+#if PNR_PP_ABL & 16
+    c.abl_sink = u32x4{0, 0, 0, 0};
+#endif
 #if PNR_TRACE
-    c.tr = reinterpret_cast<unsigned long long*>(smem + 3 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.tr = reinterpret_cast<unsigned long long*>(smem + 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0)) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
     c.titer = 0;
 #endif
     const int n = c.lane & 31;
@@ -474,16 +512,17 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 
     uint32_t dummy[1] = {0};
     u32x4 A[CTX::P];
-    struct SampleIn { float4 o4, d4; float zz, zn; int ls, li; };
+    struct SampleIn { float4 o4, d4; float zz, zn; int ls, li; bool last; };
     auto fetch = [&](int grp) {
         const int s = (grp * WAVES + c.wave) * 32 + n;
         const int sl = s < a.S ? s : a.S - 1;
-        const int ray = sl / a.N;
+        const int ray = pnr_div_magic(sl, a.n_magic, a.n_shift);     // sl / N without the ~40-instruction integer division
         SampleIn in;
         in.o4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8);
         in.d4 = *reinterpret_cast<const float4*>(a.rays + (int64_t)ray * 8 + 4);
         in.zz = a.z[sl];
         in.zn = FUSE ? a.z[sl + 1 < a.S ? sl + 1 : sl] : 0.0f;     // z of the next sample (used inside a ray only)
+        in.last = FUSE ? (sl - ray * a.N + 1 == a.N) : false;      // the ray's last sample: its interval is 1e10
         // bbox-prior labels of the sample: requested a whole sample group ahead like the rest (loaded inside the epilogue they
         // cost an HBM round trip in an L phase the partner's short output-layer M phase cannot cover)
         in.ls = (FUSE && a.lab_s) ? a.lab_s[sl] : -1;
@@ -514,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (FUSE) {
                 // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off -> the same value as nrm
                 fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.lw = 0.0f;
-                fst.ls = nextin.ls; fst.li = nextin.li;
+                fst.ls = nextin.ls; fst.li = nextin.li; fst.last = nextin.last;
                 fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
             }
         }
@@ -590,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #if PNR_TRACE
     __syncthreads();
     if (blockIdx.x == PNR_TRACE_WG && a.trace) {
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes);
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0));
         for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
     }
 #endif
@@ -688,6 +727,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     a.n_chunks = (int)plan.chunks.size();
     a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
     a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples; a.n_groups = 0;
+    pnr_set_div_magic(n_samples, a.n_magic, a.n_shift);
     a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.acts = (uint16_t*)acts;
@@ -757,6 +797,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     a.n_chunks = (int)plan.chunks.size();
     a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
     a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples;
+    pnr_set_div_magic(n_samples, a.n_magic, a.n_shift);
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
     a.rec_floats = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
     a.rec = (float*)workspace;
@@ -764,6 +805,9 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     a.lw = want_weights ? a.rec + tiles * a.rec_floats : nullptr;
     a.lab_s = label_sem; a.lab_i = label_inst;
     a.clk = g_clk_buf;
+#if PNR_TRACE
+    if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     hipStream_t st = (hipStream_t)stream;
     return desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
 }

@@ -22,6 +22,7 @@ struct MlpArgs {
     int n_chunks, slot_bytes;
     const float* rays; const float* z;
     int S, N, n_groups;
+    uint32_t n_magic; int n_shift;  // x / N for 0 <= x < 2^31 as (x * n_magic) >> n_shift (pnr_set_div_magic)
     float* raw; int64_t ss, sc;
     int D, skip, n_sem, n_inst;
     // training only (null otherwise).  acts: activations saved by the forward for the backward,
@@ -35,6 +36,20 @@ struct MlpArgs {
     unsigned long long* clk;        // optional (bench): {shader cycles, 100 MHz ticks} of workgroup 0's first wave
     int64_t acts_off[24], dys_off[24], gate_off[24];     // pnr_train_layout (bf16 units)
 };
+
+// x / d for 0 <= x < 2^31, d >= 1, without an integer division on the device: m = ceil(2^(31+s) / d), s = ceil(log2 d);
+// then m * d - 2^(31+s) <= 2^s, which makes floor(x * m / 2^(31+s)) exact for every x < 2^31 (Granlund-Montgomery).
+static inline void pnr_set_div_magic(int d, uint32_t& magic, int& shift)
+{
+    int s = 0;
+    while ((1ll << s) < (long long)d) ++s;
+    shift = 31 + s;
+    magic = (uint32_t)(((1ull << shift) + (unsigned long long)d - 1) / (unsigned long long)d);
+}
+__device__ __forceinline__ int pnr_div_magic(int x, uint32_t magic, int shift)
+{
+    return (int)(((unsigned long long)(uint32_t)x * magic) >> shift);
+}
 
 #ifndef PNR_ABL_STORE
 #define PNR_ABL_STORE 0

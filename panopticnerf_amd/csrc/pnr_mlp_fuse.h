@@ -26,6 +26,7 @@ struct FuseState {
     float zz, zn, dn;  // z of the sample, z of the ray's next sample, |d|
     int samp;          // sample index or -1
     int ls, li;        // bbox-prior labels of the sample (-1: none), fetched with the sample's inputs
+    bool last;         // the sample is its ray's last one (interval 1e10), from the input prefetch
     float* rec;        // this tile's record
 };
 
@@ -47,12 +48,11 @@ __device__ __forceinline__ void tile_scan(float f, int n, float& excl, float& to
 
 // the rgb / sigma block (rows 0..2 rgb, row 3 sigma: registers 0..3 of the hi = 0 half): weights of the tile, Q, acc, depth, rgb,
 // the per-sample local weights (optional) and the fixed fields
-__device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int hi, int n, int N, const f32x16& acc, uint32_t* hist)
+__device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int hi, int n, const f32x16& acc, uint32_t* hist)
 {
     const bool valid = st.samp >= 0;
     const float sig = __shfl(acc[3], n, 64);                   // sigma of sample n lives in lane n (hi = 0)
-    const int i = valid ? st.samp % N : 0;
-    float dist = (i + 1 < N) ? (st.zn - st.zz) : 1e10f;
+    float dist = st.last ? 1e10f : (st.zn - st.zz);
     dist *= st.dn;
     const float alpha = valid ? 1.0f - expf(-(fmaxf(sig, 0.0f) * dist)) : 0.0f;
     const float f = valid ? (1.0f - alpha) + 1e-10f : 1.0f;

@@ -93,7 +93,6 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #ifndef PNR_PP_ABL
 #define PNR_PP_ABL 0
 #endif
-
 template <int WAVES>
 struct CtxPP {
     static constexpr int P = PNR_PP_RING;
@@ -162,6 +161,9 @@ struct CtxPP {
     {
         if (!grp) barrier();                // pairs with Q's last phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refills issued past the last chunk
+#if PNR_PP_ABL & 16
+        asm volatile("" :: "v"(abl_sink));
+#endif
     }
     __device__ __forceinline__ uint32_t frag_addr() const { return lds_frag + slot_off; }
     __device__ __forceinline__ uint32_t bias_addr() const { return lds_bias + slot_off; }
@@ -213,19 +215,28 @@ struct CtxPP {
         rf_n = (int)en.nfrag;
         en = entry(wrap(ci + 3 + grp));
     }
+    u32x4 abl_sink;        // PNR_PP_ABL & 16 only
+    __device__ __forceinline__ void piece(int f)
+    {
+#if PNR_PP_ABL & 16
+        // ablation (results invalid): the same L2 reads, issued at the same places, but into a register nobody reads -- no LDS write
+        const uint8_t* src = rf_src + (size_t)f * PNR_FRAG_BYTES;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(abl_sink) : "v"(src) : "memory");
+#else
+        __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)f * PNR_FRAG_BYTES),
+                                         (lds_void*)(rf_dst + f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
+#endif
+    }
     __device__ __forceinline__ void refill_one()
     {
         if (!(PNR_PP_ABL & 1) && rf_f < rf_n) {
-            __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)rf_f * PNR_FRAG_BYTES),
-                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
+            piece(rf_f);
             rf_f += WAVES;
         }
     }
     __device__ __forceinline__ void refill_rest()
     {
-        for (; !(PNR_PP_ABL & 1) && rf_f < rf_n; rf_f += WAVES)
-            __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)rf_f * PNR_FRAG_BYTES),
-                                             (lds_void*)(rf_dst + rf_f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
+        for (; !(PNR_PP_ABL & 1) && rf_f < rf_n; rf_f += WAVES) piece(rf_f);
         stamp(1);
     }
     __device__ __forceinline__ void advance()
