@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "pnr_common.h"
+#include "pnr_fuse_record.h"
 #include "pnr_lane_ops.h"
 
 struct CompositeArgs {
@@ -531,21 +532,26 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
 
 
 // ------------------------------------------------------------------------------- second half of the fused path
-// k_composite_combine: finishes every ray from the N / 32 per-tile records the fused MLP epilogue wrote (pnr_mlp_fuse.h):
-//   out_c = sum_k T_k S_c(k),  T_k = prod_{k' < k} Q_k';   weights_i = T_{i / 32} lw_i.
-// One wave per ray, lane = record column; ~20 B per sample of traffic instead of the raw image's 324 B.
+// k_composite_combine: finishes every ray from what the fused MLP epilogue wrote (pnr_mlp_fuse.h) -- the N / 32 per-tile
+// records (Q, logit sums) and the N per-sample quadruples (lw, r, g, b):
+//   T_k = prod_{k' < k} Q_k',  w_i = T_{i / 32} lw_i,
+//   acc / depth / rgb = sum_i w_i {1, z_i, sigmoid(rgb_i)},  fix_x[c] = sum_i w_i [label_i == c],  logits_c = sum_k T_k S_c(k).
+// One wave per ray, lane = sample (i = lane + 64 j) for the per-sample part and lane = column for the logits; 26 B per sample of
+// traffic at 45 / 32 heads (+ z, + 4 B per labelled field) instead of the raw image's 324 B.  The fixed fields are a
+// fixed-point histogram in LDS (integer adds: order-independent, deterministic).
 struct CombineArgs {
-    const float* rec; int rec_floats; const float* lw;
-    int64_t R; int N, C, K, white_bkgd, has_fix_s, has_fix_i;
+    const float* rec; int rec_floats; const float4* ps; const float* z; const int32_t* lab_s; const int32_t* lab_i;
+    int64_t R; int N, C, K, white_bkgd;
     float *rgb, *depth, *acc, *weights, *sem, *inst, *fix_sem, *fix_inst;
 };
 
 __global__ __launch_bounds__(256) void k_composite_combine(CombineArgs a)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t hist_all[4][128];       // C + K <= 128 (pnr_mlp_forward_composite)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (ray >= a.R) return;
-    const int T = a.N >> 5, RF = a.rec_floats, C = a.C, K = a.K;
+    if (ray >= a.R) return;                      // wave-uniform
+    const int N = a.N, T = N >> 5, RF = a.rec_floats, C = a.C, K = a.K, CK = C + K;
     const float* rec = a.rec + ray * T * RF;
     float Tk[8];
     float t = 1.0f;
@@ -554,38 +560,62 @@ __global__ __launch_bounds__(256) void k_composite_combine(CombineArgs a)
         Tk[k] = t;
         if (k < T) t *= rec[k * RF];
     }
-    float accv = 0.0f;
+    uint32_t* hist = hist_all[wv];
+    const bool want_s = a.lab_s && a.fix_sem && C, want_i = a.lab_i && a.fix_inst && K;
+    if (want_s || want_i)
+        for (int c = lane; c < CK; c += 64) hist[c] = 0;
+    float r5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (k < T) accv = fmaf(Tk[k], rec[k * RF + 1], accv);
-    for (int c = 1 + lane; c < 6 + 2 * (C + K); c += 64) {
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < T) v = fmaf(Tk[k], rec[k * RF + c], v);
-        if (c == 1) { if (a.acc) a.acc[ray] = v; }
-        else if (c == 2) { if (a.depth) a.depth[ray] = v; }
-        else if (c < 6) { if (a.rgb) a.rgb[ray * 3 + (c - 3)] = a.white_bkgd ? v + (1.0f - accv) : v; }
-        else if (c < 6 + C) { if (a.sem) a.sem[ray * C + (c - 6)] = v; }
-        else if (c < 6 + C + K) { if (a.inst) a.inst[ray * K + (c - 6 - C)] = v; }
-        else if (c < 6 + 2 * C + K) { if (a.fix_sem && a.has_fix_s) a.fix_sem[ray * C + (c - 6 - C - K)] = v; }
-        else { if (a.fix_inst && a.has_fix_i) a.fix_inst[ray * K + (c - 6 - 2 * C - K)] = v; }
-    }
-    if (a.weights) {
-        for (int i = lane; i < a.N; i += 64) {
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < N) {
+            const int64_t s = ray * N + i;
+            const float4 p = a.ps[s];
             float tk = Tk[0];
 #pragma unroll
             for (int k = 1; k < 8; ++k) tk = (i >> 5) == k ? Tk[k] : tk;
-            a.weights[ray * a.N + i] = tk * a.lw[ray * a.N + i];
+            const float w = tk * p.x;
+            r5[0] += w;
+            r5[1] = fmaf(w, a.z[s], r5[1]);
+            r5[2] = fmaf(w, 1.0f / (1.0f + expf(-p.y)), r5[2]);
+            r5[3] = fmaf(w, 1.0f / (1.0f + expf(-p.z)), r5[3]);
+            r5[4] = fmaf(w, 1.0f / (1.0f + expf(-p.w)), r5[4]);
+            if (a.weights) a.weights[s] = w;
+            if (want_s || want_i) {
+                const uint32_t fx = (uint32_t)(w * PNR_FUSE_FIX_SCALE + 0.5f);
+                if (want_s) { const int l = a.lab_s[s]; if (l >= 0 && l < C) atomicAdd(&hist[l], fx); }
+                if (want_i) { const int l = a.lab_i[s]; if (l >= 0 && l < K) atomicAdd(&hist[C + l], fx); }
+            }
         }
+    }
+    group_sum_batch<64, 5>(r5);
+    if (lane == 0) {
+        if (a.acc) a.acc[ray] = r5[0];
+        if (a.depth) a.depth[ray] = r5[1];
+    }
+    if (lane < 3 && a.rgb) {
+        const float v = lane == 0 ? r5[2] : lane == 1 ? r5[3] : r5[4];
+        a.rgb[ray * 3 + lane] = a.white_bkgd ? v + (1.0f - r5[0]) : v;
+    }
+    for (int c = lane; c < CK; c += 64) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < T) v = fmaf(Tk[k], rec[k * RF + PNR_FUSE_REC_LOGITS + c], v);
+        if (c < C) { if (a.sem) a.sem[ray * C + c] = v; }
+        else if (a.inst) a.inst[ray * K + (c - C)] = v;
+        // LDS operations of one wave execute in order and only this wave touches its histogram: no barrier
+        if (c < C) { if (want_s) a.fix_sem[ray * C + c] = (float)hist[c] * (1.0f / PNR_FUSE_FIX_SCALE); }
+        else if (want_i) a.fix_inst[ray * K + (c - C)] = (float)hist[c] * (1.0f / PNR_FUSE_FIX_SCALE);
     }
 }
 
-int pnr_composite_combine_launch(const float* rec, int rec_floats, const float* lw, int64_t R, int N, int C, int K, int white_bkgd,
-                                 int has_fix_s, int has_fix_i, float* rgb, float* depth, float* acc, float* weights, float* sem,
-                                 float* inst, float* fix_sem, float* fix_inst, hipStream_t st)
+int pnr_composite_combine_launch(const float* rec, int rec_floats, const float4* ps, const float* z, const int32_t* label_sem,
+                                 const int32_t* label_inst, int64_t R, int N, int C, int K, int white_bkgd, float* rgb, float* depth,
+                                 float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, hipStream_t st)
 {
     CombineArgs a;
-    a.rec = rec; a.rec_floats = rec_floats; a.lw = lw; a.R = R; a.N = N; a.C = C; a.K = K; a.white_bkgd = white_bkgd;
-    a.has_fix_s = has_fix_s; a.has_fix_i = has_fix_i;
+    a.rec = rec; a.rec_floats = rec_floats; a.ps = ps; a.z = z; a.lab_s = label_sem; a.lab_i = label_inst;
+    a.R = R; a.N = N; a.C = C; a.K = K; a.white_bkgd = white_bkgd;
     a.rgb = rgb; a.depth = depth; a.acc = acc; a.weights = weights; a.sem = sem; a.inst = inst; a.fix_sem = fix_sem; a.fix_inst = fix_inst;
     const int64_t blocks = (R + 3) / 4;
     hipLaunchKernelGGL(k_composite_combine, dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -443,7 +443,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
 template <bool TRAIN, bool FUSE, class CTX, int NA, int NB>
 __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
                                              const uint32_t (&inB)[NB > 0 ? NB : 1], int n_out, int ch_base, int samp,
-                                             FuseState* st = nullptr, uint32_t* hist = nullptr)
+                                             FuseState* st = nullptr)
 {
     using CH = PPChunk<1, NA, NB>;
     const int nfb = (n_out + 31) >> 5;
@@ -478,9 +478,9 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
         }
 #else
         if constexpr (FUSE) {
-            if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, acc[0], hist);
-            else if (PNR_FUSE_TRANSPOSED) fuse_logits_t(*st, c.hi, c.lane, fb, n_out, 6 + (ch_base - 4), acc[0]);
-            else fuse_logits(*st, c.hi, c.lane & 31, fb, n_out, 6 + (ch_base - 4), acc[0]);
+            if (ch_base == 0) fuse_rgbs(c.a, *st, c.hi, c.lane & 31, acc[0]);
+            else if (PNR_FUSE_TRANSPOSED) fuse_logits_t(*st, c.hi, c.lane, fb, n_out, PNR_FUSE_REC_LOGITS + (ch_base - 4), acc[0]);
+            else fuse_logits(*st, c.hi, c.lane & 31, fb, n_out, PNR_FUSE_REC_LOGITS + (ch_base - 4), acc[0]);
         } else if (!(PNR_PP_ABL & 4)) store_raw_block(c.a, samp, c.hi, fb, n_out, ch_base, acc[0]);
         c.refill_rest();
 #endif
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
     c.abl_sink = u32x4{0, 0, 0, 0};
 #endif
 #if PNR_TRACE
-    c.tr = reinterpret_cast<unsigned long long*>(smem + 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0)) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
+    c.tr = reinterpret_cast<unsigned long long*>(smem + 3 * a.slot_bytes) + c.wave * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS;
     c.titer = 0;
 #endif
     const int n = c.lane & 31;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 
     uint32_t dummy[1] = {0};
     u32x4 A[CTX::P];
-    struct SampleIn { float4 o4, d4; float zz, zn; int ls, li; bool last; };
+    struct SampleIn { float4 o4, d4; float zz, zn; bool last; };
     auto fetch = [&](int grp) {
         const int s = (grp * WAVES + c.wave) * 32 + n;
         const int sl = s < a.S ? s : a.S - 1;
@@ -523,15 +523,9 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         in.zz = a.z[sl];
         in.zn = FUSE ? a.z[sl + 1 < a.S ? sl + 1 : sl] : 0.0f;     // z of the next sample (used inside a ray only)
         in.last = FUSE ? (sl - ray * a.N + 1 == a.N) : false;      // the ray's last sample: its interval is 1e10
-        // bbox-prior labels of the sample: requested a whole sample group ahead like the rest (loaded inside the epilogue they
-        // cost an HBM round trip in an L phase the partner's short output-layer M phase cannot cover)
-        in.ls = (FUSE && a.lab_s) ? a.lab_s[sl] : -1;
-        in.li = (FUSE && a.lab_i) ? a.lab_i[sl] : -1;
         return in;
     };
     SampleIn nextin = fetch(blockIdx.x < a.n_groups ? blockIdx.x : 0);
-    // FUSE: this wave's bbox-prior histogram (C + K <= 128 bins) behind the three weight slots
-    uint32_t* const hist = reinterpret_cast<uint32_t*>(smem + 3 * a.slot_bytes) + c.wave * 128;
     FuseState fst;
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
@@ -552,8 +546,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow, c.hi, ex);
             if constexpr (FUSE) {
                 // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off -> the same value as nrm
-                fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.lw = 0.0f;
-                fst.ls = nextin.ls; fst.li = nextin.li; fst.last = nextin.last;
+                fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.last = nextin.last;
                 fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
             }
         }
@@ -603,19 +596,19 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         uint32_t g[GR];
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
-        pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst, hist);
+        pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst);
         // panoptic heads, after the appearance branch (plan order)
         if (a.n_sem) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(4 + a.D), srow);
             gv(4 + a.D, sh);
-            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp, &fst, hist);
+            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_sem, 4, samp, &fst);
         }
         if (a.n_inst) {
             uint32_t sh[GR];
             pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
-            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp, &fst, hist);
+            pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp, &fst);
         }
 #if PNR_TRACE
         ++c.titer;
@@ -629,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #if PNR_TRACE
     __syncthreads();
     if (blockIdx.x == PNR_TRACE_WG && a.trace) {
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0));
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + 3 * a.slot_bytes);
         for (int i = threadIdx.x; i < WAVES * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS; i += blockDim.x) a.trace[i] = src[i];
     }
 #endif
@@ -639,7 +632,7 @@ template <int W, bool TRAIN, bool FUSE = false>
 static int launch_mlp_pp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
-    const int lds_bytes = 3 * a.slot_bytes + (FUSE ? 8 * 128 * 4 : 0) + (PNR_TRACE ? 8 * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
+    const int lds_bytes = 3 * a.slot_bytes + (PNR_TRACE ? 8 * PNR_TRACE_CHUNKS * PNR_TRACE_STAMPS * 8 : 0);
     PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_forward: three weight slots of %d bytes exceed the 160 KiB LDS", a.slot_bytes);
     PNR_REQUIRE(a.n_chunks >= 4, "pnr_mlp_forward: network too small for the weight stream");
     a.n_groups = (a.S + 255) / 256;
@@ -761,23 +754,23 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
     return mlp_forward_impl(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, nullptr, stream);
 }
 
-int pnr_composite_combine_launch(const float* rec, int rec_floats, const float* lw, int64_t R, int N, int C, int K, int white_bkgd,
-                                 int has_fix_s, int has_fix_i, float* rgb, float* depth, float* acc, float* weights, float* sem,
-                                 float* inst, float* fix_sem, float* fix_inst, hipStream_t st);
+int pnr_composite_combine_launch(const float* rec, int rec_floats, const float4* ps, const float* z, const int32_t* label_sem,
+                                 const int32_t* label_inst, int64_t R, int N, int C, int K, int white_bkgd, float* rgb, float* depth,
+                                 float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, hipStream_t st);
 
-// workspace of pnr_mlp_forward_composite: one record per 32-sample tile (padded to whole 256-sample groups) and, when the
-// per-sample weights are wanted, one float per sample
+// workspace of pnr_mlp_forward_composite: one record per 32-sample tile (padded to whole 256-sample groups) and one
+// (lw, r, g, b) quadruple per sample (want_weights is accepted for ABI stability and no longer changes the size)
 PNR_EXPORT int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights)
 {
+    (void)want_weights;
     if (pnr_mlp_validate(desc) != PNR_OK || n_rays < 0 || n_samples < 32 || (n_samples & 31)) return -1;
     const int64_t S = n_rays * n_samples, tiles = (S + 255) / 256 * 8;
-    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + (want_weights ? S * 4 : 0) + 256;
+    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + S * 16 + 256;
 }
 
 // the fused MLP launch alone (records + optional local weights into `workspace`); `a` is returned for the combine step
 static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z, int64_t n_rays,
-                            int n_samples, const int32_t* label_sem, const int32_t* label_inst, int want_weights,
-                            void* workspace, void* stream, MlpArgs& a)
+                            int n_samples, void* workspace, void* stream, MlpArgs& a)
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
@@ -802,8 +795,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     a.rec_floats = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
     a.rec = (float*)workspace;
     const int64_t tiles = ((int64_t)a.S + 255) / 256 * 8;
-    a.lw = want_weights ? a.rec + tiles * a.rec_floats : nullptr;
-    a.lab_s = label_sem; a.lab_i = label_inst;
+    a.ps = (float4*)(a.rec + tiles * a.rec_floats);           // rec_floats % 4 == 0: 16-byte aligned
     a.clk = g_clk_buf;
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -823,12 +815,11 @@ PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* p
     if (n_rays == 0) return PNR_OK;
     PNR_REQUIRE((!fix_sem || label_sem) && (!fix_inst || label_inst), "pnr_mlp_forward_composite: fix_* outputs need their labels");
     MlpArgs a;
-    int rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, fix_sem ? label_sem : nullptr, fix_inst ? label_inst : nullptr,
-                              weights != nullptr, workspace, stream, a);
+    int rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, workspace, stream, a);
     if (rc != PNR_OK) return rc;
-    return pnr_composite_combine_launch(a.rec, a.rec_floats, a.lw, n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd,
-                                        a.lab_s != nullptr, a.lab_i != nullptr, rgb, depth, acc, weights, sem, inst, fix_sem, fix_inst,
-                                        (hipStream_t)stream);
+    return pnr_composite_combine_launch(a.rec, a.rec_floats, a.ps, z, fix_sem ? label_sem : nullptr, fix_inst ? label_inst : nullptr,
+                                        n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd, rgb, depth, acc, weights, sem, inst,
+                                        fix_sem, fix_inst, (hipStream_t)stream);
 }
 
 // bench only: mean ms per FUSED MLP launch (the kernel the inference step runs; the combine kernel is not included) and the
@@ -848,7 +839,7 @@ PNR_EXPORT int pnr_time_mlp_forward_composite_clk(const pnr_mlp_desc* desc, cons
     int rc = PNR_OK;
     for (int i = 0; i < iters && rc == PNR_OK; ++i) {
         MlpArgs a;
-        rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, label_sem, label_inst, want_weights, workspace, stream, a);
+        rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, workspace, stream, a);
     }
     g_clk_buf = nullptr;
     if (rc != PNR_OK) return rc;

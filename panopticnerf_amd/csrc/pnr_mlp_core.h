@@ -30,8 +30,8 @@ struct MlpArgs {
     // of raw, (ch, S) channel-major fp32; dys: pre-activation gradients written by the backward.
     uint16_t* acts; const float* d_raw; uint16_t* dys;
     // fused compositing epilogue (inference, k_mlp_pp<.., FUSE>; pnr_mlp_fuse.h): one record of `rec_floats` floats per 32-sample
-    // tile, optional per-sample local weights, optional bbox-prior labels (R*N int32 each)
-    float* rec; int rec_floats; float* lw; const int32_t* lab_s; const int32_t* lab_i;
+    // tile and one (lw, r, g, b) quadruple per sample
+    float* rec; int rec_floats; float4* ps;
     unsigned long long* trace;      // PNR_TRACE builds: [8 waves][PNR_TRACE_CHUNKS][PNR_TRACE_STAMPS]
     unsigned long long* clk;        // optional (bench): {shader cycles, 100 MHz ticks} of workgroup 0's first wave
     int64_t acts_off[24], dys_off[24], gate_off[24];     // pnr_train_layout (bf16 units)

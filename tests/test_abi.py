@@ -128,7 +128,8 @@ def test_train_layout_is_padded_line_aligned_and_ordered(S):
 def test_fused_pass_eligibility_and_workspace_arithmetic():
     """Host-side rules of the fused MLP + compositing pass: ops.fused_supported mirrors what pnr_mlp_forward_composite accepts
     (bf16, logits compositing, no sigma noise, N a multiple of 32 in [32, 256], C + K <= 128), and the workspace is one record of
-    6 + 2 (C + K) floats (padded to 4) per 32-sample tile of whole 256-sample groups, plus one float per sample for the weights."""
+    1 + C + K floats (padded to 4: Q and the logit sums) per 32-sample tile of whole 256-sample groups, plus one (lw, r, g, b)
+    quadruple per sample."""
     lib = _lib.load()
     d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
     assert ops.fused_supported(d, 192) and ops.fused_supported(d, 32) and ops.fused_supported(d, 256)
@@ -137,13 +138,13 @@ def test_fused_pass_eligibility_and_workspace_arithmetic():
     assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "fp32"), 192)
     assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 100, 60, 128, "bf16"), 192)
     ws = lib.pnr_mlp_forward_composite_workspace_bytes
-    rec = (6 + 2 * 77 + 3) // 4 * 4
-    assert rec == 160
+    rec = (1 + 77 + 3) // 4 * 4
+    assert rec == 80
     for R, N in ((1, 32), (37, 192), (65536, 192), (510, 64)):
         S = R * N
         tiles = (S + 255) // 256 * 8
-        assert ws(ctypes.byref(d), R, N, 0) == tiles * rec * 4 + 256
-        assert ws(ctypes.byref(d), R, N, 1) == tiles * rec * 4 + S * 4 + 256
+        assert ws(ctypes.byref(d), R, N, 0) == tiles * rec * 4 + S * 16 + 256
+        assert ws(ctypes.byref(d), R, N, 1) == ws(ctypes.byref(d), R, N, 0)
     assert ws(ctypes.byref(d), 10, 100, 0) == -1 and ws(ctypes.byref(d), 10, 16, 0) == -1
     d0 = ops.make_desc(4, 128, -1, 10, 4, 0, 0, 64, "bf16")
-    assert ws(ctypes.byref(d0), 8, 32, 0) == 8 * 8 * 4 + 256          # no heads: 6 floats padded to 8
+    assert ws(ctypes.byref(d0), 8, 32, 0) == 8 * 4 * 4 + 8 * 32 * 16 + 256          # no heads: Q alone, padded to 4 floats
