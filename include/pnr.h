@@ -71,7 +71,9 @@ typedef struct pnr_mlp_desc {
     int32_t xyz_L, dir_L;
     int32_t n_sem, n_inst, head_W;
     int32_t precision; /* PNR_PREC_* */
-    int32_t reserved[7];
+    int32_t plan;      /* chunk order of the packed image: 0 = classic (every kernel); 1 = fused-inference order, see
+                          pnr_mlp_fused_plan (only pnr_mlp_forward_composite accepts it) */
+    int32_t reserved[6];
 } pnr_mlp_desc;
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
@@ -126,6 +128,12 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  * multiple of 32 in [32, 256], n_sem + n_inst <= 128.  Results equal the two-kernel path to fp32 rounding (the sums are
  * associated per tile).  Outputs as pnr_composite's (any may be null; fix_* need their labels); weights (R,N) optional.
  * workspace: pnr_mlp_forward_composite_workspace_bytes(desc, n_rays, n_samples, weights != null) device bytes. */
+/* Chunk order for images that only pnr_mlp_forward_composite will consume.  Returns 1 when `desc`'s geometry has the
+ * fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then BOTH
+ * head hidden layers, then the two logit layers as ONE chunk -- three 8-MFMA chunks whose memory phase nothing covered become
+ * one 24-MFMA chunk.  Set desc.plan to the returned value before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it for the
+ * forward call; 0 = the classic order, which every entry point accepts.  Same arithmetic per layer: results are bit-identical. */
+int pnr_mlp_fused_plan(const pnr_mlp_desc* desc);
 int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights);
 int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                               int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,

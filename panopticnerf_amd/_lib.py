@@ -26,7 +26,7 @@ class MlpDesc(ctypes.Structure):
     _fields_ = [("D", ctypes.c_int32), ("W", ctypes.c_int32), ("skip", ctypes.c_int32),
                 ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
                 ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
-                ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+                ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
 
 
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -63,6 +63,7 @@ SIGNATURES = {
     "pnr_mlp_backward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_f, c_i64, c_int, c_f]),
     "pnr_mlp_wgrad_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
     "pnr_mlp_wgrad": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, ctypes.POINTER(MlpParamsHost), c_f, c_f]),
+    "pnr_mlp_fused_plan": (c_int, [ctypes.POINTER(MlpDesc)]),
     "pnr_mlp_forward_composite_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64, c_int, c_int]),
     "pnr_mlp_forward_composite": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
                                           c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

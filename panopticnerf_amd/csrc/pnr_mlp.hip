@@ -199,33 +199,59 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
 #endif
 }
 
+// The bf16 encoding in stages (k_mlp_pp computes the NEXT sample group's gamma(x) and this group's gamma(d) piece by piece in
+// the memory phases of the last two trunk layers, where the partner wave group's MFMAs leave the VALU idle): sin / cos of the three
+// coordinates at the half-wave's base band, then per band one packed register triple (s_x s_y | s_z c_x | c_y c_z) and the
+// double-angle step to the next band.  embed_lane<bf16> below is these same calls in a row: bit-identical by construction.
+struct EmbedSC { float s[3], c[3]; };
+template <int NF>
+__device__ __forceinline__ void embed_sincos(float p, int a, int hi, EmbedSC& e)
+{
+    const float base = hi ? (float)(1 << NF) : 1.0f;
+    sincos_cw(p * base, e.s[a], e.c[a]);
+}
+__device__ __forceinline__ void embed_pack_band(const EmbedSC& e, uint32_t* out3)
+{
+    out3[0] = pack_bf16(e.s[0], e.s[1]); out3[1] = pack_bf16(e.s[2], e.c[0]); out3[2] = pack_bf16(e.c[1], e.c[2]);
+}
+// sin 2t = 2 s c, cos 2t = 1 - 2 s^2: the error doubles per octave (<= 2^(NF-1) * 1e-7 ~ 2e-6), far below the bf16 rounding (4e-3)
+__device__ __forceinline__ void embed_next_band(EmbedSC& e)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float s2 = 2.0f * e.s[a] * e.c[a], c2 = fmaf(-2.0f * e.s[a], e.s[a], 1.0f);
+        e.s[a] = s2; e.c[a] = c2;
+    }
+}
+__device__ __forceinline__ uint32_t embed_pack_xyz(float p0, float p1, float p2, int hi)
+{
+    return pack_bf16(hi ? p2 : p0, hi ? 0.0f : p1);
+}
+
 // gamma() of one 3-vector into this lane's share of the lane vector (pnr_mlp_layout.h).
 // NF = frequency bands per half-wave (5 for xyz, 2 for view directions); NV = values per lane.
 template <int PREC, int NF, int NV, int NREG>
 __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi, uint32_t (&out)[NREG])
 {
-    float v[NV];
-    v[0] = hi ? p2 : p0;
-    v[1] = hi ? 0.0f : p1;
     if constexpr (PREC == PNR_PREC_BF16) {
-        // One accurate sincos per coordinate at this half-wave's lowest band, then the double-angle
-        // recurrences sin 2t = 2 s c, cos 2t = 1 - 2 s^2 for the NF-1 higher bands: the error doubles per
-        // octave (<= 2^(NF-1) * 1e-7 ~ 2e-6), far below the bf16 rounding (4e-3) applied next.
-        const float base = hi ? (float)(1 << NF) : 1.0f;
-        const float pp[3] = {p0, p1, p2};
+        static_assert(NREG == NV / 2 && 1 + 3 * NF <= NREG, "packed lane vector: xyz register + three per band");
+        EmbedSC e;
+        embed_sincos<NF>(p0, 0, hi, e);
+        embed_sincos<NF>(p1, 1, hi, e);
+        embed_sincos<NF>(p2, 2, hi, e);
+        out[0] = embed_pack_xyz(p0, p1, p2, hi);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float s, co;
-            sincos_cw(pp[a] * base, s, co);
-            v[2 + a] = s; v[2 + 3 + a] = co;
-#pragma unroll
-            for (int fp = 1; fp < NF; ++fp) {
-                const float s2 = 2.0f * s * co, c2 = fmaf(-2.0f * s, s, 1.0f);
-                s = s2; co = c2;
-                v[2 + 6 * fp + a] = s; v[2 + 6 * fp + 3 + a] = co;
-            }
+        for (int fp = 0; fp < NF; ++fp) {
+            embed_pack_band(e, &out[1 + 3 * fp]);
+            if (fp + 1 < NF) embed_next_band(e);
         }
+#pragma unroll
+        for (int p = 1 + 3 * NF; p < NREG; ++p) out[p] = 0u;
     } else {
+        static_assert(NREG == NV, "fp32 lane vector: one register per value");
+        float v[NV];
+        v[0] = hi ? p2 : p0;
+        v[1] = hi ? 0.0f : p1;
 #pragma unroll
         for (int fp = 0; fp < NF; ++fp) {
             const float sc = hi ? (float)(1 << (NF + fp)) : (float)(1 << fp);
@@ -234,13 +260,8 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
             sincosf(p1 * sc, &s, &co); v[2 + 6 * fp + 1] = s; v[2 + 6 * fp + 4] = co;
             sincosf(p2 * sc, &s, &co); v[2 + 6 * fp + 2] = s; v[2 + 6 * fp + 5] = co;
         }
-    }
 #pragma unroll
-    for (int i = 2 + 6 * NF; i < NV; ++i) v[i] = 0.0f;
-    if constexpr (PREC == PNR_PREC_BF16) {
-#pragma unroll
-        for (int p = 0; p < NV / 2; ++p) out[p] = pack_bf16(v[2 * p], v[2 * p + 1]);
-    } else {
+        for (int i = 2 + 6 * NF; i < NV; ++i) v[i] = 0.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) out[i] = __float_as_uint(v[i]);
     }
@@ -390,13 +411,18 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 // ------------------------------------------------------------------------------- ping-pong form (pnr_mlp_pp.h)
 // Same arithmetic, same packed image, same register-resident activations as k_mlp_fused<bf16, W, 1 tile, 8 waves>;
 // only the time structure of the weight stream differs (two wave groups in phase opposition, 3 LDS slots).
-template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT>
+struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
+// side(slot): work that is not this layer's, placed between the refill pieces of the L phases (slot = cb * FBC + b, one per
+// output block; -1 - cb: behind the last piece of chunk cb's L phase): a wave blocks ~100-200 cycles per LDS-DMA piece while
+// the CU's queue is full, and beside a hidden layer's M phase the SIMD's VALU is ~80 % idle -- VALU work parked here costs
+// next to nothing.
+template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT, int FBC_PLAN = 0, class SIDE = NoSide>
 __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
                                               const uint32_t (&inB)[NB > 0 ? NB : 1], uint32_t (&out)[NOUT],
-                                              uint16_t* save, int srow)
+                                              uint16_t* save, int srow, SIDE&& side = NoSide{})
 {
     constexpr int FBC0 = pnr_layer_fbc(KIND, PNR_PREC_BF16);
-    constexpr int FBC = (NFB_OUT % FBC0 == 0) ? FBC0 : 1;      // mirrors pnr_build_plan
+    constexpr int FBC = FBC_PLAN > 0 ? FBC_PLAN : (NFB_OUT % FBC0 == 0) ? FBC0 : 1;      // mirrors pnr_build_plan
     using CH = PPChunk<FBC, NA, NB>;
     static_assert(NOUT >= NFB_OUT * 8, "output register array too small");
     f32x4 q[FBC][4];                                            // bias quads in flight across the chunk boundary
@@ -432,9 +458,11 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
             c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
             if (b >= PNR_PP_EPI_IN_M) epilogue(b);
             if (save) store_slots(save, NFB_OUT * 32, srow, cb * FBC + b, c.hi, &out[(cb * FBC + b) * 8]);
+            side(cb * FBC + b);                                 // a constant once the loops are unrolled
         }
         if (PNR_PP_EARLY_BIAS && nxt_same) CH::bias_issue(c.next_bias_addr(), q);   // accumulators free: next chunk's bias, asynchronous
         c.refill_rest();
+        side(-1 - cb);                                          // end of chunk cb's refill: behind every piece of this L phase
         c.advance();
     }
 }
@@ -488,9 +516,88 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
     }
 }
 
-template <int W, bool TRAIN, bool FUSE = false>
+// Plan 1 (fused inference): the two logit layers as ONE chunk of NBS + NBI transposed 32-channel blocks (8 k-steps each:
+// head_W = 128), block b < NBS from the semantic head's hidden activations, the others from the instance head's.  One
+// M phase of 8 (NBS + NBI) MFMAs on NBS + NBI interleaved accumulator chains instead of NBS + NBI single-chain chunks of 8
+// whose L phases (refill of a full-size chunk each, prologue, epilogue) nothing covered: 4400 + 2300 cycles per sample group
+// in the per-chunk trace (profiles/r03a) for 1536 cycles of MFMA.
+template <int FB, int KS>
+struct PPLogitsGeom {       // fragments of the chunk in consumption order i = ks * FB + b (block-major in the image)
+    static constexpr int NF = FB * KS, BIAS_OFF = FB * KS * PNR_FRAG_BYTES;
+    static constexpr int frag_off(int i) { return ((i % FB) * KS + (i / FB)) * PNR_FRAG_BYTES; }
+};
+template <int NBS, int NBI, class CTX>
+__device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&shs)[32], const uint32_t (&shi)[32],
+                                                 FuseState& st)
+{
+    constexpr int P = CTX::P, FB = NBS + NBI, KS = 8;
+    using GEO = PPLogitsGeom<FB, KS>;
+    constexpr int NF = GEO::NF, BIAS_OFF = GEO::BIAS_OFF;
+    const uint32_t fa = c.frag_addr();
+    // L, last part: first fragments, bias of channel fb*32 + (lane & 31) into every register of block fb's accumulator
+    pp_static_for<(P - 1 < NF ? P - 1 : NF)>([&](auto I) {
+        constexpr int i = I;
+        pp_lds_read<GEO::frag_off(i)>(A[i % P], fa);
+    });
+    f32x16 acc[FB];
+    {
+        float bj[FB];
+        const uint32_t ba = c.bias_addr() - c.hi * 16 + (uint32_t)(c.lane & 31) * 4u;
+        pp_static_for<FB>([&](auto B) {
+            constexpr int b = B;
+            pp_lds_read_b32<BIAS_OFF + b * 128>(bj[b], ba);
+        });
+#pragma unroll
+        for (int b = 0; b < FB; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bj[b]));
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = bj[b];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    c.stamp(6);
+    c.barrier();                                                    // L -> M
+    c.stamp(2);
+#if PNR_PP_PRIO
+    __builtin_amdgcn_s_setprio(PNR_PP_PRIO);
+#endif
+    pp_static_for<NF>([&](auto I) {
+        constexpr int i = I;
+        constexpr int ks = i / FB, b = i % FB;
+        constexpr int younger = (NF - 1 - i) < (P - 2) ? (NF - 1 - i) : (P - 2);
+        pp_wait<younger>(A[i % P]);
+        const uint32_t* act = b < NBS ? &shs[4 * ks] : &shi[4 * ks];
+        u32x4 av;
+        av[0] = act[0]; av[1] = act[1]; av[2] = act[2]; av[3] = act[3];
+        // operands swapped (PPChunk::mma<SWAP>): lane = output channel, register r = sample row(r, hi)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, A[i % P]), acc[b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + P - 1 < NF) {
+            pp_lds_read<GEO::frag_off(i + P - 1)>(A[(i + P - 1) % P], fa);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+#if PNR_PP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    c.m_done();
+    c.refill_begin();
+    pp_static_for<FB>([&](auto B) {
+        constexpr int b = B;
+        c.refill_one();
+        if constexpr (b < NBS) fuse_logits_t(st, c.hi, c.lane, b, c.a.n_sem, PNR_FUSE_REC_LOGITS, acc[b]);
+        else fuse_logits_t(st, c.hi, c.lane, b - NBS, c.a.n_inst, PNR_FUSE_REC_LOGITS + c.a.n_sem, acc[b]);
+    });
+    c.refill_rest();
+    c.advance();
+}
+
+// TAIL (FUSE only): 0 = classic plan (runtime loops over the logit blocks); 4 NBS + NBI = plan 1 with NBS semantic and NBI
+// instance logit blocks merged into one chunk (pnr_mlp_plan.h)
+template <int W, bool TRAIN, bool FUSE = false, int TAIL = 0>
 __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 {
+    static_assert(TAIL == 0 || (FUSE && !TRAIN && W == 256), "plan 1 is the fused inference kernel's");
     constexpr int WAVES = 8;
     using CTX = CtxPP<WAVES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -527,28 +634,37 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
     };
     SampleIn nextin = fetch(blockIdx.x < a.n_groups ? blockIdx.x : 0);
     FuseState fst;
+    // Staged encodings (see embed_sincos): gamma(d) of THIS sample group and gamma(x) of the NEXT one are computed piece by
+    // piece in the L phases of the feature layer -- the last full-size layer of a group, whose M phases leave the VALU ~80 %
+    // idle -- and the next group's inputs are requested behind the refill pieces of its first chunk.  At a group's top and in
+    // front of the views layer, where the partner wave group has little or nothing to multiply and round 2 computed them in
+    // one lump (per-chunk trace: ~4500 + ~1400 cycles per sample group), a few moves are left.  ex is free for the next
+    // group's values from the end of the trunk on (layer 0 and the skip layer are its only readers).
+    uint32_t ex[GXR], ed[GDR];
+    float dn_next;                         // |d| of the next group's sample
+    auto points = [&](const SampleIn& in, float& px, float& py, float& pz, float& nrm) {
+        const float dx = in.o4.w, dy = in.d4.x, dz = in.d4.y;
+        // pts = o + d*z: separate multiply and add, as the sampler's pnr_points does
+        px = __fadd_rn(in.o4.x, __fmul_rn(dx, in.zz));
+        py = __fadd_rn(in.o4.y, __fmul_rn(dy, in.zz));
+        pz = __fadd_rn(in.o4.z, __fmul_rn(dz, in.zz));
+        // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off
+        nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    };
+    {
+        float px, py, pz;
+        points(nextin, px, py, pz, dn_next);
+        embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
+    }
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int s0 = (grp * WAVES + c.wave) * 32 + n;
         const int samp = s0 < a.S ? s0 : -1, srow = s0;
-        float vd[3];
-        uint32_t ex[GXR];
-        {
-            const float4 o4 = nextin.o4, d4 = nextin.d4;
-            const float zz = nextin.zz;
-            const float dx = o4.w, dy = d4.x, dz = d4.y;
-            const float px = __fadd_rn(o4.x, __fmul_rn(dx, zz));
-            const float py = __fadd_rn(o4.y, __fmul_rn(dy, zz));
-            const float pz = __fadd_rn(o4.z, __fmul_rn(dz, zz));
-            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-            vd[0] = dx / nrm; vd[1] = dy / nrm; vd[2] = dz / nrm;
-            embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
-            if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow, c.hi, ex);
-            if constexpr (FUSE) {
-                // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off -> the same value as nrm
-                fst.zz = zz; fst.zn = nextin.zn; fst.dn = nrm; fst.samp = samp; fst.last = nextin.last;
-                fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
-            }
+        const float dx = nextin.o4.w, dy = nextin.d4.x, dz = nextin.d4.y, dn = dn_next;
+        if constexpr (TRAIN) store_ex(a.acts + a.acts_off[0], srow, c.hi, ex);
+        if constexpr (FUSE) {
+            fst.zz = nextin.zz; fst.zn = nextin.zn; fst.dn = dn; fst.samp = samp; fst.last = nextin.last;
+            fst.rec = a.rec + (int64_t)(grp * WAVES + c.wave) * a.rec_floats;
         }
         auto sv = [&](int idx) -> uint16_t* { return TRAIN ? a.acts + a.acts_off[idx] : nullptr; };
 
@@ -556,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], srow, c.hi, regs);
         };
         uint32_t cur[HR], nxt[HR];
-        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR>(c, A, ex, dummy, cur, sv(2), srow);
+        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR, (TAIL > 0 && PNR_PLAN1_TRUNK0_MERGE ? NFB : 0)>(c, A, ex, dummy, cur, sv(2), srow);
         gv(2, cur);
         auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
             if (l - 1 == a.skip)
@@ -585,18 +701,60 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             for (int i = 0; i < HR; ++i) cur[i] = nxt[i];       // (32 v_pk_mov_b32 instead of these 64 v_mov_b32: +-0 measured)
         }
 #endif
-        {
-            const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
-            nextin = fetch(g2);
-        }
-        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), srow);
-        uint32_t ed[GDR];
-        embed_lane<PNR_PREC_BF16, 2, 16, GDR>(vd[0], vd[1], vd[2], c.hi, ed);
+        // side work of the feature layer: eight stages over its NFB slots -- gamma(d) of this group (D0..D3), then gamma(x) of
+        // the next one (X0..X3), whose inputs are requested behind chunk 0's refill pieces (two chunks ahead of X0 at W = 256)
+        const int g2 = grp + (int)gridDim.x < a.n_groups ? grp + (int)gridDim.x : grp;
+        EmbedSC esc;
+        float q0, q1, q2;                  // the 3-vector being encoded: d / |d|, then the next group's point
+        auto stage = [&](int k) {
+            switch (k) {
+            case 0: q0 = dx / dn; q1 = dy / dn; q2 = dz / dn; break;
+            case 1: embed_sincos<2>(q0, 0, c.hi, esc); embed_sincos<2>(q1, 1, c.hi, esc); break;
+            case 2: embed_sincos<2>(q2, 2, c.hi, esc); ed[0] = embed_pack_xyz(q0, q1, q2, c.hi); embed_pack_band(esc, &ed[1]); break;
+            case 3: embed_next_band(esc); embed_pack_band(esc, &ed[4]); ed[7] = 0u; break;
+            case 4: points(nextin, q0, q1, q2, dn_next); ex[0] = embed_pack_xyz(q0, q1, q2, c.hi); embed_sincos<5>(q0, 0, c.hi, esc); break;
+            case 5: embed_sincos<5>(q1, 1, c.hi, esc); embed_sincos<5>(q2, 2, c.hi, esc); embed_pack_band(esc, &ex[1]); break;
+            case 6: embed_next_band(esc); embed_pack_band(esc, &ex[4]); embed_next_band(esc); embed_pack_band(esc, &ex[7]); break;
+            default: embed_next_band(esc); embed_pack_band(esc, &ex[10]); embed_next_band(esc); embed_pack_band(esc, &ex[13]); break;
+            }
+        };
+        auto side = [&](int slot) {
+            if (slot == -1) {
+                // the four loads of fetch(): vector-memory operations of a wave complete in order, so the next m_done() may
+                // wait for "all but the youngest four" -- the refill pieces -- instead of an HBM round trip
+                // (the count is the number of vector-memory instructions hipcc emits for fetch(); the markers let
+                // tests/test_asm_lint.py verify it, and that no LDS-DMA piece sits between them, on the compiled assembly)
+                __builtin_amdgcn_sched_barrier(0);     // the loads must stay the YOUNGEST operations: nothing may move across
+                asm volatile("; PNR_FETCH_BEGIN" ::: "memory");
+                nextin = fetch(g2);
+                if constexpr (FUSE) asm volatile("; PNR_FETCH_END 4" ::: "memory");
+                else asm volatile("; PNR_FETCH_END 3" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                c.pending_stores = FUSE ? 4 : 3;
+            }
+            if (slot < 0) return;
+            constexpr int PER = 8 / NFB;   // stages per slot: 1 (W = 256), 2 (W = 128)
+#pragma unroll
+            for (int j = 0; j < PER; ++j) stage(slot * PER + j);
+        };
+        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), srow, side);
         if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, srow, 0, c.hi, ed);   // ED: 32 slots
         uint32_t g[GR];
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst);
+        if constexpr (TAIL > 0) {
+            // plan 1: both head hidden layers, then every logit block in one chunk
+            constexpr int NBS = TAIL >> 2, NBI = TAIL & 3;
+            uint32_t shs[GR], shi[GR];
+            pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, shs, nullptr, srow);
+            if constexpr (NBI > 0) pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, shi, nullptr, srow);
+            else {
+#pragma unroll
+                for (int i = 0; i < GR; ++i) shi[i] = 0;
+            }
+            pp_logits_merged<NBS, NBI>(c, A, shs, shi, fst);
+        } else {
         // panoptic heads, after the appearance branch (plan order)
         if (a.n_sem) {
             uint32_t sh[GR];
@@ -609,6 +767,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
             pp_layer_out<TRAIN, FUSE, CTX, GR, 0>(c, A, sh, dummy, a.n_inst, 4 + a.n_sem, samp, &fst);
+        }
         }
 #if PNR_TRACE
         ++c.titer;
@@ -628,7 +787,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #endif
 }
 
-template <int W, bool TRAIN, bool FUSE = false>
+template <int W, bool TRAIN, bool FUSE = false, int TAIL = 0>
 static int launch_mlp_pp(const MlpArgs& a0, hipStream_t stream)
 {
     MlpArgs a = a0;
@@ -636,7 +795,7 @@ static int launch_mlp_pp(const MlpArgs& a0, hipStream_t stream)
     PNR_REQUIRE(lds_bytes <= 163840, "pnr_mlp_forward: three weight slots of %d bytes exceed the 160 KiB LDS", a.slot_bytes);
     PNR_REQUIRE(a.n_chunks >= 4, "pnr_mlp_forward: network too small for the weight stream");
     a.n_groups = (a.S + 255) / 256;
-    auto kern = k_mlp_pp<W, TRAIN, FUSE>;
+    auto kern = k_mlp_pp<W, TRAIN, FUSE, TAIL>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         PNR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -711,6 +870,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)packed) & 15) == 0 && (((uintptr_t)acts) & 15) == 0,
                 "pnr_mlp_forward: rays / packed / acts must be 16-byte aligned");
     PNR_REQUIRE(!acts || desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_train: the training path is bf16 only");
+    PNR_REQUIRE(desc->plan == 0, "pnr_mlp_forward: plan=%d images are for pnr_mlp_forward_composite only", desc->plan);
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     MlpArgs a;
@@ -801,6 +961,16 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     hipStream_t st = (hipStream_t)stream;
+    if (desc->plan == 1) {
+        const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;
+        switch (4 * nbs + nbi) {
+        case 4: return launch_mlp_pp<256, false, true, 4>(a, st);
+        case 5: return launch_mlp_pp<256, false, true, 5>(a, st);
+        case 8: return launch_mlp_pp<256, false, true, 8>(a, st);
+        case 9: return launch_mlp_pp<256, false, true, 9>(a, st);
+        default: PNR_REQUIRE(false, "pnr_mlp_forward_composite: no plan-1 kernel for %d + %d logit blocks", nbs, nbi);
+        }
+    }
     return desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
 }
 

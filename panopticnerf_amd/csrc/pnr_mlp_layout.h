@@ -33,7 +33,7 @@
 
 #include "pnr.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PNR_HD __host__ __device__
 #else
 #define PNR_HD
@@ -59,7 +59,7 @@ enum { PNR_SEG_GX = 0, PNR_SEG_GD = 1, PNR_SEG_FEAT = 2 };
 
 // layer kinds in execution order
 enum { PNR_L_TRUNK0 = 0, PNR_L_TRUNK, PNR_L_SEM0, PNR_L_SEM1, PNR_L_INST0, PNR_L_INST1, PNR_L_FEATURE, PNR_L_VIEWS,
-       PNR_L_RGBSIGMA };
+       PNR_L_RGBSIGMA, PNR_L_LOGITS /* plan 1: semantic and instance logit layers as one chunk */ };
 
 // 32-row output blocks per chunk.  fp32 (parity mode) keeps 1: its fragments are twice as many.
 static constexpr int pnr_layer_fbc(int kind, int precision)

@@ -26,13 +26,25 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
                 "pnr_mlp: head_W=%d must equal W/2=%d", d->head_W, d->W / 2);
     PNR_REQUIRE(d->precision == PNR_PREC_BF16 || d->precision == PNR_PREC_FP32, "pnr_mlp: bad precision %d",
                 d->precision);
+    PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)),
+                "pnr_mlp: plan=%d is not available for this geometry (ask pnr_mlp_fused_plan)", d->plan);
     return PNR_OK;
+}
+
+PNR_EXPORT int pnr_mlp_fused_plan(const pnr_mlp_desc* desc)
+{
+    if (!desc) return 0;
+    pnr_mlp_desc d = *desc;
+    d.plan = 0;
+    if (pnr_mlp_validate(&d) != PNR_OK) return 0;
+    return pnr_plan1_supported(d) ? 1 : 0;
 }
 
 static int bwd_validate(const pnr_mlp_desc* d)
 {
     int rc = pnr_mlp_validate(d);
     if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d->plan == 0, "pnr_mlp backward: plan must be 0");
     PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
     PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
                 "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
@@ -98,6 +110,12 @@ static void describe_forward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p
                     f.kind = PNR_F_WEIGHT;
                     f.row0 = (ch.fb + fbl) * 32;
                     f.lo = 0; f.hi = L.out_dim; f.off = 0;
+                    if (L.kind == PNR_L_LOGITS) {               // blocks [0, index): sem1's rows, the rest: inst1's rows
+                        const bool sem = ch.fb + fbl < L.index;
+                        f.src = sem ? p.sem1_w : p.inst1_w; f.ld = H;
+                        f.row0 = (sem ? ch.fb + fbl : ch.fb + fbl - L.index) * 32;
+                        f.hi = sem ? d.n_sem : d.n_inst;
+                    }
                     f.seg_kind = kind; f.L = kind == PNR_SEG_GX ? d.xyz_L : d.dir_L; f.ks = ks;
                     switch (L.kind) {
                     case PNR_L_TRUNK0: f.src = p.pts_w[0]; f.ld = EX; break;
@@ -112,6 +130,7 @@ static void describe_forward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p
                     case PNR_L_INST1: f.src = p.inst1_w; f.ld = H; break;
                     case PNR_L_FEATURE: f.src = p.feature_w; f.ld = W; break;
                     case PNR_L_VIEWS: f.src = p.views_w; f.ld = W + ED; f.col_off = seg == 0 ? 0 : W; break;   // [feature, gamma(d)]
+                    case PNR_L_LOGITS: break;                  // set above
                     case PNR_L_RGBSIGMA:
                         if (seg == 0) { f.src = p.rgb_w; f.ld = H; f.lo = 0; f.hi = 3; f.off = 0; }             // rows 0..2 <- g
                         else { f.src = p.alpha_w; f.ld = W; f.lo = 3; f.hi = 4; f.off = 3; }                    // row 3 <- h
@@ -134,6 +153,10 @@ static void describe_forward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p
         case PNR_L_FEATURE: b.src = p.feature_b; break;
         case PNR_L_VIEWS: b.src = p.views_b; break;
         case PNR_L_RGBSIGMA: b.src = p.rgb_b; b.lo = 0; b.hi = 3; b.src2 = p.alpha_b; b.lo2 = 3; b.hi2 = 4; b.off2 = 3; break;
+        case PNR_L_LOGITS:      // rows [0, 32 nbs): sem1's bias; rows 32 nbs + [0, n_inst): inst1's
+            b.src = p.sem1_b; b.lo = 0; b.hi = d.n_sem; b.off = 0;
+            b.src2 = p.inst1_b; b.lo2 = L.index * 32; b.hi2 = L.index * 32 + d.n_inst; b.off2 = L.index * 32;
+            break;
         }
         im.frags.push_back(b);
     }

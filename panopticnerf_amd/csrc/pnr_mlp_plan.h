@@ -1,7 +1,9 @@
 // Execution plan of the fused MLP: the ordered list of layers and (layer, 32-row block)
 // chunks.  Host-only; used by the packer and by the launcher (chunk count, LDS slot size).
 // Order = the order the kernel consumes the weight stream:
-//   trunk 0..D-1 | [sem0, sem1] | [inst0, inst1] | feature | views | rgb+sigma
+//   plan 0 (classic):          trunk 0..D-1 | feature | views | rgb+sigma | [sem0, sem1] | [inst0, inst1]
+//   plan 1 (fused inference):  trunk 0..D-1 | feature | views | rgb+sigma | [sem0] | [inst0] | logits = {sem1, inst1} in ONE chunk;
+//                              layer 0 is one chunk of all W/32 blocks (32 MFMAs) instead of two of 16
 #pragma once
 #include <stddef.h>
 
@@ -11,8 +13,18 @@
 #include "pnr.h"
 #include "pnr_mlp_layout.h"
 
+// plan 1 exists for: bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks (the instantiated kernel tails)
+static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
+{
+    const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
+    return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1;
+}
+
+#ifndef PNR_PLAN1_TRUNK0_MERGE
+#define PNR_PLAN1_TRUNK0_MERGE 1
+#endif
 struct PnrLayer {
-    int kind, index;       // index: trunk layer number
+    int kind, index;       // index: trunk layer number; PNR_L_LOGITS: number of semantic blocks
     int out_dim, n_fb;     // output rows, 32-row blocks
     int nseg;
     int seg_kind[2], seg_nfeat[2];
@@ -38,6 +50,7 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         L.nks = pnr_seg_vl(k0, n0) / kpl + (k1 >= 0 ? pnr_seg_vl(k1, n1) / kpl : 0);
         L.fbc = pnr_layer_fbc(kind, d.precision);
         if (L.n_fb % L.fbc) L.fbc = 1;
+        if (PNR_PLAN1_TRUNK0_MERGE && d.plan == 1 && kind == PNR_L_TRUNK0) L.fbc = L.n_fb;      // plan 1: layer 0 is ONE chunk of W/32 blocks x 4 k-steps
         plan.layers.push_back(L);
     };
     plan.layers.clear();
@@ -52,13 +65,21 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
     add(PNR_L_FEATURE, 0, d.W, PNR_SEG_FEAT, d.W);
     add(PNR_L_VIEWS, 0, d.W / 2, PNR_SEG_FEAT, d.W, PNR_SEG_GD, 0);
     add(PNR_L_RGBSIGMA, 0, 4, PNR_SEG_FEAT, d.W / 2, PNR_SEG_FEAT, d.W);
-    if (d.n_sem) {
-        add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
-        add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.head_W);
-    }
-    if (d.n_inst) {
-        add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
-        add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.head_W);
+    if (d.plan == 1) {
+        const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
+        if (d.n_sem) add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        if (d.n_inst) add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        add(PNR_L_LOGITS, nbs, (nbs + nbi) * 32, PNR_SEG_FEAT, d.head_W);
+        plan.layers.back().fbc = nbs + nbi;         // every logit block in one chunk
+    } else {
+        if (d.n_sem) {
+            add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+            add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.head_W);
+        }
+        if (d.n_inst) {
+            add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+            add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.head_W);
+        }
     }
     int off = 0, mx = 0;
     for (size_t li = 0; li < plan.layers.size(); ++li) {

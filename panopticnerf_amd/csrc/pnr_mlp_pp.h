@@ -61,6 +61,12 @@ __device__ __forceinline__ void pp_lds_read(f32x4& dst, uint32_t addr)
     static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
+template <int OFF>
+__device__ __forceinline__ void pp_lds_read_b32(float& dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
 // wait until at most N younger LGKM operations are outstanding; `a` (the register the oldest
 // still-needed read fills) is an in/out operand so that its consumer cannot be scheduled above the wait
 template <int N>

@@ -88,15 +88,18 @@ class Network(nn.Module):
     def _version(self, level):
         return tuple(p._version for p in self.nerf(level).parameters())
 
-    def _pack(self, level, device, precision, backward):
+    def _pack(self, level, device, precision, backward, fused=False):
         """(desc, packed image on `device`) of level's NeRF, rebuilt when any parameter changed.  When the
         parameters live on that GPU the image is packed there (pnr_mlp_pack_device, buffers reused); otherwise
         on the host and uploaded."""
         net = self.nerf(level)                   # raises when a fine level is asked of a coarse-only network
-        key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision)
+        desc = net.desc(precision)
+        if fused and not backward:
+            # image for pnr_mlp_forward_composite only: the fused-inference chunk order where the geometry has one
+            desc.plan = ops.fused_plan(desc)
+        key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision, int(desc.plan))
         ver = self._version(level)
         hit = self._packed.get(key)
-        desc = net.desc(precision)
         sd = dict(net.named_parameters())
         on_dev = torch.device(device).type == "cuda" and all(p.device == torch.device(device) for p in sd.values())
         # cached until a parameter version changes (or invalidate_packed()).  Exception: a TRAINING network whose
@@ -116,8 +119,10 @@ class Network(nn.Module):
         self._packed[key] = (ver, desc, img, ws, ptrs)
         return desc, img
 
-    def packed(self, level, device, precision=None):
-        return self._pack(level, device, precision or self.precision, False)
+    def packed(self, level, device, precision=None, fused=False):
+        """(desc, packed image).  fused=True: the image only ops.mlp_forward_composite consumes (desc.plan as
+        pnr_mlp_fused_plan says); every other op takes the classic image (fused=False)."""
+        return self._pack(level, device, precision or self.precision, False, fused)
 
     def packed_bwd(self, level, device):
         return self._pack(level, device, "bf16", True)

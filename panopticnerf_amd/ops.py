@@ -114,6 +114,12 @@ def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=N
     return d
 
 
+def fused_plan(desc):
+    """desc.plan to use for an image that only mlp_forward_composite will consume (pnr_mlp_fused_plan): 1 where the geometry
+    has the fused-inference chunk order, else 0."""
+    return int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc)))
+
+
 def _param_struct(desc, params, device):
     """pnr_mlp_params_host filled with pointers to `params` (dict name -> tensor) moved/kept on `device`.
     Returns (struct, keep-alive list)."""

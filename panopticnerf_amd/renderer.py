@@ -79,12 +79,13 @@ class Renderer:
                 from . import train as _train       # autograd path
                 out = _train.level_train(self, lv, rays, zz, ls, li, noise)
             else:
-                desc, img = net.packed(lv, dev)
                 need_w = self.keep_weights or (lv == 0 and Nf > 0)
-                if self.fuse and ops.fused_supported(desc, zz.shape[1], self.sem_mode, noise):
-                    # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite)
+                if self.fuse and ops.fused_supported(net.nerf(lv).desc(net.precision), zz.shape[1], self.sem_mode, noise):
+                    # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite, its own chunk order)
+                    desc, img = net.packed(lv, dev, fused=True)
                     out = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w)
                 else:
+                    desc, img = net.packed(lv, dev)
                     raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
                     out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
             for k, v in out.items():

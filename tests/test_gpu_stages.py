@@ -452,6 +452,39 @@ def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, he
     assert torch.equal(lean["rgb"], got["rgb"]) and torch.equal(lean["depth"], got["depth"])
 
 
+@pytest.mark.parametrize("heads,plan", [((45, 32), 1), ((45, 0), 1), ((19, 8), 1), ((4, 0), 1), ((0, 0), 0), ((100, 0), 0), ((19, 40), 0)])
+@pytest.mark.parametrize("R,N", [(510, 192), (129, 64)])
+def test_fused_inference_plan_equals_classic_plan_bit_for_bit(dev, R, N, heads, plan):
+    """Plan 1 (pnr_mlp_fused_plan: both head hidden layers first, then the semantic and instance logit layers as ONE chunk
+    of interleaved transposed blocks) is the same arithmetic per layer as the classic chunk order: every output of
+    pnr_mlp_forward_composite is bit-identical between the two images.  Geometries without a plan-1 kernel (no heads, more
+    than 2 + 1 logit blocks) report plan 0 and keep the classic order; the classic kernels refuse a plan-1 image."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N + C)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K)).to(dev)
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d0, img0 = net.packed(1, dev, "bf16")
+    d1, img1 = net.packed(1, dev, "bf16", fused=True)
+    assert d0.plan == 0 and d1.plan == plan == ops.fused_plan(d0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    hit = torch.rand((R, N), device=dev, generator=g) < 0.3
+    ls = torch.where(hit, torch.randint(0, max(C, 1), (R, N), device=dev, generator=g), -1).int() if C else None
+    li = torch.where(hit, torch.randint(0, max(K, 1), (R, N), device=dev, generator=g), -1).int() if K else None
+    a = ops.mlp_forward_composite(d0, img0, rays, z, ls, li, False, True)
+    b = ops.mlp_forward_composite(d1, img1, rays, z, ls, li, False, True)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    if plan:
+        assert img1.numel() < img0.numel()          # one bias fragment for the merged chunk instead of one per logit block
+        with pytest.raises(RuntimeError, match="pnr_mlp_forward_composite only"):
+            ops.mlp_forward(d1, img1, rays, z, channel_major=True)
+
+
 def test_fused_path_is_what_the_renderer_runs_and_can_be_switched_off(dev):
     """Renderer.render (inference, bf16) takes the fused pass by default; cfg.fuse_composite = False keeps mlp_forward +
     composite.  Both give the same maps to fp32 rounding, identical z (the coarse weights feed sample_pdf: a weight that

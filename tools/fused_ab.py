@@ -3,7 +3,7 @@ process per build.  usage: python tools/fused_ab.py name1 name2 ...   (names und
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, %r)
 from types import SimpleNamespace as NS
 from panopticnerf_amd import make_network, ops, synthetic
@@ -14,7 +14,7 @@ synthetic.trained_like_(net)
 net = net.to(dev)
 rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
-desc, img = net.packed(1, dev)
+desc, img = net.packed(1, dev, fused=os.environ.get('PNR_PLAN', '1') != '0')
 box, ids = (t.to(dev) for t in synthetic.random_boxes(64, 45, 32))
 h = ops.bbox_hits(rays, box, 8)
 ls, li = ops.sample_labels(z, h[0], h[1], h[2], ids)

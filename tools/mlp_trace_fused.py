@@ -28,7 +28,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     net = net.to(dev)
     rays = synthetic.camera_rays()[:65536].to(dev)
     z = ops.stratified(rays, 192)
-    desc, img = net.packed(1, dev)
+    desc, img = net.packed(1, dev, fused=os.environ.get('PNR_PLAN', '1') != '0')
     box, ids = (t.to(dev) for t in synthetic.random_boxes(64, 45, 32))
     h = ops.bbox_hits(rays, box, 8)
     ls, li = ops.sample_labels(z, h[0], h[1], h[2], ids)
@@ -38,10 +38,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.exit(0)
 
 # chunk names of the 8x256 + 45/32 plan (pnr_mlp_plan.h order)
-names = ["trunk0"] * 2
+PLAN1 = os.environ.get("PNR_PLAN", "1") != "0"
+names = ["trunk0"] * (1 if PLAN1 else 2)       # plan 1: layer 0 is one chunk
 for l in range(1, 8):
     names += ["trunk%d" % l] * 4
-names += ["feature"] * 4 + ["views"] * 2 + ["rgbsigma"] + ["sem0"] * 2 + ["sem1"] * 2 + ["inst0"] * 2 + ["inst1"]
+if PLAN1:
+    names += ["feature"] * 4 + ["views"] * 2 + ["rgbsigma"] + ["sem0"] * 2 + ["inst0"] * 2 + ["logits"]
+else:
+    names += ["feature"] * 4 + ["views"] * 2 + ["rgbsigma"] + ["sem0"] * 2 + ["sem1"] * 2 + ["inst0"] * 2 + ["inst1"]
 lib = os.path.join(ROOT, "build", "ab", "libpnr_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "pptr"))
 out = subprocess.run([sys.executable, __file__, "--child", lib], capture_output=True, text=True, timeout=240)
 line = [l for l in out.stdout.splitlines() if l.startswith("TRACE ")]
