@@ -2,27 +2,33 @@
 path on synthetic KITTI-360-shaped frames (1408x376 rays).
 
 A "step" is one pass of the whole hot path (Renderer.render) over one full frame:
-stratified sampler -> [bbox hits/labels] -> coarse MLP -> compositing -> [sample_pdf ->
-fine MLP -> compositing].  Inputs (rays, boxes, packed weights) are resident in HBM before the
+stratified sampler -> [bbox hits/labels] -> coarse MLP + compositing -> [sample_pdf ->
+fine MLP + compositing].  Inputs (rays, boxes, packed weights) are resident in HBM before the
 timed region.  MLP sample evaluations per ray = N_samples + (N_samples + N_importance).
 
   python bench.py [--gpus N --steps K --warmup W] [--config 1..5] [--scaling weak|strong]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+--gpus N > 1 started as a PLAIN process (no WORLD_SIZE in the environment) launches its own N ranks, one per GPU, under
+torch.distributed.run (nccl = RCCL); started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
+joins the ranks it was given.  Rank 0 prints the ONE JSON line either way.
 
 --config n   BASELINE.json configs[n-1] (panopticnerf_amd/synthetic.py::BASELINE_CONFIGS); default 5 = the
              configuration the metric is quoted on (full panoptic, 64+128 samples, 8x256 MLPs, 45+32 heads, bbox prior).
---scaling    weak (default): every rank renders its own full frame, no collective on the data path.
-             strong: ONE frame, rays sharded over the ranks (shard.render_sharded), fine-level label maps + rgb +
-             depth all-gathered inside the timed region (BASELINE configs[4]: "rays sharded over 8 GPUs").
+--scaling    which form the headline `value` is: weak (default) = every rank renders its own full frame, no collective on the
+             data path; strong = ONE frame, rays sharded over the ranks (shard.render_sharded), fine-level label maps + rgb +
+             depth all-gathered inside the timed region (BASELINE configs[4]: "rays sharded over 8 GPUs").  BOTH forms are
+             timed in every run and reported in `scaling_modes`.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline                  -- the dominant kernel (fused top-level MLP, MFMA-bound): algorithmic FLOP per launch /
-                               mean launch duration from hipEvents on the launch stream;
-  roofline_composite[_coarse] -- the compositing scan (HBM-bound) at the top / coarse level;
+                               mean launch duration from hipEvents on the launch stream (libpnr_bench.so);
+  roofline_composite[_coarse] -- the standalone compositing scan (HBM-bound; training / two-kernel path) at the top / coarse level;
+  rccl                      -- machine-checkable proof of the process group: backend, world size, one device per rank, the
+                               time of the gradient bucket's all-reduce;
+  scaling_modes             -- weak and strong whole-job values of this run;
   cpu_baseline              -- the oracle's PyTorch CPU restatement of the same workload timed on the host cores on a
-                               bounded ray sample (a reported baseline, not the target);
-  cpu_baseline_config1      -- BASELINE configs[0] (the reference's CPU-runnable case) on the host, full frame if the
-                               time budget allows;
+                               bounded ray sample, in 8192-ray chunks (a reported baseline, not the target);
+  cpu_baseline_config1      -- BASELINE configs[0] (the reference's CPU-runnable case) on the host;
   train_step                -- secondary: one training step on a ray batch per rank (never the headline value).
 """
 import argparse
@@ -162,62 +168,134 @@ def event_ms(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_leg(config, params, rays_c, box, ids, seconds, full_frame):
-    """The oracle's PyTorch CPU path on `config`, time-bounded.  full_frame: walk the frame in 8192-ray chunks in order
-    (stops early when the budget is spent); otherwise an evenly strided 512-ray-per-chunk subsample.  Returns
-    (Msamples/s, rays done, seconds, threads used, threads available, first chunk (rays, reference output))."""
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_child(argv):
+    """One timed run of the oracle's CPU path in a FRESH process whose affinity was narrowed to n CPUs before torch (and its
+    OpenMP team) started: `taskset`-visible pinning.  Walks 8192-ray chunks in frame order from chunk k0 for `seconds`
+    (at least one chunk).  Prints one JSON line."""
+    payload, n, k0, seconds, chunk = argv[0], int(argv[1]), int(argv[2]), float(argv[3]), int(argv[4])
+    cpus = sorted(os.sched_getaffinity(0))[:n]
+    os.sched_setaffinity(0, cpus)
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    os.environ["MKL_NUM_THREADS"] = str(n)
+    import torch as t
+    t.set_num_threads(n)
     from oracle import torch_oracle as to
     from panopticnerf_amd import synthetic
-    c = synthetic.BASELINE_CONFIGS[config]
-    oc = to.mlp_config(D=c["D"], W=c["W"], skips=tuple(c["skips"]), n_sem=c["num_classes"], n_inst=c["num_instances"],
-                       head_W=c["W"] // 2)
+    P = t.load(payload)
+    c = synthetic.BASELINE_CONFIGS[P["config"]]
+    oc = to.mlp_config(D=c["D"], W=c["W"], skips=tuple(c["skips"]), n_sem=c["num_classes"], n_inst=c["num_instances"], head_W=c["W"] // 2)
     Nc, Nf = c["N_samples"], c["N_importance"]
     per_ray = Nc + (Nc + Nf if Nf else 0)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-
-    def run(sub):
-        t0 = time.perf_counter()
-        r = to.render_rays(params, oc, sub, Nc, Nf, box=box if c["bbox"] else None, box_ids=ids if c["bbox"] else None)
-        return r, time.perf_counter() - t0
-
-    n_rays = rays_c.shape[0]
-    stride = max(n_rays // 512, 1)
-    # pick the thread count that is fastest on this host (all logical CPUs is often NOT: SMT +
-    # oversubscribed OpenMP teams), then spend the time budget at that setting
-    probe = rays_c[::stride][:256].contiguous()
-    best_n, best_t = 1, float("inf")
-    first = None
-    with torch.no_grad():
-        for n in sorted({min(k, avail) for k in (8, 16, 32, 64, 128, avail)}):
-            torch.set_num_threads(n)
-            run(probe[:64])
-            _, t = run(probe)
-            if t < best_t:
-                best_n, best_t = n, t
-            if t > 20.0:
-                break
-        torch.set_num_threads(best_n)
-        done, t_cpu, k = 0, 0.0, 0
-        while t_cpu < seconds:
-            if full_frame:
-                sub = rays_c[k * 8192:(k + 1) * 8192]
-            else:
-                sub = rays_c[k::stride][:512].contiguous() if k < stride else rays_c[:0]
+    rays = P["rays"]
+    box, ids = (P["box"], P["ids"]) if c["bbox"] else (None, None)
+    done, t_cpu, k, first = 0, 0.0, k0, None
+    with t.no_grad():
+        to.render_rays(P["params"], oc, rays[:64], Nc, Nf, box=box, box_ids=ids)        # thread team up, code paths warm
+        while t_cpu < seconds or done == 0:
+            sub = rays[k * chunk:(k + 1) * chunk]
             if sub.shape[0] == 0:
                 break
-            ref, t = run(sub)
-            if first is None:
-                first = (sub, ref)
-            t_cpu += t
+            t0 = time.perf_counter()
+            ref = to.render_rays(P["params"], oc, sub, Nc, Nf, box=box, box_ids=ids)
+            t_cpu += time.perf_counter() - t0
+            if first is None and P.get("keep_first"):
+                top = 1 if Nf else 0
+                t.save({"k": k, "rgb": ref[f"rgb_{top}"]}, payload + ".first")
+                first = True
             done += sub.shape[0]
             k += 1
-    return done * per_ray / t_cpu / 1e6, done, t_cpu, best_n, avail, first
+    print(json.dumps({"msamples": done * per_ray / max(t_cpu, 1e-9) / 1e6, "rays": done, "seconds": t_cpu, "threads": t.get_num_threads(),
+                      "affinity": len(os.sched_getaffinity(0)), "next_chunk": k,
+                      "parallel_info": [l.strip() for l in t.__config__.parallel_info().splitlines() if "threads" in l.lower()][:4]}), flush=True)
+
+
+def cpu_leg(config, params, rays_c, box, ids, seconds, keep_first, chunk=8192):
+    """The oracle's PyTorch CPU path on `config`, time-bounded.  The thread count is PROBED on the chunk size that is then
+    timed (8192-ray chunks): each candidate renders one whole chunk in its own pinned process (cpu_child), the
+    fastest setting then walks further chunks for `seconds`.  Returns the cpu_baseline object (+ the first chunk's rgb)."""
+    import subprocess
+    import tempfile
+    from panopticnerf_amd import synthetic
+    avail = len(os.sched_getaffinity(0))
+    cc = synthetic.BASELINE_CONFIGS[config]
+    tmp = tempfile.mkdtemp(prefix="pnr_cpu_")
+    payload = os.path.join(tmp, "payload.pt")
+    torch.save({"config": config, "params": params, "rays": rays_c, "box": box, "ids": ids, "keep_first": keep_first}, payload)
+
+    def child(n, k0, secs):
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", payload, str(n), str(k0), str(secs), str(chunk)],
+                            capture_output=True, text=True, timeout=900)
+        line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            raise RuntimeError("cpu child failed: " + cp.stderr[-400:])
+        return json.loads(line[-1])
+
+    cands = sorted({min(k, avail) for k in (8, 16, 32)})
+    probe, k = {}, 0
+    for n in cands:
+        r = child(n, k, 0.0)                   # exactly one chunk
+        probe[n] = r
+        k = r["next_chunk"]
+    best = max(probe, key=lambda n: probe[n]["msamples"])
+    tot_rays, tot_s = probe[best]["rays"], probe[best]["seconds"]
+    if seconds > tot_s:
+        r = child(best, k, seconds - tot_s)
+        tot_rays += r["rays"]
+        tot_s += r["seconds"]
+    per_ray = cc["N_samples"] + (cc["N_samples"] + cc["N_importance"] if cc["N_importance"] else 0)
+    first = None
+    if keep_first and os.path.exists(payload + ".first"):
+        first = torch.load(payload + ".first")
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(tot_rays * per_ray / tot_s / 1e6, 4), "unit": "Msamples/s", "cores": best, "kind": "port",
+            "sample": "%d rays of the frame in %d-ray chunks (frame order), %s, fp32, oracle/torch_oracle.py, %.1f s at the fastest of the "
+                      "probed thread counts; every run in its own process pinned (sched_setaffinity) to `cores` of the %d host CPUs"
+                      % (tot_rays, chunk, cc["name"], tot_s, avail),
+            "thread_probe_msamples": {str(n): round(probe[n]["msamples"], 4) for n in cands},
+            "torch_threads": probe[best]["threads"], "parallel_info": probe[best]["parallel_info"], "cpu_model": cpu_model(),
+            "host_cpus": avail}, first
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a process group in the environment: start the N ranks ourselves."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def train_bytes_per_sample(c):
+    """HBM bytes per sample of the three training kernels: forward writes the saved activations (bf16) + one gate
+    bit per ReLU output + raw; the data-gradient pass reads gate bits + d_raw and writes every dY (bf16); the weight-gradient
+    kernel reads both sets back (the trunk output h by four jobs)."""
+    D, W, H, ch = c["D"], c["W"], c["W"] // 2, 4 + c["num_classes"] + c["num_instances"]
+    acts = 2 * (64 + 32 + (D + 1) * W + 3 * H)
+    gates = (D * W + 3 * H) // 8
+    dys = 2 * ((D + 1) * W + 3 * H + 160)
+    return (acts + gates + 4 * ch) + (gates + 4 * ch + dys) + (acts + dys + 3 * 2 * W)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-child":
+        return cpu_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -228,54 +306,82 @@ def main():
     ap.add_argument("--chunk", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--cpu1-seconds", type=float, default=None,
-                    help="time budget of the config-1 CPU leg (default: 15 s with --config 5 or 1, else 0)")
+                    help="time budget of the config-1 CPU leg (default: 10 s with --config 5 or 1, else 0)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=None, help="secondary training-step measurement (0 = skip; "
                     "default 3 with --config 5, else 0)")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--graph-step-child", action="store_true", help=argparse.SUPPRESS)
+    # launch / collective plumbing test (tests/test_host.py): no GPU, gloo, a stub in place of the renderer -- never a measurement
+    ap.add_argument("--fake-render", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.train_steps is None:
         args.train_steps = 3 if args.config == 5 else 0
     if args.cpu1_seconds is None:
-        args.cpu1_seconds = 15.0 if (args.config in (1, 5) and args.cpu_seconds > 0) else 0.0
+        args.cpu1_seconds = 10.0 if (args.config in (1, 5) and args.cpu_seconds > 0) else 0.0
     if args.graph_step_child:
         return graph_step_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
+    fake = args.fake_render
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    import torch.distributed as dist
+    if fake:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if fake:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from panopticnerf_amd import make_network, make_renderer, ops, shard, synthetic
+    from panopticnerf_amd import shard, synthetic
 
     c = synthetic.BASELINE_CONFIGS[args.config]
     N_C, N_F, N_SEM, N_INST = c["N_samples"], c["N_importance"], c["num_classes"], c["num_instances"]
     N_TOP = N_C + N_F
     per_ray = N_C + (N_TOP if N_F else 0)
-    cfg = synthetic.baseline_cfg(args.config, precision=args.precision, chunk_size=args.chunk, keep_weights=False)
-    torch.manual_seed(0)
-    net = make_network(cfg).eval()
-    synthetic.trained_like_(net)
-    net = net.to(dev)
-    rend = make_renderer(cfg, net)
-    strong = args.scaling == "strong"
+    top = 1 if N_F else 0
+    KEEP_W = False      # fine-level per-sample weights are not written by the timed frames (nothing downstream reads them)
+    if fake:
+        rays = synthetic.camera_rays()[::64].contiguous()
+        net = rend = box = ids = None
+
+        def render_dict(r):        # stub with the renderer's output keys and shapes: exercises sharding / gather / JSON only
+            n = r.shape[0]
+            out = {f"rgb_{top}": r[:, :3] * 0.5, f"depth_{top}": r[:, 6].clone()}
+            if N_SEM:
+                out[f"semantic_{top}"] = r[:, :1].repeat(1, N_SEM)
+            return out
+    else:
+        from panopticnerf_amd import benchlib, make_network, make_renderer, ops
+        cfg = synthetic.baseline_cfg(args.config, precision=args.precision, chunk_size=args.chunk, keep_weights=KEEP_W)
+        torch.manual_seed(0)
+        net = make_network(cfg).eval()
+        synthetic.trained_like_(net)
+        net = net.to(dev)
+        rend = make_renderer(cfg, net)
+        box = ids = None
+        if c["bbox"]:
+            box, ids = (t.to(dev) for t in synthetic.random_boxes(64, N_SEM, max(N_INST, 1)))
     # weak scaling: every rank renders its own full frame (a different camera yaw); strong: every rank holds the SAME
     # frame and renders its interleaved share of the rays.  Rays are independent: no data-path collective;
     # strong scaling adds the all-gather of the per-ray output maps.
-    rays = synthetic.camera_rays(yaw=0.0 if strong else 0.05 * rank).to(dev)
-    box = ids = None
-    if c["bbox"]:
-        box, ids = (t.to(dev) for t in synthetic.random_boxes(64, N_SEM, max(N_INST, 1)))
-    n_rays = rays.shape[0]
-    top = 1 if N_F else 0
+    if not fake:
+        rays_weak = synthetic.camera_rays(yaw=0.05 * rank).to(dev)
+        rays_strong = rays_weak if world == 1 else synthetic.camera_rays(yaw=0.0).to(dev)
+    else:
+        rays_weak = rays_strong = rays
+    n_rays = rays_weak.shape[0]
 
     def bdict(r):
         b = {"rays": r}
@@ -283,44 +389,88 @@ def main():
             b.update(bbox=box, bbox_ids=ids)
         return b
 
-    if strong:
+    if fake:
+        def fake_reduce(local):
+            out = {k: v for k, v in local.items() if not k.startswith("semantic")}
+            if N_SEM:
+                out["semantic_label"] = local[f"semantic_{top}"].argmax(-1).int()
+            return out
+
+        def frame_strong():
+            return shard.render_sharded(render_dict, rays_strong, rank, world, gather=True, reduce_fn=fake_reduce)
+
+        def frame_weak():
+            return render_dict(rays_weak)
+    else:
         reduce_fn = shard.label_maps(level=top) if N_SEM else None
         keys = None if N_SEM else (f"rgb_{top}", f"depth_{top}")
 
-        def frame():
-            return shard.render_sharded(lambda r: {k: v[0] for k, v in rend.render(bdict(r[None])).items()}, rays, rank, world,
+        def frame_strong():
+            return shard.render_sharded(lambda r: {k: v[0] for k, v in rend.render(bdict(r[None])).items()}, rays_strong, rank, world,
                                         gather=True, keys=keys, reduce_fn=reduce_fn)
-    else:
-        full = bdict(rays.reshape(H_IMG, W_IMG, 8))
+        full = bdict(rays_weak.reshape(H_IMG, W_IMG, 8))
 
-        def frame():
+        def frame_weak():
             return rend.render(full)
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not fake:
+            torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            frame()
+    def timed(frame):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                frame()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                frame()
+            sync()
+            dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    modes = {}
+    order = ["weak", "strong"] if args.scaling == "weak" else ["strong", "weak"]
+    for mode in order:          # the headline form first
+        dt = timed(frame_weak if mode == "weak" else frame_strong)
+        frames = world if mode == "weak" else 1
+        modes[mode] = {"value": round(n_rays * per_ray * frames * args.steps / dt / 1e6, 2), "unit": "Msamples/s",
+                       "ms_per_step": round(dt / args.steps * 1e3, 3), "frames_per_step": frames}
+    value, ms_per_step, frames_per_step = (modes[args.scaling][k] for k in ("value", "ms_per_step", "frames_per_step"))
+
+    # ---- the process group, machine-checkable: backend, size, one device per rank, the gradient bucket's all-reduce
+    n_bucket = 1_300_000 if fake or net is None else sum(p.numel() for p in net.parameters())
+    mine = "cpu (fake)" if fake else "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        bucket = torch.ones(n_bucket, device=dev, dtype=torch.float32)
+        for _ in range(3):
+            dist.all_reduce(bucket)
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            frame()
+        for _ in range(10):
+            dist.all_reduce(bucket)
         sync()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    frames_per_step = 1 if strong else world
-    value = n_rays * per_ray * frames_per_step * args.steps / dt / 1e6
+        ar_ms = (time.perf_counter() - t0) / 10 * 1e3
+        ok = bool(abs(float(bucket[0]) - float(world) ** 13) <= 1e-3 * float(world) ** 13)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices,
+                "allreduce_ms": round(ar_ms, 4), "allreduce_bytes": 4 * n_bucket, "allreduce_sum_ok": ok}
+    else:
+        rccl = {"backend": None, "world_size": 1, "devices": [mine], "allreduce_ms": None, "allreduce_bytes": 4 * n_bucket,
+                "note": "single rank: no process group was created"}
 
     roofline = None
     extra = {}
-    if rank == 0 and not args.no_roofline:
+    rays = rays_weak
+    if rank == 0 and not args.no_roofline and not fake:
         with torch.no_grad():
             # dominant kernel: the fused top-level MLP on one renderer chunk
             rc = rays[: args.chunk].contiguous()
@@ -330,34 +480,30 @@ def main():
             fdesc, fimg = net.packed(top, dev, fused=True)      # the image the fused pass consumes (its own chunk order)
             ch = 4 + N_SEM + N_INST
             raw = ops.alloc_raw(ch, Rc * N_TOP, dev)   # as Renderer allocates it
-            ops.time_mlp_forward(desc, img, rc, z, raw, 1)                  # fills raw for the compositing measurements below
+            ops.mlp_forward(desc, img, rc, z, out=raw)                       # fills raw for the compositing measurements below
             # the launch the step actually runs: with the fused compositing epilogue where the renderer uses it
             fused = bool(getattr(rend, "fuse", False)) and ops.fused_supported(fdesc, N_TOP, rend.sem_mode, None)
             if fused:
-                fls = fli = None
-                if c["bbox"]:
-                    fh = ops.bbox_hits(rc, box, cfg.max_hits if hasattr(cfg, "max_hits") else 8)
-                    fls, fli = ops.sample_labels(z, fh[0], fh[1], fh[2], ids)
-                    fls, fli = (fls if N_SEM else None), (fli if N_INST else None)
-                need_w = bool(rend.keep_weights or not N_F)
-                ops.time_mlp_forward_composite_clk(fdesc, fimg, rc, z, fls, fli, need_w, 1)
-                ms, kernel_mhz = ops.time_mlp_forward_composite_clk(fdesc, fimg, rc, z, fls, fli, need_w, 5)
+                benchlib.time_mlp_forward_tiles(fdesc, fimg, rc, z, 1)
+                ms, kernel_mhz = benchlib.time_mlp_forward_tiles(fdesc, fimg, rc, z, 5)
             else:
-                ms, kernel_mhz = ops.time_mlp_forward_clk(desc, img, rc, z, raw, 5)
+                ms, kernel_mhz = benchlib.time_mlp_forward(desc, img, rc, z, raw, 5)
             # what the matrix pipe of THIS device sustains (register-only MFMA loop): with constant operands, and with
             # random operands that change from MFMA to MFMA (the toggle rate of real data: the chip lowers its clock)
-            pk_const, mhz_const = ops.probe_mfma_peak(False, 12000, dev)
-            pk_rand, mhz_rand = ops.probe_mfma_peak(True, 12000, dev)
+            pk_const, mhz_const = benchlib.probe_mfma_peak(False, 12000, dev)
+            pk_rand, mhz_rand = benchlib.probe_mfma_peak(True, 12000, dev)
             S = Rc * N_TOP
             skip = c["skips"][0] if c["skips"] else -1
             flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-            kname = ("k_mlp_pp<fused compositing epilogue>" if fused else
+            kname = ("k_mlp_pp<fused compositing epilogue, plan %d>" % fdesc.plan if fused else
                      "k_mlp_pp" if (ops.mlp_variant() >= 1 and args.precision == "bf16") else "k_mlp_fused")
+            tkey = "k_mlp_pp_fused" if fused else "k_mlp_pp"
             roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic("k_mlp_fused", Rc, args.config),
+                        "frac": round(ach / peak, 4), "traffic": traffic(tkey, Rc, args.config),
+                        "traffic_source": "profiles/latest_traffic.json: rocprofv3 PMC passes of this command, recorded (not measured in this run)",
                         "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
                         "shader_mhz_during_kernel": round(kernel_mhz, 0),
                         "mfma_sustained": {"note": "register-only bf16 MFMA loop on every SIMD of this device, measured in this run",
@@ -379,13 +525,16 @@ def main():
                 cms = event_ms(lambda: ops.composite(rw, zz, rc, N_SEM, N_INST, True, None, ls, li, 0, False, want_w), 5)
                 bytes_ray = composite_bytes_per_ray(N, N_SEM, N_INST, c["bbox"] and (N_SEM or N_INST), want_w)
                 gbs = Rc * bytes_ray / (cms * 1e-3) / 1e9
-                read_gbs = ops.probe_raw_read(rw, Rc, N, 5)     # same image, same order, no arithmetic
-                return {"kernel": "k_composite<channel-major> (%s, N=%d, %d channels)" % (tag, N, ch), "bound": "hbm",
-                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": traffic("k_composite", Rc, args.config) if N == 192 else None,
-                        "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray,
-                        "pure_read_same_pattern_gbs": round(read_gbs, 1),
-                        "frac_of_pure_read": round(gbs / read_gbs, 4) if read_gbs > 0 else None}
+                read_gbs = benchlib.probe_raw_read(rw, Rc, N, 5)     # same image, same order, no arithmetic
+                out = {"kernel": "k_composite<channel-major> (%s, N=%d, %d channels)" % (tag, N, ch), "bound": "hbm",
+                       "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "traffic": traffic("k_composite", Rc, args.config) if N == 192 else None,
+                       "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray, "timing": "hipEvents around 5 launches",
+                       "note": "training / two-kernel path only: the fused inference step does not launch it"}
+                # the pure-read probe walks the image 4 samples per lane; it is a ceiling only where that mapping is the kernel's
+                if read_gbs > gbs:
+                    out.update(pure_read_same_pattern_gbs=round(read_gbs, 1), frac_of_pure_read=round(gbs / read_gbs, 4))
+                return out
 
             # weights are written where the renderer needs them: the coarse level of a coarse+fine render (sample_pdf input)
             extra["roofline_composite"] = comp_roofline(N_TOP, not N_F, "top level")
@@ -397,7 +546,7 @@ def main():
     # backward through the HIP kernels (compositing, dgrad, wgrad), flat-bucket
     # gradient all-reduce over RCCL, Adam.  Guarded: a failure here must not lose the headline line.
     train_info = None
-    if args.train_steps > 0:
+    if args.train_steps > 0 and not fake:
         try:
             from panopticnerf_amd import NetworkWrapper, train as pnr_train
             tnet = make_network(cfg).to(dev).train()
@@ -446,70 +595,72 @@ def main():
             skip = c["skips"][0] if c["skips"] else -1
             fwd_flops = mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             n_par = sum(p.numel() for p in tnet.parameters())
+            bps = train_bytes_per_sample(c)
+            tbs = bps * S_step / tdt / 1e12
             train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms, "rays_per_rank": args.train_rays,
                           "Msamples_per_s_fwd_bwd": round(S_step * world / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
                           "grad_allreduce": "flat bucket of %d fp32, %s" % (n_par, "RCCL (nccl)" if world > 1 else "single rank: skipped"),
                           "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
                           "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE",
-                          # forward + data-gradient + weight-gradient GEMMs = 3x the forward's algorithmic FLOPs
-                          "roofline": {"bound": "mfma", "flop_per_sample_fwd_bwd": 3 * fwd_flops,
-                                       "achieved": round(3 * fwd_flops * S_step / tdt / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": round(3 * fwd_flops * S_step / tdt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                       "note": "whole step per rank incl. losses, Adam and host launch gaps; HBM-side the step writes "
-                                               "%d B/sample of saved activations (+ 1 gate bit per ReLU output) and %d B/sample of dY, "
-                                               "and k_wgrad reads both back (DESIGN.md 7)" % (
-                                                   2 * (64 + 32 + (c["D"] + 1) * c["W"] + 3 * (c["W"] // 2)),
-                                                   2 * ((c["D"] + 1) * c["W"] + 3 * (c["W"] // 2) + 160))}}
+                          # forward + data-gradient + weight-gradient GEMMs = 3x the forward's algorithmic FLOPs; the step is
+                          # nearer the HBM roof than the MFMA roof, so both fractions are reported
+                          "roofline": {"bound": "hbm", "flop_per_sample_fwd_bwd": 3 * fwd_flops,
+                                       "achieved_tflops": round(3 * fwd_flops * S_step / tdt / 1e12, 1), "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                                       "frac_mfma": round(3 * fwd_flops * S_step / tdt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                       "bytes_per_sample": bps, "achieved": round(tbs * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(tbs * 1e3 / HBM_PEAK_GBS, 4),
+                                       "note": "whole step per rank incl. losses, Adam and host launch gaps; bytes_per_sample = saved "
+                                               "activations + gate bits + raw written by the forward, gate bits + d_raw read and dY "
+                                               "written by the data-gradient pass, both sets read back by the weight-gradient kernel "
+                                               "(DESIGN.md 7)"}}
         except Exception as e:      # noqa: BLE001
             train_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
     cpu_baseline = None
     # the CPU legs run at N = 1 only (rank 0 would otherwise keep N - 1 idle ranks waiting, on host cores the other ranks share)
-    if rank == 0 and world == 1 and (args.cpu_seconds > 0 or args.cpu1_seconds > 0):
+    if rank == 0 and world == 1 and not fake and (args.cpu_seconds > 0 or args.cpu1_seconds > 0):
         rays_c = rays.cpu()
         box_c, ids_c = (None, None) if box is None else (box.cpu(), ids.cpu())
-
-        def leg(config, seconds, full_frame, prm):
-            v, done, t_cpu, best_n, avail, first = cpu_leg(config, prm, rays_c, box_c, ids_c, seconds, full_frame)
-            cc = synthetic.BASELINE_CONFIGS[config]
-            what = ("the first %d rays of the frame in 8192-ray chunks%s" % (done, " = the FULL frame" if done == n_rays else "")
-                    if full_frame else "%d rays of the same frame (every %d-th ray)" % (done, max(n_rays // 512, 1)))
-            return {"value": round(v, 4), "unit": "Msamples/s", "cores": best_n, "kind": "port",
-                    "sample": "%s, %s, fp32, oracle/torch_oracle.py, %.1f s, %d of %d host CPUs (fastest setting probed)"
-                              % (what, cc["name"], t_cpu, best_n, avail)}, first
-
         if args.cpu_seconds > 0:
             params = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
                       "fine": {k: v.detach().cpu() for k, v in (net.nerf_1 or net.nerf_0).state_dict().items()}}
-            cpu_baseline, first = leg(args.config, args.cpu_seconds, args.config == 1, params)
-            if first is not None:
-                sub, ref = first
-                with torch.no_grad():
-                    out = rend.render(bdict(sub[None].to(dev)))
-                mse = torch.mean((out[f"rgb_{top}"][0].cpu() - ref[f"rgb_{top}"]) ** 2).item()
-                extra["psnr_db_hip_vs_oracle_fp32_render"] = round(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2)
+            try:
+                cpu_baseline, first = cpu_leg(args.config, params, rays_c, box_c, ids_c, args.cpu_seconds, True)
+                if first is not None:
+                    k0 = first["k"]
+                    with torch.no_grad():
+                        out = rend.render(bdict(rays[k0 * 8192:(k0 + 1) * 8192][None].contiguous()))
+                    mse = torch.mean((out[f"rgb_{top}"][0].cpu() - first["rgb"]) ** 2).item()
+                    extra["psnr_db_hip_vs_oracle_fp32_render"] = round(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20))).item(), 2)
+            except Exception as e:      # noqa: BLE001
+                cpu_baseline = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.cpu1_seconds > 0 and args.config != 1:
             # BASELINE configs[0], the reference's own CPU-runnable case (BASELINE.md's CPU-baseline plan): its own small network
             from oracle import torch_oracle as to
             c1 = synthetic.BASELINE_CONFIGS[1]
             p1 = to.init_params(to.mlp_config(D=c1["D"], W=c1["W"], skips=tuple(c1["skips"])), seed=0, sigma_bias=0.03)
-            extra["cpu_baseline_config1"], _ = leg(1, args.cpu1_seconds, True, {"coarse": p1, "fine": p1})
+            try:
+                extra["cpu_baseline_config1"], _ = cpu_leg(1, {"coarse": p1, "fine": p1}, rays_c, None, None, args.cpu1_seconds, False)
+            except Exception as e:      # noqa: BLE001
+                extra["cpu_baseline_config1"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
-        if strong:
+        if args.scaling == "strong":
             par = "ONE frame, rays interleaved over %d rank(s); per-ray label maps + rgb + depth all-gathered (RCCL) inside the timed region" % world
         else:
             par = "one frame per rank, %d rank(s), no data-path collective" % world
-        line = {"metric": "Msamples/sec (coarse+fine), KITTI-360 1408x376", "value": round(value, 2),
+        line = {"metric": "Msamples/sec (coarse+fine), KITTI-360 1408x376", "value": value,
                 "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
-                "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": args.precision,
+                "data": "fake (CPU stub in place of the renderer: launch / collective plumbing test, not a measurement)" if fake else "synthetic",
                 "config": {"workload": "BASELINE %s; %dx%d frame, %d%s samples/ray, %dx%d MLP%s, semantic %d / instance %d heads, bbox prior %s"
                                        % (c["name"], W_IMG, H_IMG, N_C, "+%d" % N_F if N_F else "", c["D"], c["W"], "s" if N_F else "",
                                           N_SEM, N_INST, "on" if c["bbox"] else "off"),
                            "baseline_config": args.config, "rays_per_frame": n_rays, "frames_per_step": frames_per_step,
-                           "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "parallelism": par},
+                           "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "keep_weights": KEEP_W, "parallelism": par},
+                "scaling_modes": modes, "rccl": rccl,
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)
         if train_info is not None:
@@ -518,7 +669,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

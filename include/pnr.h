@@ -120,9 +120,9 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
                     int64_t raw_stride_c, void* stream);
 
 /* ---- a5 + a6 fused (inference): evaluate the network and composite in ONE pass -- the raw image (4 + n_sem + n_inst floats per
- * sample) never goes to HBM.  The fused MLP's epilogue reduces every 32-sample tile to one record (csrc/pnr_mlp_fuse.h:
- * transmittance factor, weighted sums of 1, z, sigmoid(rgb), the logits and the fixed fields: 20 B per sample instead of
- * 324 at 45 / 32 heads) and a second small kernel finishes each ray from its n_samples / 32 records.  Replaces the pair
+ * sample) never goes to HBM.  The fused MLP's epilogue keeps per 32-sample tile one record (csrc/pnr_mlp_fuse.h: transmittance
+ * factor and the weighted logit sums) and per sample (local weight, raw r, g, b): 26 B per sample instead of 324 at 45 / 32
+ * heads; a second small kernel finishes each ray from them (acc / depth / rgb sums, the fixed fields, the logits).  Replaces the pair
  * pnr_mlp_forward + pnr_composite (same reference rows: render_rays' network call + raw2outputs, /root/reference/README.md:13
  * points to the branch that holds them) under: bf16, logits compositing (sem_mode 0), no sigma noise, n_samples a
  * multiple of 32 in [32, 256], n_sem + n_inst <= 128.  Results equal the two-kernel path to fp32 rounding (the sums are
@@ -140,12 +140,15 @@ int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, cons
                               int white_bkgd, float* rgb, float* depth, float* acc, float* weights, float* sem,
                               float* inst, float* fix_sem, float* fix_inst, void* workspace, void* stream);
 
-/* bench only: mean ms per fused MLP launch of pnr_mlp_forward_composite (without the combine kernel) over `iters` launches, and
- * the mean shader clock during the last one (scratch: >= 16 device bytes). */
-int pnr_time_mlp_forward_composite_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                       int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
-                                       int want_weights, void* workspace, int iters, void* scratch, float* ms_out_host,
-                                       float* mhz_out_host, void* stream);
+/* The two halves of pnr_mlp_forward_composite as separate calls (it is exactly these two, in this order, on one workspace):
+ * pnr_mlp_forward_tiles runs the fused MLP -- per 32-sample tile one record (transmittance factor, logit sums), per sample
+ * (local weight, raw r, g, b) -- and pnr_composite_combine finishes every ray from them (k_composite_combine: one wave per ray).
+ * Same arguments and conditions as pnr_mlp_forward_composite. */
+int pnr_mlp_forward_tiles(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z, int64_t n_rays,
+                          int n_samples, void* workspace, void* stream);
+int pnr_composite_combine(const pnr_mlp_desc* desc, const void* workspace, const float* z, int64_t n_rays, int n_samples,
+                          const int32_t* label_sem, const int32_t* label_inst, int white_bkgd, float* rgb, float* depth,
+                          float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, void* stream);
 
 /* ---- a9 (training): forward that also saves what the backward needs, the data-gradient pass, and the
  * buffer layouts.  bf16 only; n_sem, n_inst <= 64.
@@ -297,27 +300,12 @@ int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float
                       const int32_t* hit_box, const int32_t* hit_count, int max_hits,
                       const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream);
 
-/* ---- measurement helper: run `iters` launches of pnr_mlp_forward / pnr_composite on `stream`
- * bracketed by hipEvents recorded on that same stream; returns mean milliseconds per launch in
- * *ms_out (host).  Synchronises the stream (bench use only; not graph-capture safe). */
-int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                         int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
-                         int64_t raw_stride_c, int iters, float* ms_out_host, void* stream);
-/* The same, plus the mean SHADER CLOCK during the last launch (s_memtime / s_memrealtime of workgroup 0's first wave);
- * scratch: >= 16 bytes of device memory.  Bench only. */
-int pnr_time_mlp_forward_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                             int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c,
-                             int iters, void* scratch, float* ms_out_host, float* mhz_out_host, void* stream);
-/* What the matrix pipe of this device SUSTAINS (bench only; synchronises): a register-only bf16 MFMA loop on every SIMD with
- * constant operands (random_operands = 0) or with pseudo-random operands that change from MFMA to MFMA (1: the toggle
- * rate of real data -- on MI355X the clock then drops from ~2.37 to ~1.83 GHz and the rate from ~2.46 to ~1.83 PFLOP/s).
- * scratch: >= 32 device bytes; tflops / mhz: host floats. */
-int pnr_probe_mfma_peak(int random_operands, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host,
-                        void* stream);
-/* What HBM delivers for k_composite's own access pattern with no arithmetic (bench only; synchronises): a pure read of the
- * channel-major raw image, per wave the 8 channel rows of a batch of one ray, 8 loads in flight.  scratch: >= 1 KiB. */
-int pnr_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,
-                       void* scratch, float* gbs_out_host, void* stream);
+/* ---- diagnostics.  Measurement helpers (hipEvent timing, MFMA / HBM ceilings of the device) live in libpnr_bench.so
+ * (include/pnr_bench.h), not here: every export of this library is stream-ordered and never synchronises.
+ * pnr_mlp_set_clock_probe: the fused MLP kernels launched by THIS thread afterwards write {shader cycles, 100 MHz ticks} of
+ * workgroup 0's first wave to two_u64_dev (16 device bytes; their ratio = the mean shader clock during the launch); NULL
+ * switches it off.  A thread-local setter: no device work, no synchronisation. */
+int pnr_mlp_set_clock_probe(void* two_u64_dev);
 /* Time structure of the fused bf16 MLP's weight stream (tests and A/B tools only; the arithmetic, the packed image and
  * the results are identical bit for bit): 0 = lock-step double buffer (k_mlp_fused), 1 = ping-pong (k_mlp_pp) for
  * inference launches [default], 2 = ping-pong for the training forward as well.  Returns the previous value; a negative

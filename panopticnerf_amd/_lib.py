@@ -67,8 +67,6 @@ SIGNATURES = {
     "pnr_mlp_forward_composite_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64, c_int, c_int]),
     "pnr_mlp_forward_composite": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
                                           c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    "pnr_time_mlp_forward_composite_clk": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int, c_f, c_int,
-                                                   c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_composite": (c_int, [c_f, c_i64, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_int, c_int, c_int, c_int,
                               c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "pnr_composite_backward": (c_int, [c_f, c_i64, c_f, c_f, c_f, c_i64, c_int, c_int, c_int,
@@ -88,13 +86,11 @@ SIGNATURES = {
     "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
-    "pnr_time_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64,
-                                     c_int, ctypes.POINTER(ctypes.c_float), c_f]),
-    "pnr_time_mlp_forward_clk": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64,
-                                         c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
-    "pnr_probe_mfma_peak": (c_int, [c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f]),
-    "pnr_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, ctypes.POINTER(ctypes.c_float), c_f]),
     "pnr_mlp_set_variant": (c_int, [c_int]),
+    "pnr_mlp_set_clock_probe": (c_int, [c_f]),
+    "pnr_mlp_forward_tiles": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f]),
+    "pnr_composite_combine": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
+                                      c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
 }
 
 _lib = None

@@ -854,7 +854,15 @@ PNR_EXPORT int pnr_mlp_set_variant(int variant)
     return prev;
 }
 
-static thread_local unsigned long long* g_clk_buf = nullptr;     // set by pnr_time_mlp_forward_clk around its launches
+// diagnostics: where the MLP kernels of this thread's next launches leave {shader cycles, 100 MHz ticks} of workgroup 0's first
+// wave (their ratio = the mean shader clock during the launch); null = off.  A setter, no synchronisation: libpnr_bench.so arms it
+// around the launches it times.
+static thread_local unsigned long long* g_clk_buf = nullptr;
+PNR_EXPORT int pnr_mlp_set_clock_probe(void* two_u64_dev)
+{
+    g_clk_buf = (unsigned long long*)two_u64_dev;
+    return PNR_OK;
+}
 
 static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
                             int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c,
@@ -888,7 +896,6 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     a.clk = g_clk_buf;
-    if (!a.clk) if (const char* e = getenv("PNR_CLK_PTR")) a.clk = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostics (tools/clk_probe.py)
     if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
@@ -974,6 +981,35 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     return desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
 }
 
+// First half of pnr_mlp_forward_composite: the fused MLP launch alone -- per-tile records and per-sample quadruples into `workspace`.
+PNR_EXPORT int pnr_mlp_forward_tiles(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z, int64_t n_rays,
+                                     int n_samples, void* workspace, void* stream)
+{
+    PNR_REQUIRE(n_rays >= 0, "pnr_mlp_forward_tiles: bad size");
+    if (n_rays == 0) return PNR_OK;
+    MlpArgs a;
+    return fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, workspace, stream, a);
+}
+
+// Second half: every ray's maps from the workspace pnr_mlp_forward_tiles filled (same desc, n_rays, n_samples).
+PNR_EXPORT int pnr_composite_combine(const pnr_mlp_desc* desc, const void* workspace, const float* z, int64_t n_rays, int n_samples,
+                                     const int32_t* label_sem, const int32_t* label_inst, int white_bkgd, float* rgb, float* depth,
+                                     float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, void* stream)
+{
+    int rc = pnr_mlp_validate(desc);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 32 && n_samples <= 256 && (n_samples & 31) == 0, "pnr_composite_combine: bad size");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(workspace && z, "pnr_composite_combine: null pointer");
+    PNR_REQUIRE((!fix_sem || label_sem) && (!fix_inst || label_inst), "pnr_composite_combine: fix_* outputs need their labels");
+    const int rf = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
+    const int64_t tiles = (n_rays * n_samples + 255) / 256 * 8;
+    const float* rec = (const float*)workspace;
+    return pnr_composite_combine_launch(rec, rf, (const float4*)(rec + tiles * rf), z, fix_sem ? label_sem : nullptr,
+                                        fix_inst ? label_inst : nullptr, n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd,
+                                        rgb, depth, acc, weights, sem, inst, fix_sem, fix_inst, (hipStream_t)stream);
+}
+
 // a5 + a6 fused (inference, bf16, logits compositing, N % 32 == 0): the maps of every ray without the raw image round trip.
 // label_sem / label_inst (R*N int32, -1 = none) and their fix_* outputs are optional; any output may be null.
 PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
@@ -990,40 +1026,6 @@ PNR_EXPORT int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* p
     return pnr_composite_combine_launch(a.rec, a.rec_floats, a.ps, z, fix_sem ? label_sem : nullptr, fix_inst ? label_inst : nullptr,
                                         n_rays, n_samples, desc->n_sem, desc->n_inst, white_bkgd, rgb, depth, acc, weights, sem, inst,
                                         fix_sem, fix_inst, (hipStream_t)stream);
-}
-
-// bench only: mean ms per FUSED MLP launch (the kernel the inference step runs; the combine kernel is not included) and the
-// mean shader clock during the last one (scratch: >= 16 device bytes)
-PNR_EXPORT int pnr_time_mlp_forward_composite_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                                  int64_t n_rays, int n_samples, const int32_t* label_sem, const int32_t* label_inst,
-                                                  int want_weights, void* workspace, int iters, void* scratch, float* ms_out_host,
-                                                  float* mhz_out_host, void* stream)
-{
-    PNR_REQUIRE(iters >= 1 && ms_out_host && mhz_out_host && scratch && n_rays >= 1, "pnr_time_mlp_forward_composite_clk: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    PNR_HIP(hipEventCreate(&e0));
-    PNR_HIP(hipEventCreate(&e1));
-    g_clk_buf = (unsigned long long*)scratch;
-    PNR_HIP(hipEventRecord(e0, st));
-    int rc = PNR_OK;
-    for (int i = 0; i < iters && rc == PNR_OK; ++i) {
-        MlpArgs a;
-        rc = fused_mlp_launch(desc, packed, rays, z, n_rays, n_samples, workspace, stream, a);
-    }
-    g_clk_buf = nullptr;
-    if (rc != PNR_OK) return rc;
-    PNR_HIP(hipEventRecord(e1, st));
-    PNR_HIP(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *ms_out_host = ms / (float)iters;
-    unsigned long long h[2] = {0, 1};
-    PNR_HIP(hipMemcpy(h, scratch, sizeof(h), hipMemcpyDeviceToHost));
-    *mhz_out_host = h[1] ? (float)(100.0 * (double)h[0] / (double)h[1]) : 0.0f;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return PNR_OK;
 }
 
 PNR_EXPORT int pnr_mlp_forward_train(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
@@ -1044,51 +1046,5 @@ PNR_EXPORT int pnr_mlp_train_layout(const pnr_mlp_desc* desc, int64_t n_samples,
     pnr_train_layout(*desc, n_samples, a, d);
     memcpy(acts_off_host, a, sizeof(int64_t) * (size_t)(desc->D + 7));
     memcpy(dys_off_host, d, sizeof(int64_t) * (size_t)(desc->D + 8));
-    return PNR_OK;
-}
-
-PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                    int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
-                                    int64_t raw_stride_c, int iters, float* ms_out_host, void* stream);
-
-// pnr_time_mlp_forward plus the mean shader clock DURING the last launch (scratch: >= 16 device bytes)
-PNR_EXPORT int pnr_time_mlp_forward_clk(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                        int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
-                                        int64_t raw_stride_c, int iters, void* scratch, float* ms_out_host,
-                                        float* mhz_out_host, void* stream)
-{
-    PNR_REQUIRE(scratch && mhz_out_host, "pnr_time_mlp_forward_clk: bad arguments");
-    g_clk_buf = (unsigned long long*)scratch;
-    const int rc = pnr_time_mlp_forward(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, iters,
-                                        ms_out_host, stream);
-    g_clk_buf = nullptr;
-    if (rc != PNR_OK) return rc;
-    unsigned long long h[2] = {0, 1};
-    PNR_HIP(hipMemcpy(h, scratch, sizeof(h), hipMemcpyDeviceToHost));
-    *mhz_out_host = h[1] ? (float)(100.0 * (double)h[0] / (double)h[1]) : 0.0f;
-    return PNR_OK;
-}
-
-PNR_EXPORT int pnr_time_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
-                                    int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
-                                    int64_t raw_stride_c, int iters, float* ms_out_host, void* stream)
-{
-    PNR_REQUIRE(iters >= 1 && ms_out_host, "pnr_time_mlp_forward: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    PNR_HIP(hipEventCreate(&e0));
-    PNR_HIP(hipEventCreate(&e1));
-    PNR_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) {
-        int rc = pnr_mlp_forward(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, stream);
-        if (rc != PNR_OK) return rc;
-    }
-    PNR_HIP(hipEventRecord(e1, st));
-    PNR_HIP(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *ms_out_host = ms / (float)iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return PNR_OK;
 }

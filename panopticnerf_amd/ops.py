@@ -306,74 +306,11 @@ def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
     return raw
 
 
-@_on_device
-def time_mlp_forward(desc, packed, rays, z, raw, iters):
-    """Mean ms per launch measured with hipEvents on the launch stream (bench only)."""
-    R, N = z.shape
-    ms = ctypes.c_float(0.0)
-    _lib.check(_lib.load().pnr_time_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1,
-                                                _chk_raw(raw, n_channels(desc), R * N), int(iters), ctypes.byref(ms), _stream()),
-               "pnr_time_mlp_forward")
-    return float(ms.value)
-
-
-@_on_device
-def time_mlp_forward_clk(desc, packed, rays, z, raw, iters):
-    """(mean ms per launch, mean shader MHz during the last launch) -- bench only."""
-    R, N = z.shape
-    ms, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
-    scratch = torch.zeros(4, device=z.device, dtype=torch.int64)
-    _lib.check(_lib.load().pnr_time_mlp_forward_clk(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), 1,
-                                                    _chk_raw(raw, n_channels(desc), R * N), int(iters), _p(scratch),
-                                                    ctypes.byref(ms), ctypes.byref(mhz), _stream()), "pnr_time_mlp_forward_clk")
-    return float(ms.value), float(mhz.value)
-
-
-@_on_device
-def time_mlp_forward_composite_clk(desc, packed, rays, z, label_sem=None, label_inst=None, want_weights=False, iters=5):
-    """(mean ms per FUSED MLP launch -- pnr_mlp_forward_composite without its combine kernel --, mean shader MHz) -- bench only."""
-    rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
-    label_sem = _chk(label_sem, "label_sem", torch.int32)
-    label_inst = _chk(label_inst, "label_inst", torch.int32)
-    R, N = z.shape
-    lib = _lib.load()
-    nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, int(bool(want_weights)))
-    ws = torch.empty(int(nbytes), device=z.device, dtype=torch.uint8)
-    ms, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
-    scratch = torch.zeros(4, device=z.device, dtype=torch.int64)
-    _lib.check(lib.pnr_time_mlp_forward_composite_clk(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(label_sem), _p(label_inst),
-                                                      int(bool(want_weights)), _p(ws), int(iters), _p(scratch), ctypes.byref(ms),
-                                                      ctypes.byref(mhz), _stream()), "pnr_time_mlp_forward_composite_clk")
-    return float(ms.value), float(mhz.value)
-
-
 def mlp_variant(variant=None):
     """Which form of the fused bf16 MLP pnr_mlp_forward launches: 0 lock-step (k_mlp_fused), 1 ping-pong (k_mlp_pp) for
     inference launches (default), 2 ping-pong for the training forward as well.  Returns the setting in force BEFORE the
     call; variant=None only queries."""
     return int(_lib.load().pnr_mlp_set_variant(-1 if variant is None else int(variant)))
-
-
-def probe_mfma_peak(random_operands, iters=20000, device=None):
-    """(TFLOP/s, shader MHz) a register-only bf16 MFMA loop sustains on this device (pnr_probe_mfma_peak) -- bench only."""
-    dev = torch.device(device if device is not None else "cuda")
-    tf, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
-    scratch = torch.zeros(4, device=dev, dtype=torch.int64)
-    with torch.cuda.device(dev):
-        _lib.check(_lib.load().pnr_probe_mfma_peak(int(bool(random_operands)), int(iters), _p(scratch), ctypes.byref(tf),
-                                                   ctypes.byref(mhz), _stream()), "pnr_probe_mfma_peak")
-    return float(tf.value), float(mhz.value)
-
-
-@_on_device
-def probe_raw_read(raw, n_rays, n_samples, iters=5):
-    """GB/s of a pure read of the channel-major raw image in k_composite's access order (pnr_probe_raw_read) -- bench only."""
-    gbs = ctypes.c_float(0.0)
-    scratch = torch.zeros(256, device=raw.device, dtype=torch.float32)
-    _lib.check(_lib.load().pnr_probe_raw_read(_p(raw), _chk_raw(raw, raw.shape[0], n_rays * n_samples), int(n_rays), int(n_samples),
-                                              int(raw.shape[0]), int(iters), _p(scratch), ctypes.byref(gbs), _stream()),
-               "pnr_probe_raw_read")
-    return float(gbs.value)
 
 
 @_on_device

@@ -228,3 +228,60 @@ def test_reference_checkpoint_key_map():
         dst.load_reference_state_dict(bad)
     rep = dst.load_reference_state_dict({k: v for k, v in sd.items() if "fine." not in k}, strict=False)
     assert rep["missing"] and all(m.startswith("nerf_1.") for m in rep["missing"])
+
+
+# ----------------------------------------------------------------------------- bench.py launch contract
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def _bench_line(cmd, timeout=300):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert cp.returncode == 0 and len(lines) == 1, (cp.returncode, cp.stdout[-800:], cp.stderr[-800:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("how", ["plain", "torchrun"])
+def test_bench_starts_its_own_ranks_and_reports_the_process_group(how):
+    """`python bench.py --gpus 2` started as a PLAIN process (no WORLD_SIZE: how the driver starts the N = 1 run) must bring up
+    its own 2 ranks instead of dying on an assertion, and rank 0 must print exactly ONE JSON line; under
+    `python -m torch.distributed.run` it must join the ranks it was given.  Run with --fake-render (gloo on CPU, a stub in
+    place of the renderer): this checks the launch / sharding / collective / JSON plumbing, not a measurement.  The line
+    carries machine-checkable proof of the group (`rccl`: backend, world size, one device per rank, a summed all-reduce) and
+    BOTH scaling forms."""
+    import socket
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--fake-render", "--cpu-seconds", "0", "--train-steps", "0"]
+    if how == "plain":
+        line = _bench_line([os.path.join(ROOT, "bench.py")] + args)
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        line = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args)
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["data"].startswith("fake") and line["higher_is_better"] is True and line["unit"] == "Msamples/s"
+    r = line["rccl"]
+    assert r["backend"] == "gloo" and r["world_size"] == 2 and len(r["devices"]) == 2 and r["allreduce_sum_ok"] is True
+    assert r["allreduce_ms"] > 0 and r["allreduce_bytes"] > 4_000_000
+    m = line["scaling_modes"]
+    assert set(m) == {"weak", "strong"} and m["weak"]["frames_per_step"] == 2 and m["strong"]["frames_per_step"] == 1
+    assert line["value"] == m["weak"]["value"] and line["config"]["frames_per_step"] == 2 and line["config"]["keep_weights"] is False
+    # value = whole-job samples / time: rays x 256 MLP samples x frames x steps
+    n = line["config"]["rays_per_frame"] * line["config"]["mlp_samples_per_ray"]
+    assert abs(m["weak"]["value"] - n * 2 / (m["weak"]["ms_per_step"] * 1e-3) / 1e6) <= 0.02 * m["weak"]["value"]
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fake-render", "--cpu-seconds", "0"],
+                        capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert cp.returncode != 0 and "--gpus 2" in cp.stderr + cp.stdout

@@ -7,8 +7,8 @@ import torch
 from types import SimpleNamespace as NS
 dev = torch.device("cuda:0")
 clk = torch.zeros(2, dtype=torch.int64, device=dev)
-os.environ["PNR_CLK_PTR"] = str(clk.data_ptr())
-from panopticnerf_amd import make_network, ops, synthetic
+from panopticnerf_amd import _lib, make_network, ops, synthetic
+_lib.load().pnr_mlp_set_clock_probe(clk.data_ptr())      # the forward kernels of this thread stamp their clock here
 net = make_network(NS(N_samples=64, N_importance=128, num_classes=45, num_instances=32, precision="bf16")).to(dev).train()
 R, N = 4096, 192
 rays = synthetic.camera_rays()[::129][:R].contiguous().to(dev)

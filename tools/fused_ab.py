@@ -6,7 +6,7 @@ CHILD = r'''
 import os, sys, torch
 sys.path.insert(0, %r)
 from types import SimpleNamespace as NS
-from panopticnerf_amd import make_network, ops, synthetic
+from panopticnerf_amd import benchlib, make_network, ops, synthetic
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = make_network(NS(N_importance=128, num_classes=45, num_instances=32)).eval()
@@ -18,8 +18,8 @@ desc, img = net.packed(1, dev, fused=os.environ.get('PNR_PLAN', '1') != '0')
 box, ids = (t.to(dev) for t in synthetic.random_boxes(64, 45, 32))
 h = ops.bbox_hits(rays, box, 8)
 ls, li = ops.sample_labels(z, h[0], h[1], h[2], ids)
-ops.time_mlp_forward_composite_clk(desc, img, rays, z, ls, li, False, 2)
-r = [ops.time_mlp_forward_composite_clk(desc, img, rays, z, ls, li, False, 5) for _ in range(3)]
+benchlib.time_mlp_forward_tiles(desc, img, rays, z, 2)
+r = [benchlib.time_mlp_forward_tiles(desc, img, rays, z, 5) for _ in range(3)]
 ms, mhz = min(r)
 out = ops.mlp_forward_composite(desc, img, rays, z, ls, li, False, True)
 torch.cuda.synchronize()

@@ -11,7 +11,7 @@ import sys, torch
 sys.path.insert(0, %r)
 import bench
 from types import SimpleNamespace as NS
-from panopticnerf_amd import make_network, ops, synthetic
+from panopticnerf_amd import benchlib, make_network, ops, synthetic
 from oracle import torch_oracle as to
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -23,8 +23,8 @@ rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
 desc, img = net.packed(1, dev)
 raw = ops.alloc_raw(81, 65536 * 192, dev)
-ops.time_mlp_forward(desc, img, rays, z, raw, 2)
-ms = min(ops.time_mlp_forward(desc, img, rays, z, raw, 5) for _ in range(3))
+benchlib.time_mlp_forward(desc, img, rays, z, raw, 2)
+ms = min(benchlib.time_mlp_forward(desc, img, rays, z, raw, 5)[0] for _ in range(3))
 fl = 65536 * 192 * bench.mlp_flops_per_sample()
 # correctness spot check against the bf16-emulating oracle on 24 rays spread over the launch
 idx = torch.arange(0, 65536, 2731)

@@ -41,7 +41,7 @@ for kind in ("mlp-written", "random", "mlp-written"):
     ms = ctypes.c_float(0.0)
     for pd in pads:
         if kind == "random": bufs[pd].normal_()
-        else: _lib.check(lib.pnr_time_mlp_forward(ctypes.byref(desc), p(img), p(rays), p(z), R, N, p(bufs[pd]), 1, S + pd, 1, ctypes.byref(ms), st), "mlp")
+        else: _lib.check(lib.pnr_mlp_forward(ctypes.byref(desc), p(img), p(rays), p(z), R, N, p(bufs[pd]), 1, S + pd, st), "mlp")
     torch.cuda.synchronize()
     res = {pd: [] for pd in pads}
     for rep in range(3):

@@ -21,7 +21,7 @@ try:      # kernels that did not run in these passes keep their last recorded en
     out = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
 except (OSError, ValueError):
     out = {}
-for key, pat in (("k_mlp_fused", "%k_mlp_%"), ("k_composite", "%k_composite<true, 64%")):
+for key, pat in (("k_mlp_pp_fused", "%k_mlp_pp%"), ("k_composite", "%k_composite<true, 64%")):
     f, w = biggest(fetch_db, "FETCH_SIZE", pat), biggest(write_db, "WRITE_SIZE", pat)
     if f is None or w is None:
         continue
