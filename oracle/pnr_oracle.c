@@ -11,12 +11,18 @@
  * north_star (render_rays, sample_pdf, raw2outputs, Embedder) denote.
  *
  * Why C and a fixed op order: BASELINE.json asks for bit-exact sample indices and
- * ray-bbox hits.  searchsorted flips at bin edges when the CDF differs by one ulp, and
- * torch's own CPU reductions (sum / cumsum / linspace) change association order with the
- * host's SIMD width.  This file therefore pins ONE order -- strictly sequential fp32,
- * one rounding per operation, no FMA contraction (build with -ffp-contract=off) -- which
- * the HIP kernels reproduce instruction for instruction.  The vectorised torch
- * restatement (oracle/torch_oracle.py) is compared to this file within tolerance.
+ * ray-bbox hits.  searchsorted flips at bin edges when the CDF differs by one ulp, so the
+ * order of every fp32 operation has to be pinned.  Since round 3 the order pinned here is
+ * TORCH'S OWN, as its CPU kernels (torch 2.10, this container) evaluate the reference's
+ * expressions -- restated from measurements against torch, bit for bit
+ * (tests/test_oracle.py::test_c_oracle_is_torch_as_written):
+ *   torch.linspace(0, 1, N)   step = 1/(N-1);  t_i = step*i for i < N/2, else 1 - step*(N-1-i) with ONE rounding (fma)
+ *   torch.sum(x, -1)          8-lane vector partial sums, 4 of them interleaved (pnro_torch_sum below)
+ *   torch.cumsum(x, -1)       running sum in DOUBLE, every output rounded to fp32
+ * everything else is elementwise: one rounding per operation, no FMA contraction (build with
+ * -ffp-contract=off).  The HIP kernels reproduce this file instruction for instruction; the
+ * vectorised torch restatement (oracle/torch_oracle.py) IS torch as written and must agree with
+ * this file exactly on z, sample indices, z_samples and z_fine.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC).
  */
@@ -51,9 +57,44 @@ PNRO_API void pnro_gen_rays(const float* intr, const float* c2w, int width, int 
     }
 }
 
+/* torch.linspace(0, 1, steps = N)[i], fp32, as ATen's CPU kernel computes it (RangeFactories: two-sided, the upper half from
+ * the end point; the product is not rounded separately there).  Measured bit-exact against torch for N = 7 .. 192. */
+static inline float pnro_linspace01(int i, int N)
+{
+    if (N <= 1) return 0.0f;
+    const float step = 1.0f / (float)(N - 1);
+    if (i < N / 2) return step * (float)i;
+    return fmaf(-step, (float)(N - 1 - i), 1.0f);
+}
+
+/* torch.sum over a contiguous fp32 row of n >= 8 elements, as ATen's CPU reduction orders it: the row is cut into vectors of
+ * 8 lanes; vectors 0..3 (mod 4) accumulate into four partial vectors, leftover vectors into partial 0; partials 1..3 are
+ * added to partial 0; the scalar tail is summed sequentially from 0; finally the 8 lanes of partial 0 are added to that in
+ * lane order.  Measured bit-exact against torch.sum for n = 30 .. 200 (tests); rows shorter than one vector: sequential. */
+static float pnro_torch_sum(const float* x, int n)
+{
+    enum { V = 8, ILP = 4 };
+    const int nv = n / V;
+    float part[ILP][V];
+    for (int k = 0; k < ILP; ++k) for (int l = 0; l < V; ++l) part[k][l] = 0.0f;
+    const int groups = nv / ILP;
+    for (int g = 0; g < groups; ++g)
+        for (int k = 0; k < ILP; ++k)
+            for (int l = 0; l < V; ++l) part[k][l] = part[k][l] + x[(g * ILP + k) * V + l];
+    for (int v = groups * ILP; v < nv; ++v)
+        for (int l = 0; l < V; ++l) part[0][l] = part[0][l] + x[v * V + l];
+    for (int k = 1; k < ILP; ++k)
+        for (int l = 0; l < V; ++l) part[0][l] = part[0][l] + part[k][l];
+    float acc = 0.0f;
+    for (int i = nv * V; i < n; ++i) acc = acc + x[i];
+    for (int l = 0; l < V; ++l) acc = acc + part[0][l];
+    return acc;
+}
+PNRO_API float pnro_torch_sum_row(const float* x, int n) { return pnro_torch_sum(x, n); }
+PNRO_API float pnro_linspace01_at(int i, int N) { return pnro_linspace01(i, N); }
+
 /* ---------------------------------------------------------------- a3: stratified sampler
- * SURVEY 8a row a3.  t_i = i/(N-1) (one correctly rounded division; torch.linspace's
- * bits depend on the host SIMD width, so the strict spec uses the division form);
+ * SURVEY 8a row a3.  t = torch.linspace(0, 1, N) (pnro_linspace01);
  * z = near*(1-t) + far*t, or 1/(1/near*(1-t) + 1/far*t) when lindisp.
  * With t_rand (perturb>0): mids = .5*(z[1:]+z[:-1]); upper = cat(mids, z[-1]);
  * lower = cat(z[0], mids); z = lower + (upper-lower)*t_rand.
@@ -65,7 +106,7 @@ PNRO_API void pnro_stratified(const float* rays, int64_t R, int N, int lindisp,
     for (int64_t r = 0; r < R; ++r) {
         const float nr = rays[r * 8 + 6], fr = rays[r * 8 + 7];
         for (int i = 0; i < N; ++i) {
-            const float t = (N > 1) ? (float)i / (float)(N - 1) : 0.0f;
+            const float t = pnro_linspace01(i, N);
             const float omt = 1.0f - t;
             float z;
             if (!lindisp) {
@@ -203,13 +244,13 @@ PNRO_API void pnro_composite(const float* raw, int64_t stride_s, int64_t stride_
 }
 
 /* ---------------------------------------------------------------- a7: sample_pdf
- * SURVEY 8a row a7.  Strict-order form (all fp32, sequential):
+ * SURVEY 8a row a7.  Torch-as-written order:
  *   bins_k = .5*(z_{k+1}+z_k), k=0..Nc-2            (Nc-1 bins)
  *   w_j = weights_{j+1} + 1e-5,  j=0..Nc-3          (Nc-2 weights)
- *   total = ((w_0 + w_1) + w_2) + ...               (sequential)
+ *   total = torch.sum(w)                            (pnro_torch_sum)
  *   pdf_j = w_j / total
- *   cdf_0 = 0; cdf_{j+1} = cdf_j + pdf_j            (sequential; Nc-1 entries)
- *   u_i = i/(Nf-1) when u==NULL (det) else given
+ *   cdf_0 = 0; cdf_{j+1} = fl32(sum_{i<=j} (double) pdf_i)   (torch.cumsum: running sum in double; Nc-1 entries)
+ *   u = torch.linspace(0, 1, Nf) when u==NULL (det) else given
  *   inds = #{k : cdf_k <= u}  (searchsorted right=True); below=max(inds-1,0);
  *   above=min(inds, Nc-2); denom = cdf[above]-cdf[below]; denom<1e-5 -> 1
  *   t=(u-cdf[below])/denom;  z_s = bins[below] + t*(bins[above]-bins[below])
@@ -220,19 +261,22 @@ PNRO_API void pnro_sample_pdf(const float* z, const float* weights, const float*
     const int nb = Nc - 1, nw = Nc - 2;
     float* bins = (float*)malloc(sizeof(float) * (size_t)nb);
     float* cdf = (float*)malloc(sizeof(float) * (size_t)nb);
+    float* wbuf = (float*)malloc(sizeof(float) * (size_t)(nw > 0 ? nw : 1));
     for (int64_t r = 0; r < R; ++r) {
         const float* zr = z + r * Nc;
         const float* wr = weights + r * Nc;
         for (int k = 0; k < nb; ++k) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
-        float total = 0.0f;
-        for (int j = 0; j < nw; ++j) total = total + (wr[j + 1] + 1e-5f);
+        for (int j = 0; j < nw; ++j) wbuf[j] = wr[j + 1] + 1e-5f;
+        const float total = pnro_torch_sum(wbuf, nw);
         cdf[0] = 0.0f;
+        double run = 0.0;
         for (int j = 0; j < nw; ++j) {
-            const float p = (wr[j + 1] + 1e-5f) / total;
-            cdf[j + 1] = cdf[j] + p;
+            const float p = wbuf[j] / total;
+            run += (double)p;
+            cdf[j + 1] = (float)run;
         }
         for (int i = 0; i < Nf; ++i) {
-            const float uu = u ? u[r * Nf + i] : ((Nf > 1) ? (float)i / (float)(Nf - 1) : 0.0f);
+            const float uu = u ? u[r * Nf + i] : pnro_linspace01(i, Nf);
             int lo = 0, hi = nb; /* upper_bound: first k with cdf[k] > uu */
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
             const int inds = lo;
@@ -247,7 +291,7 @@ PNRO_API void pnro_sample_pdf(const float* z, const float* weights, const float*
             if (inds_out) inds_out[r * Nf + i] = inds;
         }
     }
-    free(bins); free(cdf);
+    free(bins); free(cdf); free(wbuf);
 }
 
 static int cmp_float(const void* a, const void* b)

@@ -1,18 +1,30 @@
 // K1 / K1b / K2 / K5: per-ray sample generation, Embedder, sample_pdf + merge, bbox prior.
 // gfx950 only.  The sampler, sample_pdf and bbox kernels are BIT-EXACT restatements of
 // oracle/pnr_oracle.c (pnro_stratified / pnro_points / pnro_sample_pdf / pnro_bbox_hits /
-// pnro_sample_labels): same fp32 operations in the same order, one rounding each; the file
-// is compiled with -ffp-contract=off and the pragma below so no mul+add pair is fused.
+// pnro_sample_labels), which since round 3 pins TORCH'S OWN op order (linspace two-sided, sum in
+// ATen's vector order, cumsum in double): same operations in the same order, one rounding each; the
+// file is compiled with -ffp-contract=off and the pragma below so no mul+add pair is fused.
 // Reference functions these replace (the reference source
 // is not in the mount, include/pnr.h explains the citation form).
 #include "pnr_common.h"
 
 #pragma clang fp contract(off)
 
+// torch.linspace(0, 1, N)[i] as ATen's CPU kernel computes it (two-sided; the upper half from the end point with one
+// rounding): oracle/pnr_oracle.c::pnro_linspace01, measured bit-exact against torch.  An explicit fmaf -- the file is built
+// with contraction off.
+__device__ __forceinline__ float pnr_linspace01(int i, int N)
+{
+    if (N <= 1) return 0.0f;
+    const float step = 1.0f / (float)(N - 1);
+    if (i < N / 2) return step * (float)i;
+    return fmaf(-step, (float)(N - 1 - i), 1.0f);
+}
+
 // ------------------------------------------------------------------------------- a3
 __device__ __forceinline__ float strat_z(float nr, float fr, int i, int N, int lindisp)
 {
-    const float t = (N > 1) ? ((float)i / (float)(N - 1)) : 0.0f;
+    const float t = pnr_linspace01(i, N);
     const float omt = 1.0f - t;
     if (!lindisp) {
         const float a = nr * omt, b = fr * t;
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
 {
     __shared__ float s_z[PDF_MAXC], s_w[PDF_MAXC], s_pdf[PDF_MAXC], s_cdf[PDF_MAXC], s_bins[PDF_MAXC];
     __shared__ float s_sort[PDF_MAXT], s_out[PDF_MAXT];
-    __shared__ float s_total;
+    __shared__ float s_total, s_part[32];
     const int lane = threadIdx.x;
     const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
     int P = 1;
@@ -134,9 +146,26 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
         }
         __syncthreads();
         for (int k = lane; k < nb; k += 64) s_bins[k] = 0.5f * (s_z[k + 1] + s_z[k]);
+        // total = torch.sum(w) in ATen's order (pnro_torch_sum): 8-lane vectors, four partial vectors interleaved -> lane
+        // 8 k + l owns accumulator (k, l) and adds its elements in ascending order, exactly as the vector code does
+        if (lane < 32) {
+            const int k = lane >> 3, l = lane & 7, nv = nw / 8, groups = nv / 4;
+            float pacc = 0.0f;
+            for (int g = 0; g < groups; ++g) pacc = pacc + (s_w[(g * 4 + k) * 8 + l + 1] + 1e-5f);
+            if (k == 0)
+                for (int v = groups * 4; v < nv; ++v) pacc = pacc + (s_w[v * 8 + l + 1] + 1e-5f);
+            s_part[lane] = pacc;
+        }
+        __syncthreads();
         if (lane == 0) {
+            const int nv = nw / 8;
             float total = 0.0f;
-            for (int j = 0; j < nw; ++j) total = total + (s_w[j + 1] + 1e-5f);
+            for (int j = nv * 8; j < nw; ++j) total = total + (s_w[j + 1] + 1e-5f);          // the scalar tail, from 0
+            for (int l = 0; l < 8; ++l) {
+                float p0 = s_part[l];
+                p0 = p0 + s_part[8 + l]; p0 = p0 + s_part[16 + l]; p0 = p0 + s_part[24 + l];
+                total = total + p0;
+            }
             s_total = total;
         }
         __syncthreads();
@@ -144,16 +173,17 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
         for (int j = lane; j < nw; j += 64) s_pdf[j] = (s_w[j + 1] + 1e-5f) / total;
         __syncthreads();
         if (lane == 0) {
-            float c = 0.0f;
+            // torch.cumsum: the running sum is kept in DOUBLE, every output rounded to fp32
+            double c = 0.0;
             s_cdf[0] = 0.0f;
             for (int j = 0; j < nw; ++j) {
-                c = c + s_pdf[j];
-                s_cdf[j + 1] = c;
+                c += (double)s_pdf[j];
+                s_cdf[j + 1] = (float)c;
             }
         }
         __syncthreads();
         for (int i = lane; i < Nf; i += 64) {
-            const float uu = u ? u[r * Nf + i] : ((Nf > 1) ? ((float)i / (float)(Nf - 1)) : 0.0f);
+            const float uu = u ? u[r * Nf + i] : pnr_linspace01(i, Nf);
             int lo = 0, hi = nb;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;

@@ -3,8 +3,10 @@ of the path.
 
 PARITY UNPINNED: the reference's code branches are not in /root/reference,
 so these vectors come from this repo's own oracle, accepted only where its independent
-restatements agree (strict-order C, vectorised torch fp32, plain-loop numpy float64; see
-tests/test_oracle.py).  When the `panopticnerf` branch is mounted, regenerate them by importing
+restatements agree (torch-order C, vectorised torch fp32, plain-loop numpy float64; see
+tests/test_oracle.py).  The sampler vectors (z, sample indices, z_samples, z_fine) are produced by
+torch ops AS WRITTEN (torch_oracle) -- the reference's arithmetic substrate -- and the C oracle /
+HIP kernels must reproduce them bit for bit.  When the `panopticnerf` branch is mounted, regenerate them by importing
 the real renderer here and keep this script as the record of how.
 
 Run from the repo root:  python tests/golden/make_golden.py
@@ -43,10 +45,14 @@ def main():
 
     g = {"rays": rays, "t_rand": t_rand, "u": u, "box": box, "box_ids": box_ids,
          "dims": np.array([R, Nc, Nf, C, K, M, MH], np.int32)}
-    # a3
-    g["z_det"] = co.stratified(rays, Nc)
-    g["z_lindisp"] = co.stratified(rays, Nc, lindisp=True)
-    g["z_perturb"] = co.stratified(rays, Nc, t_rand=t_rand)
+    # a3 -- FROM TORCH AS WRITTEN (oracle/torch_oracle.py: torch.linspace and elementwise ops on this container's torch CPU);
+    # the C oracle restates torch's op order and must reproduce every bit
+    tr = torch.tensor(rays)
+    g["z_det"] = to.stratified(tr, Nc).numpy()
+    g["z_lindisp"] = to.stratified(tr, Nc, lindisp=True).numpy()
+    g["z_perturb"] = to.stratified(tr, Nc, t_rand=torch.tensor(t_rand)).numpy()
+    assert np.array_equal(g["z_det"], co.stratified(rays, Nc)) and np.array_equal(g["z_lindisp"], co.stratified(rays, Nc, lindisp=True))
+    assert np.array_equal(g["z_perturb"], co.stratified(rays, Nc, t_rand=t_rand))
     g["pts"] = co.points(rays, g["z_perturb"])
     # a4
     x = g["pts"].reshape(-1, 3)[:257]
@@ -71,9 +77,13 @@ def main():
     # a7
     w = g["comp0_weights"]
     for tag, uu in (("det", None), ("rand", u)):
+        # sample indices, z_samples and the sorted union FROM TORCH AS WRITTEN (sum, cumsum, linspace, searchsorted, sort)
+        zf_t, zs_t, i_t = to.importance_z(torch.tensor(g["z_perturb"]), torch.tensor(w), Nf, None if uu is None else torch.tensor(uu))
+        g[f"pdf_{tag}_zs"], g[f"pdf_{tag}_inds"] = zs_t.numpy(), i_t.numpy().astype(np.int32)
+        g[f"pdf_{tag}_zfine"] = zf_t.numpy()
         zs, inds = co.sample_pdf(g["z_perturb"], w, Nf, uu)
-        g[f"pdf_{tag}_zs"], g[f"pdf_{tag}_inds"] = zs, inds
-        g[f"pdf_{tag}_zfine"] = co.merge_sorted(g["z_perturb"], zs)
+        assert np.array_equal(inds, g[f"pdf_{tag}_inds"]) and np.array_equal(zs, g[f"pdf_{tag}_zs"])
+        assert np.array_equal(co.merge_sorted(g["z_perturb"], zs), g[f"pdf_{tag}_zfine"])
     # a5: small MLP with stored weights; big MLP from seed
     cfg_s = to.mlp_config(D=4, W=128, skips=(1,), n_sem=C, n_inst=K, head_W=64)
     p_s = to.init_params(cfg_s, seed=3)

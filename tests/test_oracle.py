@@ -78,14 +78,78 @@ def test_sample_pdf_restatements():
         zs_c, i_c = co.sample_pdf(z, w, Nf, uu)
         zs_n, i_n = no.sample_pdf(z, w, Nf, uu)
         zf_t, zs_t, i_t = to.importance_z(torch.tensor(z), torch.tensor(w), Nf, None if uu is None else torch.tensor(uu))
-        # the det grid's last u == 1.0 sits exactly on cdf[-1] ~ 1 +- 1 ulp: its index legitimately differs
-        # between fp32 orders (the z it maps to does not), hence 0.99 and not 1.0 here
-        assert (i_c == i_n).mean() > 0.99 and (i_c == i_t.numpy()).mean() > 0.99
+        # the float64 plain-loop restatement rounds differently at bin edges (the det grid's last u == 1.0 sits exactly on
+        # cdf[-1] ~ 1 +- 1 ulp): > 0.99 there.  Against torch AS WRITTEN the C oracle is exact: every index, every bit.
+        assert (i_c == i_n).mean() > 0.99
+        assert np.array_equal(i_c, i_t.numpy()) and np.array_equal(zs_c, zs_t.numpy())
         np.testing.assert_allclose(zs_c, zs_n, atol=2e-3)
         np.testing.assert_allclose(zs_c, zs_t.numpy(), atol=2e-3)
         zf_c = co.merge_sorted(z, zs_c)
         assert np.all(np.diff(zf_c, axis=1) >= 0)
         np.testing.assert_allclose(zf_c, zf_t.numpy(), atol=2e-3)
+
+
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (32, 64), (64, 64), (128, 64), (16, 32)])
+def test_c_oracle_is_torch_as_written(Nc, Nf):
+    """BASELINE north_star: "bit-exact sample indices".  The reference's sampler is torch ops (linspace, sum, cumsum,
+    searchsorted, sort); oracle/pnr_oracle.c restates the op ORDER of this container's torch CPU kernels -- two-sided linspace
+    with a fused upper half, ATen's 8-lane / 4-way interleaved sum, cumsum accumulated in double -- and must reproduce torch
+    bit for bit: stratified z (det, perturbed, lindisp), every sample index, z_samples and the sorted union, on peaked, flat,
+    all-zero and noisy weights, with the deterministic grid and with given uniforms.  (The HIP kernels are pinned to the C oracle
+    bit for bit by tests/test_gpu_stages.py, and tests/golden/path_small.npz holds torch's own outputs.)"""
+    rng = np.random.default_rng(Nc * 1000 + Nf)
+    R = 600
+    rays = np.zeros((R, 8), np.float32)
+    rays[:, 3:6] = rng.normal(size=(R, 3))
+    rays[:, 6] = rng.uniform(0.05, 2.0, R)
+    rays[:, 7] = rng.uniform(20.0, 120.0, R)
+    tr = torch.tensor(rays)
+    t_rand = rng.random((R, Nc)).astype(np.float32)
+    z = co.stratified(rays, Nc)
+    assert np.array_equal(z, to.stratified(tr, Nc).numpy())
+    assert np.array_equal(co.stratified(rays, Nc, True), to.stratified(tr, Nc, True).numpy())
+    zp = co.stratified(rays, Nc, False, t_rand)
+    assert np.array_equal(zp, to.stratified(tr, Nc, False, torch.tensor(t_rand)).numpy())
+    w = (np.exp(-0.5 * ((np.arange(Nc)[None] - rng.uniform(2, Nc - 2, (R, 1))) / rng.uniform(0.5, 8, (R, 1))) ** 2)
+         * rng.uniform(0, 1, (R, 1)) + rng.random((R, Nc)) * 1e-3).astype(np.float32)
+    w[:40] = 0.0                      # no density at all: the 1e-5 floor alone
+    w[40:80] = 1.0                    # flat
+    for zz in (z, zp):
+        for uu in (None, rng.random((R, Nf)).astype(np.float32)):
+            zs, inds = co.sample_pdf(zz, w, Nf, uu)
+            zf_t, zs_t, i_t = to.importance_z(torch.tensor(zz), torch.tensor(w), Nf, None if uu is None else torch.tensor(uu))
+            assert np.array_equal(inds, i_t.numpy()), float((inds == i_t.numpy()).mean())
+            assert np.array_equal(zs, zs_t.numpy())
+            assert np.array_equal(co.merge_sorted(zz, zs), zf_t.numpy())
+
+
+def test_torch_op_orders_the_c_oracle_restates():
+    """The three measured facts about torch's CPU kernels that pnro_linspace01 / pnro_torch_sum / the double cumsum encode,
+    checked directly (if a torch upgrade changes one of them this fails before any index does)."""
+    import ctypes
+    lib = co.lib()
+    lib.pnro_linspace01_at.restype = ctypes.c_float
+    lib.pnro_linspace01_at.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.pnro_torch_sum_row.restype = ctypes.c_float
+    lib.pnro_torch_sum_row.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    for N in (7, 32, 63, 64, 100, 128, 192, 256):
+        t = torch.linspace(0.0, 1.0, steps=N).numpy()
+        mine = np.array([lib.pnro_linspace01_at(i, N) for i in range(N)], np.float32)
+        assert np.array_equal(t, mine), N
+    # ... which is NOT i / (N - 1): the round-2 oracle's form differs from torch in up to half of the values by one ulp
+    assert (torch.linspace(0.0, 1.0, steps=64).numpy() != (np.arange(64, dtype=np.float32) / np.float32(63))).sum() > 10
+    rng = np.random.default_rng(0)
+    for n in (30, 62, 64, 126, 200):
+        x = rng.random((200, n)).astype(np.float32)
+        s = torch.sum(torch.tensor(x), -1).numpy()
+        mine = np.array([lib.pnro_torch_sum_row(np.ascontiguousarray(r).ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n) for r in x], np.float32)
+        assert np.array_equal(s, mine), n
+        seq = np.zeros(200, np.float32)
+        for j in range(n):
+            seq = (seq + x[:, j]).astype(np.float32)
+        assert (s != seq).mean() > 0.2            # ... and not a sequential sum
+        cs = torch.cumsum(torch.tensor(x), -1).numpy()
+        assert np.array_equal(cs, np.cumsum(x.astype(np.float64), axis=1).astype(np.float32))       # double running sum
 
 
 def test_sample_pdf_uniform_weights_gives_even_samples():
