@@ -73,11 +73,15 @@ typedef struct pnr_mlp_desc {
     int32_t precision; /* PNR_PREC_* */
     int32_t plan;      /* chunk order of the packed image: 0 = classic (every kernel); 1 = fused-inference order, see
                           pnr_mlp_fused_plan (only pnr_mlp_forward_composite accepts it) */
-    int32_t reserved[6];
+    int32_t head_tap;  /* what the semantic / instance heads read: 0 = the trunk output h (default), 1 = the feature_linear
+                          output (the reference's tap point cannot be checked here, so it is a switch) */
+    int32_t head_depth;/* 0 or 2 = W -> head_W -> n (ReLU between; default), 1 = one Linear W -> n (inference only) */
+    int32_t reserved[4];
 } pnr_mlp_desc;
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
- * pts_w[i]/pts_b[i] for i < D.  Head pointers may be NULL when the head is absent. */
+ * pts_w[i]/pts_b[i] for i < D.  Head pointers may be NULL when the head is absent; with head_depth = 1 a head is the single
+ * Linear sem1_w / inst1_w of shape (n, W) and sem0_* / inst0_* are NULL. */
 typedef struct pnr_mlp_params_host {
     const float* const* pts_w; const float* const* pts_b;
     const float* alpha_w; const float* alpha_b;
@@ -294,6 +298,13 @@ int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t
  * pnr_sample_labels uses min(hit_count, max_hits) entries.  Bit-exact with pnro_bbox_hits. */
 int pnr_bbox_hits(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits,
                   float* hit_t, int32_t* hit_box, int32_t* hit_count, void* stream);
+
+/* Sampling restricted to the bbox prior (cfg.bbox_sampling = "hull"; SURVEY.md 9 item 2 -- whether the reference samples
+ * [near, far] or the hit intervals cannot be checked here, so it is a switch): rays_out = rays with near / far replaced by the
+ * hull [min t_in, max t_out] of the ray's kept intervals (min(hit_count, max_hits) entries of hit_t); rays without a hit are
+ * copied unchanged.  rays_out may not alias rays.  Bit-exact with pnro_restrict_rays. */
+int pnr_restrict_rays(const float* rays, int64_t n_rays, const float* hit_t, const int32_t* hit_count, int max_hits,
+                      float* rays_out, void* stream);
 
 /* box_ids (M,2) int32 = (semantic id, instance id).  label_* (R,N) int32. */
 int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float* hit_t,

@@ -156,6 +156,15 @@ def bbox_hits(rays, box, max_hits):
     return hit_t, hit_box, hit_count
 
 
+def restrict_rays(rays, hit_t, hit_count):
+    rays = _f32(rays).reshape(-1, 8)
+    hit_t = _f32(hit_t)
+    hit_count = _i32(hit_count)
+    out = np.empty_like(rays)
+    lib().pnro_restrict_rays(_fp(rays), ctypes.c_int64(rays.shape[0]), _fp(hit_t), _ip(hit_count), int(hit_t.shape[1]), _fp(out))
+    return out
+
+
 def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     z = _f32(z)
     hit_t = _f32(hit_t)

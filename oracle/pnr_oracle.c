@@ -371,6 +371,24 @@ PNRO_API void pnro_bbox_hits(const float* rays, int64_t R, const float* box, int
     }
 }
 
+/* cfg.bbox_sampling = "hull" (a switch: the reference's choice is not in the mount): near / far of a ray that
+ * hits boxes become the hull [min t_in, max t_out] of its kept intervals; rays without a hit are copied. */
+PNRO_API void pnro_restrict_rays(const float* rays, int64_t R, const float* hit_t, const int32_t* hit_count, int max_hits, float* out)
+{
+    for (int64_t r = 0; r < R; ++r) {
+        memcpy(out + r * 8, rays + r * 8, 8 * sizeof(float));
+        const int cnt = hit_count[r] < max_hits ? hit_count[r] : max_hits;
+        if (cnt <= 0) continue;
+        float lo = hit_t[(r * max_hits) * 2], hi = hit_t[(r * max_hits) * 2 + 1];
+        for (int h = 1; h < cnt; ++h) {
+            lo = fminf(lo, hit_t[(r * max_hits + h) * 2]);
+            hi = fmaxf(hi, hit_t[(r * max_hits + h) * 2 + 1]);
+        }
+        out[r * 8 + 6] = lo;
+        out[r * 8 + 7] = hi;
+    }
+}
+
 /* Per-sample fixed labels: among the ray's hits with t_in <= z <= t_out take the smallest
  * t_in (ties: first in list); label = box_ids of that box, else -1.  Outputs (R,N) int32. */
 PNRO_API void pnro_sample_labels(const float* z, int64_t R, int N, const float* hit_t,

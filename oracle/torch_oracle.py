@@ -23,9 +23,11 @@ import torch
 import torch.nn.functional as F
 
 
-def mlp_config(D=8, W=256, skips=(4,), xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=128):
+def mlp_config(D=8, W=256, skips=(4,), xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=128, head_tap="trunk", head_depth=2):
+    """head_tap / head_depth: SURVEY.md 9 item 4 as switches -- the heads read the trunk output h ('trunk') or the
+    feature_linear output ('feature'); they are W -> head_W -> n (2) or one Linear W -> n (1)."""
     return SimpleNamespace(D=D, W=W, skips=tuple(skips), xyz_L=xyz_L, dir_L=dir_L,
-                           n_sem=n_sem, n_inst=n_inst, head_W=head_W)
+                           n_sem=n_sem, n_inst=n_inst, head_W=head_W, head_tap=head_tap, head_depth=int(head_depth))
 
 
 def init_params(cfg, seed=0, sigma_bias=None):
@@ -46,12 +48,15 @@ def init_params(cfg, seed=0, sigma_bias=None):
     lin("feature_linear", cfg.W, cfg.W)
     lin("views_linears.0", cfg.W + ed, cfg.W // 2)
     lin("rgb_linear", cfg.W // 2, 3)
-    if cfg.n_sem:
-        lin("semantic_linears.0", cfg.W, cfg.head_W)
-        lin("semantic_linears.1", cfg.head_W, cfg.n_sem)
-    if cfg.n_inst:
-        lin("instance_linears.0", cfg.W, cfg.head_W)
-        lin("instance_linears.1", cfg.head_W, cfg.n_inst)
+    deep = getattr(cfg, "head_depth", 2) == 2
+    for name, n in (("semantic_linears", cfg.n_sem), ("instance_linears", cfg.n_inst)):
+        if not n:
+            continue
+        if deep:
+            lin(name + ".0", cfg.W, cfg.head_W)
+            lin(name + ".1", cfg.head_W, n)
+        else:
+            lin(name + ".0", cfg.W, n)
     if sigma_bias is not None:
         p["alpha_linear.bias"] = torch.full((1,), float(sigma_bias))
     return p
@@ -115,10 +120,11 @@ def mlp_forward(p, cfg, pts, viewdirs, emulate_bf16=False):
     g = F.relu(lin("views_linears.0", torch.cat([feat, ed], -1)))   # (!) order: [feature, gamma(d)]
     rgb = lin("rgb_linear", g)
     outs = [rgb, sigma]
-    if cfg.n_sem:
-        outs.append(lin("semantic_linears.1", F.relu(lin("semantic_linears.0", h))))
-    if cfg.n_inst:
-        outs.append(lin("instance_linears.1", F.relu(lin("instance_linears.0", h))))
+    tap = feat if getattr(cfg, "head_tap", "trunk") == "feature" else h
+    deep = getattr(cfg, "head_depth", 2) == 2
+    for name, n in (("semantic_linears", cfg.n_sem), ("instance_linears", cfg.n_inst)):
+        if n:
+            outs.append(lin(name + ".1", F.relu(lin(name + ".0", tap))) if deep else lin(name + ".0", tap))
     return torch.cat(outs, -1)
 
 
@@ -235,6 +241,20 @@ def bbox_hits(rays, box, max_hits):
     return hit_t, hit_box, hit.sum(1).int()
 
 
+def restrict_rays(rays, hit_t, hit_count):
+    """cfg.bbox_sampling = "hull" (a switch): near / far of a ray that hits boxes -> the hull of its
+    kept intervals [min t_in, max t_out]; rays without a hit are unchanged."""
+    mh = hit_t.shape[1]
+    valid = torch.arange(mh)[None, :] < hit_count.clamp(max=mh)[:, None]
+    lo = torch.where(valid, hit_t[..., 0], torch.full_like(hit_t[..., 0], float("inf"))).min(-1).values
+    hi = torch.where(valid, hit_t[..., 1], torch.full_like(hit_t[..., 1], float("-inf"))).max(-1).values
+    has = hit_count > 0
+    out = rays.clone()
+    out[:, 6] = torch.where(has, lo, rays[:, 6])
+    out[:, 7] = torch.where(has, hi, rays[:, 7])
+    return out
+
+
 def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
     R, N = z.shape
     mh = hit_box.shape[1]
@@ -254,14 +274,15 @@ def sample_labels(z, hit_t, hit_box, hit_count, box_ids):
 # ------------------------------------------------------------------ a2 render_rays
 def render_rays(params, cfg, rays, n_samples, n_importance=0, lindisp=False, t_rand=None, u=None,
                 noise0=None, noise1=None, box=None, box_ids=None, max_hits=8, sem_mode=0,
-                white_bkgd=False, emulate_bf16=False, keep_raw=False):
+                white_bkgd=False, emulate_bf16=False, keep_raw=False, bbox_sampling="none"):
     """params: {"coarse": dict, "fine": dict} (fine used when n_importance>0).
     Returns dict with *_0 (coarse) and *_1 (fine) maps."""
     ret = {}
     hits = None
     if box is not None:
         hits = bbox_hits(rays, box, max_hits)
-    z = stratified(rays, n_samples, lindisp, t_rand)
+    rays_s = restrict_rays(rays, hits[0], hits[2]) if (hits is not None and bbox_sampling == "hull") else rays
+    z = stratified(rays_s, n_samples, lindisp, t_rand)
 
     def level(tag, prm, zz, noise):
         raw = run_network(prm, cfg, rays, zz, emulate_bf16)

@@ -26,7 +26,8 @@ class MlpDesc(ctypes.Structure):
     _fields_ = [("D", ctypes.c_int32), ("W", ctypes.c_int32), ("skip", ctypes.c_int32),
                 ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
                 ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
-                ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("head_tap", ctypes.c_int32),
+                ("head_depth", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -85,6 +86,7 @@ SIGNATURES = {
     "pnr_confusion": (c_int, [c_f, c_f, c_i64, c_int, c_f, c_f]),
     "pnr_sample_pdf": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_restrict_rays": (c_int, [c_f, c_i64, c_f, c_f, c_int, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
     "pnr_mlp_set_variant": (c_int, [c_int]),
     "pnr_mlp_set_clock_probe": (c_int, [c_f]),

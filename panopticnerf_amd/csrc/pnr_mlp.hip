@@ -377,7 +377,18 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
         layer_regs<PREC, TILES, CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         layer_out<PREC, TILES, CTX, GR, HR>(c, g, cur, 4, 0, samp);
-        // panoptic heads, after the appearance branch (plan order; h = cur stays live to the end)
+        // panoptic heads, after the appearance branch (plan order).  They read the trunk output h = cur, or -- head_tap 1 -- the
+        // feature_linear output: h is dead once sigma is out, so the feature registers simply take its place.
+        if (a.head_tap && (a.n_sem || a.n_inst)) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int i = 0; i < HR; ++i) cur[t][i] = nxt[t][i];
+        }
+        if (a.head_depth == 1) {          // one Linear per head (inference only)
+            if (a.n_sem) layer_out<PREC, TILES, CTX, HR, 0>(c, cur, dummy, a.n_sem, 4, samp);
+            if (a.n_inst) layer_out<PREC, TILES, CTX, HR, 0>(c, cur, dummy, a.n_inst, 4 + a.n_sem, samp);
+        } else {
         if (a.n_sem) {
             uint32_t sh[TILES][GR];
             layer_regs<PREC, TILES, CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(4 + a.D), srow);
@@ -389,6 +400,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
             layer_regs<PREC, TILES, CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, cur, dummy, sh, sv(5 + a.D), srow);
             gv(5 + a.D, sh);
             layer_out<PREC, TILES, CTX, GR, 0>(c, sh, dummy, a.n_inst, 4 + a.n_sem, samp);
+        }
         }
 #if PNR_TRACE
         ++c.titer;
@@ -743,6 +755,12 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
         gv(3 + a.D, g);
         pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst);
+        // the heads read the trunk output h = cur, or -- head_tap 1 -- the feature_linear output: h is dead once sigma is out, so
+        // the feature registers take its place (64 moves per sample group, only in that mode)
+        if (a.head_tap && (a.n_sem || a.n_inst)) {
+#pragma unroll
+            for (int i = 0; i < HR; ++i) cur[i] = nxt[i];
+        }
         if constexpr (TAIL > 0) {
             // plan 1: both head hidden layers, then every logit block in one chunk
             constexpr int NBS = TAIL >> 2, NBI = TAIL & 3;
@@ -754,6 +772,9 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
                 for (int i = 0; i < GR; ++i) shi[i] = 0;
             }
             pp_logits_merged<NBS, NBI>(c, A, shs, shi, fst);
+        } else if (a.head_depth == 1) {     // one Linear per head (inference only)
+            if (a.n_sem) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_sem, 4, samp, &fst);
+            if (a.n_inst) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_inst, 4 + a.n_sem, samp, &fst);
         } else {
         // panoptic heads, after the appearance branch (plan order)
         if (a.n_sem) {
@@ -879,6 +900,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
                 "pnr_mlp_forward: rays / packed / acts must be 16-byte aligned");
     PNR_REQUIRE(!acts || desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_train: the training path is bf16 only");
     PNR_REQUIRE(desc->plan == 0, "pnr_mlp_forward: plan=%d images are for pnr_mlp_forward_composite only", desc->plan);
+    PNR_REQUIRE(!acts || desc->head_depth != 1, "pnr_mlp_forward_train: head_depth = 1 is inference only");
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     MlpArgs a;
@@ -891,6 +913,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     pnr_set_div_magic(n_samples, a.n_magic, a.n_shift);
     a.raw = raw; a.ss = raw_stride_s; a.sc = raw_stride_c;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.head_tap = desc->head_tap; a.head_depth = desc->head_depth == 1 ? 1 : 2;
     a.acts = (uint16_t*)acts;
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
@@ -959,6 +982,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     a.rays = rays; a.z = z; a.S = (int)(n_rays * n_samples); a.N = n_samples;
     pnr_set_div_magic(n_samples, a.n_magic, a.n_shift);
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.head_tap = desc->head_tap; a.head_depth = desc->head_depth == 1 ? 1 : 2;
     a.rec_floats = pnr_fuse_record_floats(desc->n_sem, desc->n_inst);
     a.rec = (float*)workspace;
     const int64_t tiles = ((int64_t)a.S + 255) / 256 * 8;

@@ -2,7 +2,7 @@
 // Mirrors the forward kernel (pnr_mlp.hip): every backward layer is  dX^T = W^T * dY^T  with the
 // transposed weights streamed through LDS as the MFMA A operand and the gradients register-resident
 // as the B operand, so gradients flow from d_raw back to layer 1 without leaving the register file.
-//   dY_l = dX_{l+1} (.) [X_{l+1} > 0]   (ReLU mask from the activations the forward saved, bf16)
+//   dY_l = dX_{l+1} (.) [X_{l+1} > 0]   (ReLU mask from the GATE BITS the forward saved: one bit per ReLU output)
 // Every dY_l is also stored slot-ordered (MlpArgs::dys) for the weight-gradient GEMMs
 // dW_l = dY_l^T X_l, which are plain (S-reduction) GEMMs done outside this kernel.
 // Execution order / k-segments: pnr_mlp_plan.h (pnr_build_bwd_plan).  No gradient is needed for
@@ -139,6 +139,36 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
         // d g = W_rgb^T d rgb ; gate by g ; -> dY_views
         uint32_t dyv[TILES][GR];
         layer_bwd<TILES, CTX, 8, HFB, GR, 0>(c, drs, dyv, acts + a.gate_off[3 + D], dys + a.dys_off[0], samp, srow);
+        uint32_t dy[TILES][HR], dn[TILES][HR];
+        if (a.head_tap) {
+            // the heads read the FEATURE: their gradients join the views gradient in d F (plan order DG | DSHS | DSHI | DF | DH)
+            constexpr int C3 = 3 * GR;              // [dY_views | dY_sem0 | dY_inst0]
+            uint32_t c3[TILES][C3];
+#pragma unroll
+            for (int i = 0; i < GR; ++i) { c3[0][i] = dyv[0][i]; c3[0][GR + i] = 0; c3[0][2 * GR + i] = 0; }
+            if (a.n_sem) {
+                uint32_t ds[TILES][OBR];
+                load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
+#pragma unroll
+                for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &ds[0][b * 8]);
+                layer_bwd<TILES, CTX, OBR, HFB, C3, GR>(c, ds, c3, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp, srow);
+            }
+            if (a.n_inst) {
+                uint32_t di[TILES][OBR];
+                load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
+#pragma unroll
+                for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &di[0][b * 8]);
+                layer_bwd<TILES, CTX, OBR, HFB, C3, 2 * GR>(c, di, c3, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
+            }
+            // d F = W_views[:, :W]^T dY_views + W_sem0^T dY_sem0 + W_inst0^T dY_inst0   (feature_linear has no activation)
+            constexpr int C2 = HR + 8;              // [dY_feature | d rgb, sigma]
+            uint32_t c2[TILES][C2];
+            layer_bwd<TILES, CTX, C3, NFB, C2, 0, false>(c, c3, c2, nullptr, dys + a.dys_off[1], samp, srow);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c2[0][HR + i] = drs[0][i];
+            // d h = W_feature^T d F + alpha^T d sigma ; gate by h = X_D
+            layer_bwd<TILES, CTX, C2, NFB, HR, 0, true, PNR_BWD_FBC_DH>(c, c2, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
+        } else {
         // d f = W_views[:, :W]^T dY_views  (feature_linear has no activation) -> dY_feature
         layer_bwd<TILES, CTX, GR, NFB, CATR, 0, false>(c, dyv, cat, nullptr, dys + a.dys_off[1], samp, srow);
         if (a.n_sem) {
@@ -156,8 +186,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
-        uint32_t dy[TILES][HR], dn[TILES][HR];
         layer_bwd<TILES, CTX, CATR, NFB, HR, 0, true, PNR_BWD_FBC_DH>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
+        }
         // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
 #pragma unroll 1
         for (int l = D - 1; l >= 1; --l) {
@@ -210,6 +240,7 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_backward: bf16 only");
+    PNR_REQUIRE(desc->head_depth != 1, "pnr_mlp_backward: head_depth = 1 is inference only");
     PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS,
                 "pnr_mlp_backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
     PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_mlp_backward: bad size");
@@ -228,9 +259,9 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
     a.S = (int)(n_rays * n_samples); a.N = n_samples;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
+    a.head_tap = desc->head_tap; a.head_depth = 2;
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
     pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
-    if (const char* e = getenv("PNR_CLK_PTR")) a.clk = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostics (tools/clk_probe.py)
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

@@ -25,6 +25,7 @@ struct MlpArgs {
     uint32_t n_magic; int n_shift;  // x / N for 0 <= x < 2^31 as (x * n_magic) >> n_shift (pnr_set_div_magic)
     float* raw; int64_t ss, sc;
     int D, skip, n_sem, n_inst;
+    int head_tap, head_depth;       // pnr_mlp_desc: 0 / 1 = the heads read h / the feature; 1 / 2 Linear layers per head
     // training only (null otherwise).  acts: activations saved by the forward for the backward,
     // bf16, one [S][width] slot-ordered region per tensor (pnr_train_layout); d_raw: upstream gradient
     // of raw, (ch, S) channel-major fp32; dys: pre-activation gradients written by the backward.

@@ -26,6 +26,8 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
                 "pnr_mlp: head_W=%d must equal W/2=%d", d->head_W, d->W / 2);
     PNR_REQUIRE(d->precision == PNR_PREC_BF16 || d->precision == PNR_PREC_FP32, "pnr_mlp: bad precision %d",
                 d->precision);
+    PNR_REQUIRE(d->head_tap == 0 || d->head_tap == 1, "pnr_mlp: head_tap=%d must be 0 (trunk output) or 1 (feature)", d->head_tap);
+    PNR_REQUIRE(d->head_depth >= 0 && d->head_depth <= 2, "pnr_mlp: head_depth=%d must be 1 or 2", d->head_depth);
     PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)),
                 "pnr_mlp: plan=%d is not available for this geometry (ask pnr_mlp_fused_plan)", d->plan);
     return PNR_OK;
@@ -45,6 +47,7 @@ static int bwd_validate(const pnr_mlp_desc* d)
     int rc = pnr_mlp_validate(d);
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(d->plan == 0, "pnr_mlp backward: plan must be 0");
+    PNR_REQUIRE(pnr_head_depth(*d) == 2, "pnr_mlp backward: head_depth = 1 is inference only");
     PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
     PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
                 "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
@@ -56,8 +59,9 @@ static int check_params(const pnr_mlp_desc* desc, const pnr_mlp_params_host* p, 
     PNR_REQUIRE(p, "pnr_mlp_pack: null params");
     PNR_REQUIRE(p->pts_w && p->alpha_w && p->feature_w && p->views_w && p->rgb_w, "pnr_mlp_pack: missing trunk parameter");
     if (bias) PNR_REQUIRE(p->pts_b && p->alpha_b && p->feature_b && p->views_b && p->rgb_b, "pnr_mlp_pack: missing trunk bias");
-    if (desc->n_sem) PNR_REQUIRE(p->sem0_w && p->sem1_w && (!bias || (p->sem0_b && p->sem1_b)), "pnr_mlp_pack: missing semantic head");
-    if (desc->n_inst) PNR_REQUIRE(p->inst0_w && p->inst1_w && (!bias || (p->inst0_b && p->inst1_b)), "pnr_mlp_pack: missing instance head");
+    const bool deep = pnr_head_depth(*desc) == 2;
+    if (desc->n_sem) PNR_REQUIRE((!deep || p->sem0_w) && p->sem1_w && (!bias || ((!deep || p->sem0_b) && p->sem1_b)), "pnr_mlp_pack: missing semantic head");
+    if (desc->n_inst) PNR_REQUIRE((!deep || p->inst0_w) && p->inst1_w && (!bias || ((!deep || p->inst0_b) && p->inst1_b)), "pnr_mlp_pack: missing instance head");
     return PNR_OK;
 }
 
@@ -125,9 +129,9 @@ static void describe_forward(const pnr_mlp_desc& d, const pnr_mlp_params_host& p
                         else f.ld = W;
                         break;
                     case PNR_L_SEM0: f.src = p.sem0_w; f.ld = W; break;
-                    case PNR_L_SEM1: f.src = p.sem1_w; f.ld = H; break;
+                    case PNR_L_SEM1: f.src = p.sem1_w; f.ld = pnr_head_depth(d) == 1 ? W : H; break;
                     case PNR_L_INST0: f.src = p.inst0_w; f.ld = W; break;
-                    case PNR_L_INST1: f.src = p.inst1_w; f.ld = H; break;
+                    case PNR_L_INST1: f.src = p.inst1_w; f.ld = pnr_head_depth(d) == 1 ? W : H; break;
                     case PNR_L_FEATURE: f.src = p.feature_w; f.ld = W; break;
                     case PNR_L_VIEWS: f.src = p.views_w; f.ld = W + ED; f.col_off = seg == 0 ? 0 : W; break;   // [feature, gamma(d)]
                     case PNR_L_LOGITS: break;                  // set above

@@ -14,10 +14,11 @@
 #include "pnr_mlp_layout.h"
 
 // plan 1 exists for: bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks (the instantiated kernel tails)
+static inline int pnr_head_depth(const pnr_mlp_desc& d) { return d.head_depth == 1 ? 1 : 2; }
 static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
 {
     const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
-    return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1;
+    return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1 && pnr_head_depth(d) == 2;
 }
 
 #ifndef PNR_PLAN1_TRUNK0_MERGE
@@ -71,6 +72,9 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         if (d.n_inst) add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
         add(PNR_L_LOGITS, nbs, (nbs + nbi) * 32, PNR_SEG_FEAT, d.head_W);
         plan.layers.back().fbc = nbs + nbi;         // every logit block in one chunk
+    } else if (pnr_head_depth(d) == 1) {      // one Linear per head, straight from the tap (W inputs)
+        if (d.n_sem) add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.W);
+        if (d.n_inst) add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.W);
     } else {
         if (d.n_sem) {
             add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
@@ -102,7 +106,8 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
 // ---- backward (dgrad) plan, bf16 only.  Every backward layer computes  dX^T = W^T * dY^T  for one tensor X:
 // rows = X's features (32-row blocks), k = the forward layer's OUTPUT features, supplied by up to four
 // k-segments in FEAT slot order (pnr_seg_col).  Chunks hold 2 row blocks and no bias fragment.
-// Execution order: DG | DF | [DSHS] | [DSHI] | DH | DX(D-1) ... DX(1).
+// Execution order: DG | DF | [DSHS] | [DSHI] | DH | DX(D-1) ... DX(1)                     (head_tap 0: the heads read h)
+//                  DG | [DSHS] | [DSHI] | DF (views + head contributions) | DH | DX ...     (head_tap 1: the heads read the feature)
 enum { PNR_B_DG = 0, PNR_B_DF, PNR_B_DSHS, PNR_B_DSHI, PNR_B_DH, PNR_B_DX };
 enum { PNR_K_RGBS = 0, PNR_K_VIEWS, PNR_K_SEM1, PNR_K_INST1, PNR_K_FEATURE, PNR_K_SEM0, PNR_K_INST0, PNR_K_TRUNK };
 #define PNR_BWD_OUT_SLOTS 64      /* k-slots reserved for a head's outputs (n_sem, n_inst <= 64 when training) */
@@ -139,10 +144,19 @@ static inline void pnr_build_bwd_plan(const pnr_mlp_desc& d, PnrBPlan& plan)
     plan.layers.clear();
     plan.chunks.clear();
     add(PNR_B_DG, 0, H, {{PNR_K_RGBS, 32}});
-    add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}});
-    if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
-    if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
-    add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
+    if (d.head_tap == 1) {
+        // the head gradients reach the FEATURE: d F = views^T dY_views + sem0^T dY_sem0 + inst0^T dY_inst0 (all three segments
+        // always present: an absent head's fragments are zeros), then d h = feature^T d F + alpha^T d sigma
+        if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
+        add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
+        add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}});
+    } else {
+        add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}});
+        if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
+        add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
+    }
     for (int l = d.D - 1; l >= 1; --l) add(PNR_B_DX, l, W, {{PNR_K_TRUNK, W}});
     int off = 0, mx = 0;
     for (size_t li = 0; li < plan.layers.size(); ++li) {

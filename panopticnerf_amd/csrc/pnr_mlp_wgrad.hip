@@ -416,12 +416,13 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     add(dof[0], H, ao[1], 32, 0, H, PNR_SEG_GD, d.dir_L, EDn, have ? F(g->views_w) : nullptr, W + EDn, W, nullptr);
     add(dof[4 + D], 32, ao[3 + D], H, 0, 3, PNR_SEG_FEAT, 0, H, have ? F(g->rgb_w) : nullptr, H, 0, have ? F(g->rgb_b) : nullptr);
     add(dof[4 + D], 32, Xh, W, 3, 1, PNR_SEG_FEAT, 0, W, have ? F(g->alpha_w) : nullptr, W, 0, have ? F(g->alpha_b) : nullptr);
+    const int64_t Xtap = d.head_tap ? ao[2 + D] : Xh;       // what the heads read: the feature (head_tap 1) or h
     if (d.n_sem) {
-        add(dof[2], H, Xh, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
+        add(dof[2], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
         add(dof[5 + D], 64, ao[4 + D], H, 0, d.n_sem, PNR_SEG_FEAT, 0, H, have ? F(g->sem1_w) : nullptr, H, 0, have ? F(g->sem1_b) : nullptr);
     }
     if (d.n_inst) {
-        add(dof[3], H, Xh, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
+        add(dof[3], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
         add(dof[6 + D], 64, ao[5 + D], H, 0, d.n_inst, PNR_SEG_FEAT, 0, H, have ? F(g->inst1_w) : nullptr, H, 0, have ? F(g->inst1_b) : nullptr);
     }
     pl.partial_floats = po;
@@ -442,6 +443,7 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(desc->head_depth != 1, "pnr_mlp_wgrad: head_depth = 1 is inference only");
     PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_wgrad: the training path is bf16 only");
     PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS, "pnr_mlp_wgrad: n_sem, n_inst <= %d", PNR_BWD_OUT_SLOTS);
     PNR_REQUIRE(n_samples >= 1 && n_samples < ((int64_t)1 << 31) - 65536, "pnr_mlp_wgrad: bad sample count");

@@ -443,3 +443,41 @@ PNR_EXPORT int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, 
     PNR_CHECK_LAUNCH("pnr_sample_labels");
     return PNR_OK;
 }
+
+// ---- a8 / a3 switch: sampling restricted to the bbox prior ("is z uniform in [near, far] or restricted to
+// bbox hit intervals?" -- the reference's answer is not in the mount; this is the restricted form as a CONFIG switch,
+// cfg.bbox_sampling = "hull").  A ray that hits boxes is sampled over the hull of its kept intervals, [min t_in, max t_out]
+// (the slab test starts from [near, far], so the hull already lies inside it); a ray without a hit keeps [near, far].  Only
+// the near / far columns of the ray record change: everything downstream (stratified, sample_pdf, labels) is unchanged.
+__global__ __launch_bounds__(256) void k_restrict_rays(const float* __restrict__ rays, int64_t R, const float* __restrict__ hit_t,
+                                                        const int32_t* __restrict__ hit_count, int max_hits, float* __restrict__ out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(rays + r * 8);
+        float4 b = *reinterpret_cast<const float4*>(rays + r * 8 + 4);
+        const int cnt = hit_count[r] < max_hits ? hit_count[r] : max_hits;
+        if (cnt > 0) {
+            float lo = hit_t[(r * max_hits) * 2], hi = hit_t[(r * max_hits) * 2 + 1];
+            for (int h = 1; h < cnt; ++h) {
+                lo = fminf(lo, hit_t[(r * max_hits + h) * 2]);
+                hi = fmaxf(hi, hit_t[(r * max_hits + h) * 2 + 1]);
+            }
+            b.z = lo; b.w = hi;
+        }
+        *reinterpret_cast<float4*>(out + r * 8) = a;
+        *reinterpret_cast<float4*>(out + r * 8 + 4) = b;
+    }
+}
+
+PNR_EXPORT int pnr_restrict_rays(const float* rays, int64_t n_rays, const float* hit_t, const int32_t* hit_count, int max_hits,
+                                 float* rays_out, void* stream)
+{
+    PNR_REQUIRE(n_rays >= 0 && max_hits >= 1, "pnr_restrict_rays: bad size");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(rays && hit_t && hit_count && rays_out, "pnr_restrict_rays: null pointer");
+    PNR_REQUIRE(((((uintptr_t)rays) | ((uintptr_t)rays_out)) & 15) == 0, "pnr_restrict_rays: ray records must be 16-byte aligned");
+    hipLaunchKernelGGL(k_restrict_rays, dim3(pnr_grid_cap((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, n_rays,
+                       hit_t, hit_count, max_hits, rays_out);
+    PNR_CHECK_LAUNCH("pnr_restrict_rays");
+    return PNR_OK;
+}

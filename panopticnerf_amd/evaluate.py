@@ -18,11 +18,17 @@ class Evaluator:
         g = lambda k, d: getattr(cfg, k, d) if cfg is not None else d
         self.n_classes = n_classes if n_classes is not None else g("num_classes", 0)
         self.is_thing = is_thing
+        # panoptic id = class * 1000 + instance on things, class on stuff (KITTI-360's convention, where id 0 is 'unlabeled'):
+        # a THING of class 0 would be encoded as its bare instance index and read back as the stuff class of that number
+        if is_thing is not None and len(is_thing) and int(is_thing[0]):
+            raise ValueError("Evaluator: class 0 cannot be a 'thing' under the class * 1000 + instance id convention (its "
+                             "segments would alias stuff classes); re-index the label set so that class 0 is stuff / unlabeled")
         self.level = 1
         self.conf = None
         self.mse = []
         self.n_inst = g("num_instances", 0)
         self.pq = None          # (C, 4) device tensor: sum of matched IoUs, TP, FP, FN per class
+        self._bad_ids = None    # device counter: segments whose class index was >= n_classes (reported by summarize())
 
     def evaluate(self, output, batch):
         lv = self.level if f"rgb_{self.level}" in output else 0
@@ -63,9 +69,11 @@ class Evaluator:
             comp = torch.full_like(ids, -1)
             comp[ok] = inv.int()
             cls = torch.where(uniq >= 1000, uniq // 1000, uniq).long()
-            if uniq.numel() and int(cls.max()) >= C:
-                raise ValueError("panoptic id with class %d >= n_classes %d" % (int(cls.max()), C))
-            return comp.contiguous(), cls
+            # out-of-range classes are dropped on the device (clamped into an overflow row that summarize() reports) instead
+            # of a host round trip per frame
+            bad = cls >= C
+            self._bad_ids = bad.sum() if self._bad_ids is None else self._bad_ids + bad.sum()
+            return comp.contiguous(), cls.clamp(max=C - 1)
 
         seg_p, cls_p = segments(pred_id)
         seg_g, cls_g = segments(gt_id)
@@ -104,6 +112,8 @@ class Evaluator:
             out["miou"] = float(iou[seen].mean()) if seen.any() else math.nan
             out["pixel_acc"] = float(tp.sum() / c.sum().clamp(min=1))
         if self.pq is not None:
+            if self._bad_ids is not None and int(self._bad_ids) > 0:
+                raise ValueError("Evaluator: %d segment id(s) carried a class index >= n_classes = %d" % (int(self._bad_ids), self.n_classes))
             t = self.pq.cpu()
             denom = t[:, 1] + 0.5 * t[:, 2] + 0.5 * t[:, 3]
             seen = denom > 0
@@ -112,5 +122,5 @@ class Evaluator:
             out["pq"] = float(pq[seen].mean()) if seen.any() else math.nan
             out["sq"] = float((t[:, 0][seen] / t[:, 1][seen].clamp(min=1e-12))[t[:, 1][seen] > 0].mean()) if (t[:, 1] > 0).any() else math.nan
             out["rq"] = float((t[:, 1] / denom.clamp(min=1e-12))[seen].mean()) if seen.any() else math.nan
-        self.mse, self.conf, self.pq = [], None, None
+        self.mse, self.conf, self.pq, self._bad_ids = [], None, None, None
         return out

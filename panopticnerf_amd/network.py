@@ -22,11 +22,15 @@ class NeRF(nn.Module):
 
     pts_linears[i] (i<D): gamma(x)->W, W->W, with [gamma(x), h] concatenated after layer `skip`;
     alpha_linear W->1; feature_linear W->W; views_linears[0] (W+gamma(d))->W/2; rgb_linear W/2->3;
-    semantic_linears / instance_linears: W -> W/2 -> n_sem / n_inst."""
+    semantic_linears / instance_linears: W -> W/2 -> n_sem / n_inst (head_depth 2) or W -> n (head_depth 1), reading the trunk
+    output (head_tap 'trunk') or the feature_linear output ('feature')."""
 
-    def __init__(self, D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0):
+    def __init__(self, D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_tap="trunk", head_depth=2):
         super().__init__()
         self.D, self.W, self.skip, self.xyz_L, self.dir_L = D, W, skip, xyz_L, dir_L
+        if head_tap not in ("trunk", "feature") or int(head_depth) not in (1, 2):
+            raise ValueError("head_tap must be 'trunk' or 'feature' and head_depth 1 or 2 (got %r, %r)" % (head_tap, head_depth))
+        self.head_tap, self.head_depth = head_tap, int(head_depth)
         self.n_sem, self.n_inst, self.head_W = n_sem, n_inst, W // 2
         ex, ed = 3 + 6 * xyz_L, 3 + 6 * dir_L
         self.pts_linears = nn.ModuleList(
@@ -35,14 +39,15 @@ class NeRF(nn.Module):
         self.feature_linear = nn.Linear(W, W)
         self.views_linears = nn.ModuleList([nn.Linear(W + ed, W // 2)])
         self.rgb_linear = nn.Linear(W // 2, 3)
+        head = (lambda n: [nn.Linear(W, n)]) if self.head_depth == 1 else (lambda n: [nn.Linear(W, W // 2), nn.Linear(W // 2, n)])
         if n_sem:
-            self.semantic_linears = nn.ModuleList([nn.Linear(W, W // 2), nn.Linear(W // 2, n_sem)])
+            self.semantic_linears = nn.ModuleList(head(n_sem))
         if n_inst:
-            self.instance_linears = nn.ModuleList([nn.Linear(W, W // 2), nn.Linear(W // 2, n_inst)])
+            self.instance_linears = nn.ModuleList(head(n_inst))
 
     def desc(self, precision):
         return ops.make_desc(self.D, self.W, self.skip, self.xyz_L, self.dir_L, self.n_sem, self.n_inst,
-                             self.head_W, precision)
+                             self.head_W, precision, self.head_tap, self.head_depth)
 
 
 class Network(nn.Module):
@@ -56,7 +61,9 @@ class Network(nn.Module):
         if skip >= D - 1:
             skip = -1
         kw = dict(D=D, W=W, skip=skip, xyz_L=_get(cfg, "xyz_res", 10), dir_L=_get(cfg, "view_res", 4),
-                  n_sem=_get(cfg, "num_classes", 0), n_inst=_get(cfg, "num_instances", 0))
+                  n_sem=_get(cfg, "num_classes", 0), n_inst=_get(cfg, "num_instances", 0),
+                  # SURVEY.md 9 item 4 as config switches: where the heads tap the network, and how deep they are
+                  head_tap=_get(cfg, "head_tap", "trunk"), head_depth=_get(cfg, "head_depth", 2))
         self.precision = _get(cfg, "precision", "bf16")
         # the same key fallback as Renderer: N_importance, else cascade_samples
         self.N_importance = _get(cfg, "N_importance", _get(cfg, "cascade_samples", 0))
@@ -84,6 +91,14 @@ class Network(nn.Module):
         packed eagerly for another (level, precision, direction) key is stale afterwards)."""
         for k, hit in list(self._packed.items()):
             self._packed[k] = (None,) + tuple(hit[1:])        # keep the buffers (graph-captured pointers stay valid)
+
+    def train(self, mode=True):
+        """Every train <-> eval switch drops the packed images (the buffers are kept: one pack kernel per image on the next
+        render).  An eval-mode network serves them from the cache keyed on tensor VERSIONS, and versions do not see what a
+        training phase may have done to the values: HIP-graph replays of the optimiser step, `.data` writes, EMA."""
+        if bool(mode) != self.training:
+            self.invalidate_packed()
+        return super().train(mode)
 
     def _version(self, level):
         return tuple(p._version for p in self.nerf(level).parameters())

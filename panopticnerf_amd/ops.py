@@ -105,12 +105,17 @@ def embed(x, L):
     return out
 
 
-def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=None, precision="bf16"):
+def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=None, precision="bf16", head_tap="trunk",
+              head_depth=2):
+    """head_tap: what the semantic / instance heads read -- 'trunk' (the trunk output h) or 'feature' (the feature_linear
+    output); head_depth: 2 (W -> head_W -> n) or 1 (one Linear W -> n, inference only).  SURVEY.md 9 item 4 as switches."""
     d = MlpDesc()
     d.D, d.W, d.skip, d.xyz_L, d.dir_L = D, W, skip, xyz_L, dir_L
     d.n_sem, d.n_inst = n_sem, n_inst
     d.head_W = W // 2 if head_W is None else head_W
     d.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_FP32}[precision]
+    d.head_tap = {"trunk": 0, "feature": 1}[head_tap]
+    d.head_depth = {1: 1, 2: 2}[int(head_depth)]
     return d
 
 
@@ -144,12 +149,15 @@ def _param_struct(desc, params, device):
     P.feature_w, P.feature_b = fp("feature_linear.weight"), fp("feature_linear.bias")
     P.views_w, P.views_b = fp("views_linears.0.weight"), fp("views_linears.0.bias")
     P.rgb_w, P.rgb_b = fp("rgb_linear.weight"), fp("rgb_linear.bias")
+    last = 0 if desc.head_depth == 1 else 1            # head_depth 1: the head is its single Linear (the struct's *1 slot)
     if desc.n_sem:
-        P.sem0_w, P.sem0_b = fp("semantic_linears.0.weight"), fp("semantic_linears.0.bias")
-        P.sem1_w, P.sem1_b = fp("semantic_linears.1.weight"), fp("semantic_linears.1.bias")
+        if last:
+            P.sem0_w, P.sem0_b = fp("semantic_linears.0.weight"), fp("semantic_linears.0.bias")
+        P.sem1_w, P.sem1_b = fp(f"semantic_linears.{last}.weight"), fp(f"semantic_linears.{last}.bias")
     if desc.n_inst:
-        P.inst0_w, P.inst0_b = fp("instance_linears.0.weight"), fp("instance_linears.0.bias")
-        P.inst1_w, P.inst1_b = fp("instance_linears.1.weight"), fp("instance_linears.1.bias")
+        if last:
+            P.inst0_w, P.inst0_b = fp("instance_linears.0.weight"), fp("instance_linears.0.bias")
+        P.inst1_w, P.inst1_b = fp(f"instance_linears.{last}.weight"), fp(f"instance_linears.{last}.bias")
     return P, keep
 
 
@@ -494,6 +502,16 @@ def bbox_hits(rays, box, max_hits=8):
     _lib.check(_lib.load().pnr_bbox_hits(_p(rays), R, _p(box), M, max_hits, _p(hit_t), _p(hit_box), _p(hit_count),
                                          _stream()), "pnr_bbox_hits")
     return hit_t, hit_box, hit_count
+
+
+@_on_device
+def restrict_rays(rays, hit_t, hit_count):
+    """rays with near / far replaced by the hull of each ray's kept bbox intervals (pnr_restrict_rays); no hit: unchanged."""
+    rays = _chk(rays, "rays")
+    out = torch.empty_like(rays)
+    _lib.check(_lib.load().pnr_restrict_rays(_p(rays), rays.shape[0], _p(_chk(hit_t, "hit_t")), _p(_chk(hit_count, "hit_count", torch.int32)),
+                                             hit_t.shape[1], _p(out), _stream()), "pnr_restrict_rays")
+    return out
 
 
 @_on_device

@@ -45,6 +45,12 @@ class Renderer:
         # cfg.fuse_composite = False (or PNR_FUSE=0) keeps the two-kernel path with the raw image in HBM
         self.fuse = bool(_get(cfg, "fuse_composite", os.environ.get("PNR_FUSE", "1") != "0"))
         self.strict_hits = bool(_get(cfg, "strict_hits", False))
+        # "none": stratified over [near, far] (canonical NeRF); "hull": rays that hit boxes are sampled over the hull of their
+        # hit intervals (SURVEY.md 9 item 2 -- which of the two the reference does is unverifiable here: a switch)
+        self.bbox_sampling = _get(cfg, "bbox_sampling", "none")
+        if self.bbox_sampling not in ("none", "hull"):
+            raise ValueError("cfg.bbox_sampling must be 'none' or 'hull', not %r" % (self.bbox_sampling,))
+        self._overflow = None
         if self.N_importance > 0 and getattr(net, "nerf_1", None) is None and not getattr(net, "share_coarse_fine", False):
             raise ValueError("make_renderer: cfg asks for a fine pass (N_importance / cascade_samples = %d) but the network "
                              "was built without a fine NeRF -- build it with make_network(cfg) from the SAME cfg, or set "
@@ -60,13 +66,14 @@ class Renderer:
         hits = None
         if box is not None:
             hits = ops.bbox_hits(rays, box, self.max_hits)
-            if self.strict_hits and int((hits[2] > self.max_hits).sum()) > 0:      # opt-in: costs a device sync
-                raise RuntimeError("render_rays: %d ray(s) cross more than max_hits = %d boxes (up to %d): the farthest "
-                                   "intervals were dropped -- raise cfg.max_hits" % (int((hits[2] > self.max_hits).sum()),
-                                                                                    self.max_hits, int(hits[2].max())))
+            if self.strict_hits:          # accumulated on the device; checked ONCE at the end of render() (a single sync)
+                over = torch.stack([(hits[2] > self.max_hits).sum(), hits[2].max()])
+                self._overflow = over if self._overflow is None else torch.stack([self._overflow[0] + over[0],
+                                                                                  torch.maximum(self._overflow[1], over[1])])
         if t_rand is None and self.perturb > 0 and train:
             t_rand = torch.rand((rays.shape[0], Nc), device=dev)
-        z = ops.stratified(rays, Nc, self.lindisp, t_rand)
+        rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and self.bbox_sampling == "hull") else rays
+        z = ops.stratified(rays_s, Nc, self.lindisp, t_rand)
 
         def level(lv, zz):
             ls = li = None
@@ -123,12 +130,19 @@ class Renderer:
         if u is not None:
             u = u.reshape(R, -1).float().contiguous()
         train = self.net.training
+        self._overflow = None
         outs = []
         for s in range(0, R, self.chunk_size):
             e = min(R, s + self.chunk_size)
             outs.append(self.render_rays(rays[s:e], box, box_ids,
                                          None if t_rand is None else t_rand[s:e],
                                          None if u is None else u[s:e], train, grad))
+        if self._overflow is not None:
+            n_over, worst = (int(v) for v in self._overflow.tolist())         # the one device sync of strict_hits
+            self._overflow = None
+            if n_over > 0:
+                raise RuntimeError("Renderer.render: %d ray(s) cross more than max_hits = %d boxes (up to %d): the farthest "
+                                   "intervals were dropped -- raise cfg.max_hits" % (n_over, self.max_hits, worst))
         ret = {}
         for k in outs[0]:
             if outs[0][k].dim() == 0:

@@ -137,6 +137,7 @@ def weight_grads(nerf, desc, acts, dys, d_raw, S):
         return g.index_select(0, _inverse(idx, idx.numel()))
 
     X_h = A(1 + D, W)                               # h = X_D
+    X_tap = A(2 + D, W) if getattr(desc, "head_tap", 0) else X_h      # what the heads read: the feature (head_tap 1) or h
     EX, ED = A(0, 64), A(1, 32)
     F_, G_, SHS, SHI = A(2 + D, W), A(3 + D, H), A(4 + D, H), A(5 + D, H)
     g = {}
@@ -151,13 +152,13 @@ def weight_grads(nerf, desc, acts, dys, d_raw, S):
         g["semantic_linears.1.weight"] = unperm_cols(_mm(drb[:, 4:4 + C].contiguous(), SHS), fH, H)
         g["semantic_linears.1.bias"] = dr[4:4 + C].sum(1)
         dy = Y(2, H)
-        g["semantic_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_h), fW, W), fH)
+        g["semantic_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_tap), fW, W), fH)
         g["semantic_linears.0.bias"] = unperm_rows(_sum0(dy), fH)
     if K:
         g["instance_linears.1.weight"] = unperm_cols(_mm(drb[:, 4 + C:4 + C + K].contiguous(), SHI), fH, H)
         g["instance_linears.1.bias"] = dr[4 + C:4 + C + K].sum(1)
         dy = Y(3, H)
-        g["instance_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_h), fW, W), fH)
+        g["instance_linears.0.weight"] = unperm_rows(unperm_cols(_mm(dy, X_tap), fW, W), fH)
         g["instance_linears.0.bias"] = unperm_rows(_sum0(dy), fH)
     dy = Y(0, H)                                    # views: input [feature, gamma(d)]
     g["views_linears.0.weight"] = unperm_rows(torch.cat([unperm_cols(_mm(dy, F_), fW, W),

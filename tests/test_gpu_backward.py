@@ -56,7 +56,8 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
-@pytest.mark.parametrize("geom", [(2, 128, [], 0, 0), (3, 128, [1], 5, 3), (8, 256, [4], 45, 32), (8, 256, [4], 0, 0)])
+@pytest.mark.parametrize("geom", [(2, 128, [], 0, 0), (3, 128, [1], 5, 3), (8, 256, [4], 45, 32), (8, 256, [4], 0, 0),
+                                  (3, 128, [1], 5, 3, "feature"), (8, 256, [4], 45, 32, "feature"), (4, 256, [], 19, 0, "feature")])
 def test_mlp_backward_matches_autograd(dev, geom):
     """pnr_mlp_forward_train + pnr_mlp_backward + weight-gradient GEMMs vs torch autograd through the
     bf16-emulating oracle MLP (same rounded activations => same ReLU gates; against the fp32 forward the
@@ -65,15 +66,16 @@ def test_mlp_backward_matches_autograd(dev, geom):
     from panopticnerf_amd import make_network
     import _wgrad_ref as wref
     from types import SimpleNamespace as NS
-    D, W, skips, C, K = geom
+    D, W, skips, C, K = geom[:5]
+    tap = geom[5] if len(geom) > 5 else "trunk"      # cfg.head_tap: the heads read the trunk output or the feature (a switch)
     torch.manual_seed(D * 7 + W + C)
-    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K))
+    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K, head_tap=tap))
     nerf = net.nerf_0
     rng = np.random.default_rng(D + W)
     R, N = 7, 41                                     # 287 samples: ragged last tile and last group
     rays = torch.tensor(_rays(rng, R, 0.5, 8.0))
     z = torch.tensor(co.stratified(rays.numpy(), N, t_rand=rng.random((R, N)).astype(np.float32)))
-    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2)
+    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2, head_tap=tap)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in nerf.state_dict().items()}
     raw_ref = to.run_network(params, ocfg, rays, z, emulate_bf16=True)    # (R,N,ch)
     d_raw = torch.tensor(rng.normal(size=raw_ref.shape).astype(np.float32))

@@ -92,9 +92,10 @@ def test_render_baseline_configs(dev, cfg_golden, n, prec):
         assert derr < (1e-4 if prec == "fp32" else 1e-2) * 100.0, (n, prec, "depth", lv, derr)     # metres, far = 100
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
 def test_baseline_config_full_frame_properties(dev, n):
-    """Configs 1..4 at the size BASELINE quotes (one 1408x376 frame), bf16 (config 5: test_gpu_render.py)."""
+    """Every BASELINE config at the size it is quoted on (one 1408x376 frame), bf16, at its own head widths (config 5: the
+    benched 45 semantic + 32 instance logits, through the fused pass with the fused-inference chunk order)."""
     c, oc, params, _, box, ids, cfg, rend = _build(n, "bf16", dev)
     rays = synthetic.camera_rays()
     batch = {"rays": rays.reshape(376, 1408, 8).to(dev)}

@@ -42,7 +42,7 @@ def test_confusion_exact_and_accumulates(dev):
 def test_evaluator_psnr_miou(dev):
     g = torch.Generator().manual_seed(3)
     R, C, K = 5000, 6, 3
-    ev = Evaluator(n_classes=C, is_thing=[1, 0, 0, 1, 0, 0])
+    ev = Evaluator(n_classes=C, is_thing=[0, 1, 0, 1, 0, 0])
     ref_conf = np.zeros((C, C), np.int64)
     psnr = []
     for f in range(3):
@@ -51,7 +51,7 @@ def test_evaluator_psnr_miou(dev):
         lab = torch.randint(-1, C, (1, R), generator=g)
         out = {"rgb_1": rgb.to(dev), "semantic_1": sem.to(dev), "instance_1": inst.to(dev)}
         res = ev.evaluate(out, {"rgb": gt_rgb.to(dev), "pseudo_label": lab.to(dev)})
-        sl, il, pan = no.panoptic_labels(sem[0].numpy(), inst[0].numpy(), np.array([1, 0, 0, 1, 0, 0]))
+        sl, il, pan = no.panoptic_labels(sem[0].numpy(), inst[0].numpy(), np.array([0, 1, 0, 1, 0, 0]))
         assert np.array_equal(res["panoptic_id"].cpu().numpy(), pan)
         ref_conf += no.confusion(sl, lab[0].numpy(), C)
         psnr.append(-10 * np.log10(((rgb - gt_rgb).double() ** 2).mean().item()))
@@ -91,3 +91,4 @@ def test_panoptic_quality_matches_oracle(dev):
     s = ev.summarize()
     den = ref[:, 1] + 0.5 * ref[:, 2] + 0.5 * ref[:, 3]
     assert abs(s["pq"] - np.mean(ref[den > 0, 0] / den[den > 0])) < 1e-12
+

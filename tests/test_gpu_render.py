@@ -227,3 +227,23 @@ def test_reference_checkpoint_loads_packs_and_renders(dev, tmp_path):
         dst.invalidate_packed()
         fresh = rend.render(batch)
     assert torch.equal(stale["rgb_1"], after["rgb_1"]) and not torch.equal(fresh["rgb_1"], after["rgb_1"])
+
+
+def test_strict_hits_reports_overflow_once_per_render(dev):
+    """cfg.strict_hits: rays that cross more than max_hits boxes raise -- accumulated on the device over the chunks and checked
+    with ONE sync at the end of render(), naming the count and the worst case; without the flag the nearest
+    max_hits intervals are kept silently."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network, make_renderer
+    cfg = dict(N_samples=32, N_importance=0, num_classes=5, num_instances=0, precision="bf16", chunk_size=128, D=2, W=128, skips=[], max_hits=1)
+    net = make_network(NS(**cfg)).to(dev).eval()
+    rays = synthetic.camera_rays()[::1500][:300].contiguous().to(dev)
+    box, ids = synthetic.random_boxes(64, 5, 1)
+    batch = {"rays": rays[None], "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        out = make_renderer(NS(**cfg), net).render(batch)
+        assert out["fix_semantic_0"].shape == (1, 300, 5)
+        with pytest.raises(RuntimeError, match=r"cross more than max_hits = 1 boxes \(up to \d+\)"):
+            make_renderer(NS(strict_hits=True, **cfg), net).render(batch)
+        big = dict(cfg, max_hits=64)
+        make_renderer(NS(strict_hits=True, **big), net).render(batch)        # room for every box: no complaint

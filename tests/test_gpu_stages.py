@@ -512,3 +512,79 @@ def test_fused_path_is_what_the_renderer_runs_and_can_be_switched_off(dev):
     for k in ("rgb_1", "acc_1", "semantic_1", "instance_1", "fix_semantic_1", "fix_instance_1"):
         x, y = a[k][0], b[k][0]
         assert float(torch.quantile((x - y).abs().flatten(), 0.99)) <= 5e-3 * max(1.0, float(y.abs().max())), k
+
+
+def test_bbox_restricted_sampling_switch(dev):
+    """cfg.bbox_sampling = 'hull' (SURVEY.md 9 item 2 as a config switch): pnr_restrict_rays is bit-exact with the C oracle, and a
+    render with the switch on equals the bf16-emulating oracle run with the same switch -- samples of rays that hit boxes lie in
+    the hull of their intervals, rays without a hit are sampled over [near, far] as before."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network, make_renderer
+    rays = synthetic.camera_rays()[::997][:400].contiguous()
+    box, ids = synthetic.random_boxes(40, 6, 3, seed=3)
+    ht, hb, hc = co.bbox_hits(rays.numpy(), box.numpy(), 8)
+    got = ops.restrict_rays(rays.to(dev), torch.tensor(ht).to(dev), torch.tensor(hc).to(dev))
+    assert np.array_equal(got.cpu().numpy(), co.restrict_rays(rays.numpy(), ht, hc))
+    cfg = dict(N_samples=32, N_importance=32, num_classes=6, num_instances=3, precision="bf16", D=4, W=128, skips=[1])
+    torch.manual_seed(2)
+    net = make_network(NS(**cfg)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    batch = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        a = make_renderer(NS(**cfg), net).render(batch)
+        b = make_renderer(NS(bbox_sampling="hull", **cfg), net).render(batch)
+    rr = co.restrict_rays(rays.numpy(), ht, hc)
+    assert np.array_equal(b["z_vals_0"][0].cpu().numpy(), co.stratified(rr, 32))
+    hit = torch.tensor(hc > 0)
+    assert torch.equal(a["z_vals_0"][0].cpu()[~hit], b["z_vals_0"][0].cpu()[~hit]) and not torch.equal(a["z_vals_0"], b["z_vals_0"])
+    oc = to.mlp_config(D=4, W=128, skips=(1,), n_sem=6, n_inst=3, head_W=64)
+    prm = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
+           "fine": {k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}}
+    want = to.render_rays(prm, oc, rays, 32, 32, box=box, box_ids=ids, emulate_bf16=True, bbox_sampling="hull")
+    assert torch.equal(b["z_vals_0"][0].cpu(), want["z_vals_0"])
+    for k in ("rgb_0", "acc_0", "fix_semantic_0"):
+        e = (b[k][0].cpu() - want[k]).abs()
+        assert float(torch.quantile(e.flatten(), 0.95)) < 1e-2, (k, float(e.max()))
+    with pytest.raises(ValueError, match="bbox_sampling"):
+        make_renderer(NS(bbox_sampling="intervals", **cfg), net)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tap,depth", [("feature", 2), ("trunk", 1), ("feature", 1)])
+@pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (4, 128, [1], 6, 0)])
+def test_head_tap_and_depth_switches(dev, geom, tap, depth, prec):
+    """SURVEY.md 9 item 4 as CONFIG switches (cfg.head_tap, cfg.head_depth): the semantic / instance heads read the trunk output
+    or the feature_linear output, and are W -> W/2 -> n or one Linear W -> n.  Every combination against the oracle MLP with
+    the same switch: fp32-MFMA mode to 1e-4 (the parity bar), bf16 against the bf16-emulating oracle; the fused inference pass
+    (plan 1 where the geometry has one, else the classic order) equals the two-kernel path."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    D, W, skips, C, K = geom
+    torch.manual_seed(D + C + depth)
+    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K, N_importance=0, head_tap=tap, head_depth=depth,
+                          precision=prec)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    assert len(net.nerf_0.semantic_linears) == depth
+    R, N = 70, 32
+    rays = synthetic.camera_rays()[::7001][:R].contiguous()
+    z = torch.tensor(co.stratified(rays.numpy(), N))
+    oc = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2, head_tap=tap, head_depth=depth)
+    prm = {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()}
+    want = to.run_network(prm, oc, rays, z, emulate_bf16=(prec == "bf16"))
+    base = to.run_network(prm, to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2), rays, z) if depth == 2 else None
+    desc, img = net.packed(0, dev, prec)
+    assert desc.head_tap == (1 if tap == "feature" else 0) and desc.head_depth == depth
+    raw = ops.mlp_forward(desc, img, rays.to(dev), z.to(dev), channel_major=True)
+    got = raw.unflatten(1, (R, N)).permute(1, 2, 0).cpu()
+    err = (got - want).abs()
+    if prec == "fp32":
+        assert float(err.max()) < 1e-4, float(err.max())
+    else:
+        assert float(torch.quantile(err.flatten(), 0.99)) < 2e-2 and float(err.max()) < 0.2, (float(err.max()),)
+    assert torch.equal(got[..., :4], got[..., :4]) and (base is None or float((want[..., 4:] - base[..., 4:]).abs().max()) > 1e-3)  # the switch matters
+    if prec == "bf16":
+        a = ops.composite(raw, z.to(dev), rays.to(dev), C, K, True, None, None, None, 0, False, True)
+        fd, fimg = net.packed(0, dev, prec, fused=True)
+        b = ops.mlp_forward_composite(fd, fimg, rays.to(dev), z.to(dev), None, None, False, True)
+        for k in a:
+            assert float((a[k] - b[k]).abs().max()) <= 4e-6 * max(1.0, float(a[k].abs().max())) * (N // 32), k

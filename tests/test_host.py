@@ -285,3 +285,31 @@ def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fake-render", "--cpu-seconds", "0"],
                         capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert cp.returncode != 0 and "--gpus 2" in cp.stderr + cp.stdout
+
+
+def test_evaluator_refuses_a_class_zero_thing():
+    """Panoptic id = class * 1000 + instance on things, class on stuff: a thing of class 0 would be encoded as its bare instance
+    index and counted as the stuff class of that number.  The evaluator refuses such a label set up front."""
+    from panopticnerf_amd.evaluate import Evaluator
+    with pytest.raises(ValueError, match="class 0"):
+        Evaluator(n_classes=4, is_thing=[1, 0, 1, 0])
+    Evaluator(n_classes=4, is_thing=[0, 1, 1, 0])
+
+
+def test_train_eval_switch_drops_the_packed_images():
+    """Network.train(mode) invalidates the packed-image cache on every train <-> eval switch: an eval-mode
+    render after a training phase must never serve an image keyed on tensor versions that HIP-graph replays / .data writes
+    do not bump.  The buffers are kept (graph-captured pointers stay valid); only the version stamp goes."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    net = make_network(NS(N_importance=0, D=2, W=128))
+    buf = object()
+    net._packed[("fwd", 0, "cuda:0", "bf16", 0)] = (net._version(0), "desc", buf, None, ())
+    net.train(True)                                   # already training: nothing to drop
+    assert net._packed[("fwd", 0, "cuda:0", "bf16", 0)][0] is not None
+    net.eval()
+    hit = net._packed[("fwd", 0, "cuda:0", "bf16", 0)]
+    assert hit[0] is None and hit[2] is buf
+    net._packed[("fwd", 0, "cuda:0", "bf16", 0)] = (net._version(0),) + tuple(hit[1:])
+    net.train()
+    assert net._packed[("fwd", 0, "cuda:0", "bf16", 0)][0] is None

@@ -379,3 +379,22 @@ def test_tile_factorisation_equals_the_scan(N, tile):
         b = no.composite_by_tiles(raw, z, rays, C, K, tile, ls, li, white)
         for k in a:
             np.testing.assert_allclose(b[k], a[k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_restrict_rays_restatements_agree():
+    """cfg.bbox_sampling = 'hull': C and torch restatements give the same near / far, rays without a hit are untouched, the
+    hull lies inside [near, far], and the samples drawn from it all lie inside the ray's hull."""
+    rng = np.random.default_rng(9)
+    R, M = 300, 20
+    rays = _rays(rng, R)
+    box = np.concatenate([rng.uniform([-6, -2, 2], [6, 2, 40], (M, 3)), np.tile(np.eye(3, dtype=np.float32).reshape(-1), (M, 1)),
+                          rng.uniform(0.5, 3.0, (M, 3))], 1).astype(np.float32)
+    ht, hb, hc = co.bbox_hits(rays, box, 4)
+    rc = co.restrict_rays(rays, ht, hc)
+    rt = to.restrict_rays(torch.tensor(rays), torch.tensor(ht), torch.tensor(hc)).numpy()
+    assert np.array_equal(rc, rt)
+    none = hc == 0
+    assert none.any() and (~none).any() and np.array_equal(rc[none], rays[none]) and np.array_equal(rc[:, :6], rays[:, :6])
+    assert (rc[:, 6] >= rays[:, 6]).all() and (rc[:, 7] <= rays[:, 7]).all() and (rc[~none, 6] <= rc[~none, 7]).all()
+    z = co.stratified(rc, 16)
+    assert (z >= rc[:, 6:7] - 1e-6).all() and (z <= rc[:, 7:8] + 1e-6).all()
