@@ -17,8 +17,10 @@
 
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
-// 8 waves (two per SIMD) measured 7 % faster than 4 (one per SIMD) although the concatenated dH input (136 B registers)
-// makes hipcc spill ~160 dwords at the 256-register cap: the pass is HBM/latency-bound (masks in, dY out: ~9 KB/sample).
+// 8 waves (two per SIMD) measured 7 % faster than 4 (one per SIMD).  The concatenated d h input (136 B registers) leaves no
+// room for the layer's 64 output registers at the 256-register cap (round 2: ~150 dwords per lane spilled to scratch); the
+// d h layer therefore only STORES its output (it is stored for the weight gradients anyway) and the wave reads it back once
+// the inputs are dead (layer_bwd<KEEP = false> + load_layer).
 #ifndef PNR_BWD_SLOTS
 #define PNR_BWD_SLOTS 2             /* LDS weight slots: the stream runs PNR_BWD_SLOTS - 1 chunks ahead (3: measured +-0) */
 #endif
@@ -30,7 +32,10 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 // gate  : the ReLU gate BITS of the layer's forward output ([S][NFB_OUT] dwords, pnr_train_layout; nullptr: linear):
 //         NFB_OUT/2 dwords per lane, loaded once per layer, instead of the 16 x NFB_OUT bytes of bf16 activations
 // store : slot-ordered [S][NFB_OUT*32] destination of the gated gradient
-template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF, bool GATED = true, int FBC = PNR_BWD_FBC>
+// KEEP  : false = the gated gradient goes to `store` only (the caller reloads it with load_layer once its inputs are dead):
+//         the d h layer's 136 input registers + 64 output registers + accumulators + fragment window do not fit 256, and
+//         hipcc spilled ~150 dwords per lane to scratch (FETCH 1.6 GB per launch against 0.63 GB algorithmic, round 2)
+template <int TILES, class CTX, int NA, int NFB_OUT, int NOUT, int OFF, bool GATED = true, int FBC = PNR_BWD_FBC, bool KEEP = true>
 __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA], uint32_t (&out)[TILES][NOUT],
                                           const uint16_t* gate, uint16_t* store, const int (&samp)[TILES], const int (&srow)[TILES])
 {
@@ -61,17 +66,33 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
             const int fb = cb * FBC + b;
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
+                uint32_t blk[8];
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const uint32_t v = pack_bf16(acc[b][t][2 * p], acc[b][t][2 * p + 1]);
-                    out[t][OFF + fb * 8 + p] = GATED ? gate_apply(v, gw[t][fb / 2], fb, p) : v;
+                    blk[p] = GATED ? gate_apply(v, gw[t][fb / 2], fb, p) : v;
+                    if constexpr (KEEP) out[t][OFF + fb * 8 + p] = blk[p];
                 }
                 // (stores before the hand-over: moving them behind finish() -- so that its vmcnt(0) would not wait for this
                 // chunk's write acknowledgements -- measured +17 % time: the gradient registers stay live across the barrier)
-                store_slots(store, NFB_OUT * 32, srow[t], fb, c.hi, &out[t][OFF + fb * 8]);
+                store_slots(store, NFB_OUT * 32, srow[t], fb, c.hi, blk);
             }
         }
         c.finish(2 * FBC * TILES);
+    }
+}
+
+// A layer output written with KEEP = false, back into registers (the wave reads what it stored itself: L2 / L1 hits)
+template <int NFB, int NOUT>
+__device__ __forceinline__ void load_layer(const uint16_t* store, int srow, int hi, uint32_t (&out)[NOUT])
+{
+    static_assert(NOUT >= NFB * 8, "register array too small");
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(store + pnr_saved_chunk(NFB * 4, srow, fb * 4 + hi * 2));
+        const u32x4 a = p[0], b = p[8];
+        out[fb * 8 + 0] = a[0]; out[fb * 8 + 1] = a[1]; out[fb * 8 + 2] = a[2]; out[fb * 8 + 3] = a[3];
+        out[fb * 8 + 4] = b[0]; out[fb * 8 + 5] = b[1]; out[fb * 8 + 6] = b[2]; out[fb * 8 + 7] = b[3];
     }
 }
 
@@ -79,16 +100,20 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
 template <int NB>
 __device__ __forceinline__ void load_draw(const MlpArgs& a, int s, int hi, int ch_base, int n_out, uint32_t (&out)[NB * 8])
 {
+    const float* const base = a.d_raw + ((int64_t)(ch_base + 4 * hi) * a.S + (s >= 0 ? s : 0));
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
+            // row = u + 4 hi: the lane-dependent part of the address (the sample, the half-wave's 4-row offset) is ONE base per
+            // call; every row then adds the wave-uniform u * S.  (With the whole index per lane hipcc hoisted ~130 64-bit
+            // row products out of the sample-group loop and spilled them: that was the kernel's scratch traffic.)
             float v[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * p + e;
-                const int row = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                v[e] = (s >= 0 && row < n_out) ? a.d_raw[(int64_t)(ch_base + row) * a.S + s] : 0.0f;
+                const int u = b * 32 + (r & 3) + 8 * (r >> 2);
+                v[e] = (s >= 0 && u + 4 * hi < n_out) ? base[(int64_t)u * a.S] : 0.0f;
             }
             out[b * 8 + p] = pack_bf16(v[0], v[1]);
         }
@@ -186,7 +211,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
-        layer_bwd<TILES, CTX, CATR, NFB, HR, 0, true, PNR_BWD_FBC_DH>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
+        layer_bwd<TILES, CTX, CATR, NFB, HR, 0, true, PNR_BWD_FBC_DH, false>(c, cat, dy, acts + a.gate_off[1 + D], dys + a.dys_off[3 + D], samp, srow);
+        load_layer<NFB>(dys + a.dys_off[3 + D], srow[0], c.hi, dy[0]);       // cat is dead: d h comes back from where it was stored
         }
         // trunk: d X_l = W_l[:, h columns]^T dY_l ; gate by X_l ; -> dY_{l-1}
 #pragma unroll 1
