@@ -22,7 +22,10 @@
 #include "pnr_fuse_record.h"
 
 struct FuseState {
-    float lws[32];     // the tile's 32 local weights as wave-uniform values (v_readlane of lw): the logit blocks multiply by them
+    float lwr[16];     // lane (n, hi), register r: the local weight of sample row(r, hi) -- what a TRANSPOSED logit accumulator (lane =
+                       // channel, register r = sample row(r, hi)) is multiplied by.  16 VGPRs; round 2 kept the 32 weights wave-uniform in
+                       // SGPRs, which lived across five chunks, spilled to VGPR lanes and cost each logit block 64 FMAs + the reloads
+    float lw;          // this lane's own sample weight (lane n of either half)
     float zz, zn, dn;  // z of the sample, z of the ray's next sample, |d|
     int samp;          // sample index or -1
     bool last;         // the sample is its ray's last one (interval 1e10), from the input prefetch
@@ -58,8 +61,17 @@ __device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int h
     float excl, q;
     tile_scan(f, n, excl, q);
     const float lw = alpha * excl;
+#if defined(PNR_FUSE_TRANSPOSED) && !PNR_FUSE_TRANSPOSED
+    st.lw = __shfl(lw, n, 64);                   // butterfly form of the logit blocks: both halves need the weight of sample n
+#else
+    st.lw = lw;
+#endif
 #pragma unroll
-    for (int k = 0; k < 32; ++k) st.lws[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), k));
+    for (int r = 0; r < 16; ++r) {
+        const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), pnr_row_of(r, 0)));
+        const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), pnr_row_of(r, 1)));
+        st.lwr[r] = hi ? w1 : w0;
+    }
     if (hi == 0) {
         if (valid) a.ps[st.samp] = make_float4(lw, acc[0], acc[1], acc[2]);
         if (n == 0) st.rec[0] = q;
@@ -69,9 +81,8 @@ __device__ __forceinline__ void fuse_rgbs(const MlpArgs& a, FuseState& st, int h
 // a 32-row logit block (rows fb*32 + row(r, hi), valid below n_out) -> record floats at rec_base + row
 __device__ __forceinline__ void fuse_logits(FuseState& st, int hi, int n, int fb, int n_out, int rec_base, const f32x16& acc)
 {
-    float wn = st.lws[0];                                // this lane's sample weight, from the wave-uniform copies
-#pragma unroll
-    for (int k = 1; k < 32; ++k) wn = (n == k) ? st.lws[k] : wn;
+    const float wn = st.lw;                              // this lane's sample weight
+    (void)n;
     float r[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) r[k] = wn * acc[k];
@@ -85,17 +96,13 @@ __device__ __forceinline__ void fuse_logits(FuseState& st, int hi, int n, int fb
 }
 
 // a 32-channel logit block computed TRANSPOSED (PPChunk::mma<SWAP>: lane = channel fb*32 + (lane & 31), register r = sample
-// row(r, hi)): the weighted sum over the tile's samples is 16 FMAs against the wave-uniform weights (both halves' row sets are
-// evaluated, the lane keeps its own), one exchange between the half-waves, and one contiguous 128-byte store
+// row(r, hi)): the weighted sum over the tile's samples is 16 FMAs against the lane's weight registers lwr, one exchange between
+// the half-waves, and one contiguous 128-byte store
 __device__ __forceinline__ void fuse_logits_t(FuseState& st, int hi, int lane, int fb, int n_out, int rec_base, const f32x16& acc)
 {
-    float s0 = 0.0f, s1 = 0.0f;
+    float s = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        s0 = fmaf(st.lws[pnr_row_of(r, 0)], acc[r], s0);
-        s1 = fmaf(st.lws[pnr_row_of(r, 1)], acc[r], s1);
-    }
-    float s = hi ? s1 : s0;
+    for (int r = 0; r < 16; ++r) s = fmaf(st.lwr[r], acc[r], s);
     s += __shfl_xor(s, 32, 64);
     const int ch = fb * 32 + (lane & 31);
     if (hi == 0 && ch < n_out) st.rec[rec_base + ch] = s;
