@@ -20,21 +20,34 @@ def shard_rays(rays, rank, world):
 
 
 def gather_maps(local, n_rays, rank, world, group=None):
-    """Inverse of shard_rays for a dict of per-ray tensors (first dim = local ray count)."""
+    """Inverse of shard_rays for a dict of per-ray tensors (first dim = local ray count): ONE collective per frame.  Every
+    map is flattened to 4-byte columns (int32 maps bit-cast) and packed side by side into one (n_max, F) buffer; one
+    all_gather_into_tensor brings the (world, n_max, F) block to every rank, and because the sharding is interleaved
+    (ray = i * world + r) a permute to (n_max, world, F) IS the frame order -- no per-rank scatter.  On xGMI a collective is
+    latency-bound at these sizes (a few MB), so one flat bucket beats one all_gather per map."""
     if world == 1:
         return local
-    out = {}
     n_max = (n_rays + world - 1) // world
-    for k, v in local.items():
-        pad = torch.zeros((n_max,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        pad[: v.shape[0]] = v
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        full = torch.empty((n_rays,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        for r in range(world):
-            idx = shard_indices(n_rays, r, world)
-            full[idx] = parts[r][: idx.numel()]
-        out[k] = full
+    keys = list(local)
+    cols, parts = [], []
+    for k in keys:
+        v = local[k]
+        if v.element_size() != 4:
+            raise TypeError("gather_maps: %s has dtype %s; only 4-byte maps (float32 / int32) travel" % (k, v.dtype))
+        flat = v.reshape(v.shape[0], -1).contiguous().view(torch.float32)
+        cols.append(flat.shape[1])
+        parts.append(flat)
+    first = local[keys[0]]
+    buf = torch.zeros((n_max, sum(cols)), dtype=torch.float32, device=first.device)
+    buf[: first.shape[0]] = torch.cat(parts, 1) if len(parts) > 1 else parts[0]
+    out_all = torch.empty((world * n_max, buf.shape[1]), dtype=torch.float32, device=first.device)    # rank-major concatenation
+    dist.all_gather_into_tensor(out_all, buf, group=group)
+    full = out_all.view(world, n_max, buf.shape[1]).permute(1, 0, 2).reshape(world * n_max, buf.shape[1])[:n_rays]   # (i, r) -> ray i * world + r
+    out, c0 = {}, 0
+    for k, c in zip(keys, cols):
+        v = local[k]
+        out[k] = full[:, c0:c0 + c].contiguous().view(v.dtype).reshape((n_rays,) + tuple(v.shape[1:]))
+        c0 += c
     return out
 
 
