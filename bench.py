@@ -285,12 +285,14 @@ def self_launch(args):
 def train_bytes_per_sample(c):
     """HBM bytes per sample of the three training kernels: forward writes the saved activations (bf16) + one gate
     bit per ReLU output + raw; the data-gradient pass reads gate bits + d_raw and writes every dY (bf16); the weight-gradient
-    kernel reads both sets back (the trunk output h by four jobs)."""
+    kernel reads both sets back (the trunk output h by three jobs: feature, the stacked first Linears of the two heads, alpha --
+    four when only one head exists)."""
     D, W, H, ch = c["D"], c["W"], c["W"] // 2, 4 + c["num_classes"] + c["num_instances"]
     acts = 2 * (64 + 32 + (D + 1) * W + 3 * H)
     gates = (D * W + 3 * H) // 8
     dys = 2 * ((D + 1) * W + 3 * H + 160)
-    return (acts + gates + 4 * ch) + (gates + 4 * ch + dys) + (acts + dys + 3 * 2 * W)
+    h_rereads = 2 if (c["num_classes"] and c["num_instances"]) else (2 if (c["num_classes"] or c["num_instances"]) else 1)
+    return (acts + gates + 4 * ch) + (gates + 4 * ch + dys) + (acts + dys + h_rereads * 2 * W)
 
 
 def main():
@@ -533,14 +535,14 @@ def main():
                     hits = ops.bbox_hits(rc, box, cfg.max_hits if hasattr(cfg, "max_hits") else 8)
                     ls, li = ops.sample_labels(zz, hits[0], hits[1], hits[2], ids)
                     ls, li = (ls if N_SEM else None), (li if N_INST else None)
-                cms = event_ms(lambda: ops.composite(rw, zz, rc, N_SEM, N_INST, True, None, ls, li, 0, False, want_w), 5)
+                cms = event_ms(lambda: ops.composite(rw, zz, rc, N_SEM, N_INST, True, None, ls, li, 0, False, want_w), 20, 3)
                 bytes_ray = composite_bytes_per_ray(N, N_SEM, N_INST, c["bbox"] and (N_SEM or N_INST), want_w)
                 gbs = Rc * bytes_ray / (cms * 1e-3) / 1e9
                 read_gbs = benchlib.probe_raw_read(rw, Rc, N, 5)     # same image, same order, no arithmetic
                 out = {"kernel": "k_composite<channel-major> (%s, N=%d, %d channels)" % (tag, N, ch), "bound": "hbm",
                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                        "traffic": traffic("k_composite", Rc, args.config) if N == 192 else None,
-                       "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray, "timing": "hipEvents around 5 launches",
+                       "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray, "timing": "hipEvents around 20 back-to-back launches",
                        "note": "training / two-kernel path only: the fused inference step does not launch it"}
                 # the pure-read probe walks the image 4 samples per lane; it is a ceiling only where that mapping is the kernel's
                 if read_gbs > gbs:

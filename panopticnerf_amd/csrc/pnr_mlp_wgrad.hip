@@ -63,13 +63,18 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 #endif
 #define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
 static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && WG_NBUF * 2 * WG_TILE_BYTES <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
+#ifndef WG_STACK_HEADS
+#define WG_STACK_HEADS 1            /* sem0 + inst0 as one stacked-dY job (A/B knob) */
+#endif
 #define WG_MAX_JOBS 24
 #define WG_BIAS_COLS 32             /* partial block: [ma][nb + 32], column nb = row sum (bias gradient) */
 
 struct WgJob {
     int64_t a_off, b_off;           // element offsets of the dY region (in dys) and the X region (in acts)
+    int64_t a2_off;                 // -1, or a SECOND dY region of the same width stacked under the first (rows ma/2 .. ma-1):
+                                    // two layers that read the same X (the semantic and instance heads' first Linear) in one pass
     int64_t p_off;                  // float offset of this job's partials: [n_slabs][ma][nb + WG_BIAS_COLS]
-    int ma, nb;                     // region widths in slots: 32, 64, 128 or 256
+    int ma, nb;                     // widths in slots: 32, 64, 128 or 256 (ma: both stacked regions together)
 };
 struct WgArgs {
     const uint16_t* acts; const uint16_t* dys;
@@ -120,13 +125,18 @@ constexpr WgGridT wg_grid(int MB, int NB)
 }
 
 // One (job, slab) of shape MB x NB blocks: partial[ma][nb + 32] = sum over the slab's samples of dY^T [X | 1].
-template <int MB, int NB>
+// STACK: the dY tile is two verbatim sub-tiles of MB / 2 row blocks each (WgJob::a2_off), one behind the other in the LDS.
+template <int MB, int NB, bool STACK = false>
 __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const int jb, const int slab, const int lane, const int wave)
 {
     constexpr WgGridT G = wg_grid(MB, NB);
     constexpr int WM = G.wm, WN = G.wn, TM = MB / WM, TN = NB / WN;
-    constexpr int cprA = MB * 4, cprB = NB * 4;                     // 16 B chunks per tile row
-    constexpr int piecesA = WG_KT * cprA / 64, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB;
+    constexpr int MBS = STACK ? MB / 2 : MB;                        // row blocks per dY region
+    constexpr int cprA = MBS * 4, cprB = NB * 4;                    // 16 B chunks per tile row (of one region)
+    constexpr int subA = WG_KT * cprA * 16;                         // bytes of one dY (sub-)tile
+    static_assert(!STACK || (MB % 2 == 0 && TM <= MBS && MBS % TM == 0), "a wave's row blocks lie in one of the stacked regions");
+    constexpr int piecesS = WG_KT * cprA / 64;                      // 1 KiB pieces of one dY (sub-)tile
+    constexpr int piecesA = (STACK ? 2 : 1) * piecesS, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB;
     constexpr int NQ = (pieces + 7) / 8;                            // LDS-DMA pieces per wave and tile (at most)
     constexpr int NKS = WG_KT / 16;
 
@@ -139,6 +149,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     // ---- LDS-DMA: a tile (WG_KT samples of a region) is contiguous in the saved-tensor layout (pnr_mlp_layout.h); it is
     // copied verbatim, 1 KiB (8 lines) per wave instruction.  Rows past S exist (S_pad) and hold zeros in dys.
     const char* const srcA = reinterpret_cast<const char*>(Ag) + lane * 16;
+    const char* const srcA2 = STACK ? reinterpret_cast<const char*>(a.dys + a.job[jb].a2_off) + lane * 16 : srcA;
     const char* const srcB = reinterpret_cast<const char*>(Bg) + lane * 16;
     auto issue = [&](int t, int buf, int q0, int q1) {
         const int64_t g0 = (s_begin + t * WG_KT) >> 3;              // first 8-sample group of the tile
@@ -149,8 +160,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             const int p = wave + 8 * q;
             if (p >= pieces) continue;
             const bool isA = p < piecesA;
-            const int pp = isA ? p : p - piecesA;
-            const char* src = (isA ? srcA + g0 * (cprA * 128) : srcB + g0 * (cprB * 128)) + pp * 1024;
+            const int pp = isA ? p : p - piecesA;                   // LDS side: the sub-tiles of a stacked dY lie back to back
+            const bool second = STACK && isA && p >= piecesS;
+            const char* src = (isA ? (second ? srcA2 : srcA) + g0 * (cprA * 128) : srcB + g0 * (cprB * 128)) + (second ? pp - piecesS : pp) * 1024;
             __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dst + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
         }
     };
@@ -166,7 +178,10 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     const int pos = ((al >> 2) ^ ((gq & 1) << 2)) * 16 + (al & 1) * 8;
     int offA[TM], offB[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) offA[i] = (hi * cprA + (wm * TM + i) * 4 + cin) * 128 + pos;
+    for (int i = 0; i < TM; ++i) {
+        const int blk = wm * TM + i, sub = STACK ? blk / MBS : 0;
+        offA[i] = sub * subA + (hi * cprA + (blk - sub * MBS) * 4 + cin) * 128 + pos;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) offB[j] = (hi * cprB + (wn * TN + j) * 4 + cin) * 128 + pos;
 
@@ -310,6 +325,10 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
 #endif
     // region widths are 32, 64, 128 or 256 slots: one straight-line instance of the loop per shape
     const int shape = (31 - __builtin_clz(a.job[jb].ma >> 5)) * 4 + (31 - __builtin_clz(a.job[jb].nb >> 5));
+    if (a.job[jb].a2_off >= 0) {       // two stacked 128-slot dY regions against one 256-slot X (wg_plan makes no other stack)
+        wg_body<8, 8, true>(a, smem, jb, slab, lane, wave);
+        return;
+    }
     switch (shape) {
 #define WG_CASE(mb, nb) case (mb) * 4 + (nb): wg_body<1 << (mb), 1 << (nb)>(a, smem, jb, slab, lane, wave); break;
         WG_CASE(0, 0) WG_CASE(0, 1) WG_CASE(0, 2) WG_CASE(0, 3)
@@ -374,7 +393,7 @@ static int wg_slab(int64_t S)
     return slab;
 }
 
-struct WgPlan { int n; WgJob job[WG_MAX_JOBS]; WgRed red[WG_MAX_JOBS]; int64_t partial_floats; int slab, n_slabs; };
+struct WgPlan { int n, n_red; WgJob job[WG_MAX_JOBS]; WgRed red[WG_MAX_JOBS]; int64_t partial_floats; int slab, n_slabs; };
 
 // grads: pnr_mlp_params_host whose pointers are DEVICE pointers to the gradients (null for a plan used for sizes only)
 static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host* g, WgPlan& pl)
@@ -386,17 +405,25 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     pl.slab = wg_slab(S);
     pl.n_slabs = (int)((S + pl.slab - 1) / pl.slab);
     pl.n = 0;
+    pl.n_red = 0;
     int64_t po = 0;
     auto F = [](const float* p) { return const_cast<float*>(p); };
+    // a reduction item: rows [row0, row0 + n_rows) of the partial block at p_off -> one weight (and bias) gradient
+    auto add_red = [&](int64_t p_off, int ma, int nb, int row0, int n_rows, int ck, int cL, int n_cols,
+                       float* out, int ld, int col_off, float* out_b) {
+        WgRed& r = pl.red[pl.n_red++];
+        r.p_off = p_off; r.ma = ma; r.nb = nb; r.row0 = row0; r.n_rows = n_rows; r.col_kind = ck; r.col_L = cL; r.n_cols = n_cols;
+        r.out = out; r.ld = ld; r.col_off = col_off; r.out_b = out_b;
+    };
+    auto add_job = [&](int64_t a_off, int64_t a2_off, int ma, int64_t b_off, int nb) {
+        WgJob& j = pl.job[pl.n++];
+        j.a_off = a_off; j.a2_off = a2_off; j.b_off = b_off; j.ma = ma; j.nb = nb; j.p_off = po;
+        po += (int64_t)pl.n_slabs * ma * (nb + WG_BIAS_COLS);
+        return j.p_off;
+    };
     auto add = [&](int64_t a_off, int ma, int64_t b_off, int nb, int row0, int n_rows, int ck, int cL, int n_cols,
                    float* out, int ld, int col_off, float* out_b) {
-        WgJob& j = pl.job[pl.n];
-        j.a_off = a_off; j.b_off = b_off; j.ma = ma; j.nb = nb; j.p_off = po;
-        WgRed& r = pl.red[pl.n];
-        r.p_off = po; r.ma = ma; r.nb = nb; r.row0 = row0; r.n_rows = n_rows; r.col_kind = ck; r.col_L = cL; r.n_cols = n_cols;
-        r.out = out; r.ld = ld; r.col_off = col_off; r.out_b = out_b;
-        po += (int64_t)pl.n_slabs * ma * (nb + WG_BIAS_COLS);
-        ++pl.n;
+        add_red(add_job(a_off, -1, ma, b_off, nb), ma, nb, row0, n_rows, ck, cL, n_cols, out, ld, col_off, out_b);
     };
     const bool have = g != nullptr;
     // trunk
@@ -417,12 +444,20 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     add(dof[4 + D], 32, ao[3 + D], H, 0, 3, PNR_SEG_FEAT, 0, H, have ? F(g->rgb_w) : nullptr, H, 0, have ? F(g->rgb_b) : nullptr);
     add(dof[4 + D], 32, Xh, W, 3, 1, PNR_SEG_FEAT, 0, W, have ? F(g->alpha_w) : nullptr, W, 0, have ? F(g->alpha_b) : nullptr);
     const int64_t Xtap = d.head_tap ? ao[2 + D] : Xh;       // what the heads read: the feature (head_tap 1) or h
+    // the first Linear of both heads reads the same X: one pass over it with the two dY regions stacked (X read once instead
+    // of twice: 512 of the ~13.8 KB a sample costs this kernel).  The stacked shape exists for 128 + 128 rows x 256 only.
+    const bool stack = d.n_sem && d.n_inst && H == 128 && W == 256 && WG_STACK_HEADS;
+    if (stack) {
+        const int64_t p = add_job(dof[2], dof[3], 2 * H, Xtap, W);
+        add_red(p, 2 * H, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
+        add_red(p, 2 * H, W, H, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
+    }
     if (d.n_sem) {
-        add(dof[2], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
+        if (!stack) add(dof[2], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->sem0_w) : nullptr, W, 0, have ? F(g->sem0_b) : nullptr);
         add(dof[5 + D], 64, ao[4 + D], H, 0, d.n_sem, PNR_SEG_FEAT, 0, H, have ? F(g->sem1_w) : nullptr, H, 0, have ? F(g->sem1_b) : nullptr);
     }
     if (d.n_inst) {
-        add(dof[3], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
+        if (!stack) add(dof[3], H, Xtap, W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->inst0_w) : nullptr, W, 0, have ? F(g->inst0_b) : nullptr);
         add(dof[6 + D], 64, ao[5 + D], H, 0, d.n_inst, PNR_SEG_FEAT, 0, H, have ? F(g->inst1_w) : nullptr, H, 0, have ? F(g->inst1_b) : nullptr);
     }
     pl.partial_floats = po;
@@ -452,8 +487,8 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     hipStream_t st = (hipStream_t)stream;
     WgPlan pl;
     wg_plan(*desc, n_samples, grads_dev, pl);
-    PNR_REQUIRE(pl.n <= WG_MAX_JOBS, "pnr_mlp_wgrad: too many jobs");
-    for (int i = 0; i < pl.n; ++i)      // out_b is null by design for the second job of a concatenated weight
+    PNR_REQUIRE(pl.n <= WG_MAX_JOBS && pl.n_red <= WG_MAX_JOBS, "pnr_mlp_wgrad: too many jobs");
+    for (int i = 0; i < pl.n_red; ++i)  // out_b is null by design for the second job of a concatenated weight
         PNR_REQUIRE(pl.red[i].out, "pnr_mlp_wgrad: a weight-gradient pointer of grads_dev is null");
     PNR_REQUIRE(grads_dev->alpha_b && grads_dev->rgb_b && grads_dev->feature_b && grads_dev->views_b,
                 "pnr_mlp_wgrad: a bias-gradient pointer of grads_dev is null");
@@ -472,14 +507,14 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
     WgRedArgs r;
     memset(&r, 0, sizeof(r));
-    r.partial = a.partial; r.n_slabs = pl.n_slabs; r.n_items = pl.n;
+    r.partial = a.partial; r.n_slabs = pl.n_slabs; r.n_items = pl.n_red;
     int maxel = 0;
-    for (int i = 0; i < pl.n; ++i) {
+    for (int i = 0; i < pl.n_red; ++i) {
         r.item[i] = pl.red[i];
         const int el = pl.red[i].n_rows * (pl.red[i].n_cols + 1);
         if (el > maxel) maxel = el;
     }
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((maxel + 255) / 256, pl.n), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((maxel + 255) / 256, pl.n_red), dim3(256), 0, st, r);
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad (reduce)");
     return PNR_OK;
 }

@@ -27,7 +27,7 @@ t, d_raw = T(lambda: ops.composite_backward(raw, z, rays, 45, 32, g)); print(f"c
 t, dys = T(lambda: ops.mlp_backward(desc, img_b, d_raw, acts, R, N)); print(f"mlp_backward (dgrad)   {t:8.3f} ms")
 t, wg = T(lambda: wref.weight_grads(nerf, desc, acts, dys, d_raw, R * N)); print(f"weight_grads (torch)   {t:8.3f} ms")
 shapes = {k: v.shape for k, v in nerf.state_dict().items()}
-t, wk = T(lambda: ops.mlp_wgrad(desc, acts, dys, R * N, shapes)); print(f"pnr_mlp_wgrad (HIP)    {t:8.3f} ms")
+t, wk = T(lambda: ops.mlp_wgrad(desc, acts, dys, R * N, shapes), 20); print(f"pnr_mlp_wgrad (HIP)    {t:8.3f} ms")
 opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 for p in net.parameters(): p.grad = torch.zeros_like(p)
 t, _ = T(lambda: opt.step()); print(f"Adam.step              {t:8.3f} ms")
