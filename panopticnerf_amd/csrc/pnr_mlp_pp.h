@@ -219,6 +219,10 @@ struct CtxPP {
         rf_dst = smem + wrap_slot(slot_off + (2 + grp) * a.slot_bytes);     // Q: chunk ci+3 takes over chunk ci's own slot
         rf_f = wave;
         rf_n = (int)en.nfrag;
+#ifdef PNR_ABL_SKIP_MASK
+        // ablation (results invalid): the chunks of the mask are never refilled -- what a chunk RESIDENT in the LDS would save
+        if ((PNR_ABL_SKIP_MASK >> wrap(ci + 2 + grp)) & 1ull) rf_n = 0;
+#endif
         en = entry(wrap(ci + 3 + grp));
     }
     u32x4 abl_sink;        // PNR_PP_ABL & 16 only
