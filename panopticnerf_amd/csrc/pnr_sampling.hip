@@ -172,8 +172,28 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
         const float total = s_total;
         for (int j = lane; j < nw; j += 64) s_pdf[j] = (s_w[j + 1] + 1e-5f) / total;
         __syncthreads();
-        if (lane == 0) {
-            // torch.cumsum: the running sum is kept in DOUBLE, every output rounded to fp32
+        // torch.cumsum: the running sum is kept in DOUBLE, every output rounded to fp32 -- a sequential chain of nw f64 adds
+        // (with its LDS traffic, half of this kernel's issue cycles when one lane walks it).  The pdf values are fp32 and
+        // non-negative: when every one of them is 0 or >= 2^-28, each is a multiple of 2^-51, and when their sum is < 2 so is
+        // every partial sum of ANY subset -- 52 significant bits at most: no f64 add ever rounds, and a parallel prefix scan
+        // returns the sequential chain's values bit for bit.  (pdf_j >= 1e-5 / total and sum(pdf) ~ 1: always the case for
+        // compositing weights; the sum is checked on the scan's own result, which is exact whenever the true sum is < 2.)
+        // Otherwise, and for more than 64 values, the sequential chain runs.
+        const float pl = lane < nw ? s_pdf[lane < nw ? lane : 0] : 0.0f;
+        double c = (double)pl;
+        bool exact = nw <= 64 && __all(pl == 0.0f || pl >= 0x1p-28f);
+        if (exact) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double o = __shfl_up(c, d, 64);
+                if (lane >= d) c += o;
+            }
+            exact = __shfl(c, 63, 64) < 1.999;
+        }
+        if (exact) {
+            if (lane == 0) s_cdf[0] = 0.0f;
+            if (lane < nw) s_cdf[lane + 1] = (float)c;
+        } else if (lane == 0) {
             double c = 0.0;
             s_cdf[0] = 0.0f;
             for (int j = 0; j < nw; ++j) {
