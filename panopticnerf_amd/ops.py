@@ -70,8 +70,17 @@ def gen_rays(intr, c2w, width, height, near, far, pix=None, device=None):
     return rays
 
 
+def _own(out, shape, dtype, dev, what):
+    """`out` (a caller-owned tensor: checked) or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, device=dev, dtype=dtype)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise ValueError("%s: out must be a contiguous %s tensor of shape %s on %s" % (what, dtype, tuple(shape), dev))
+    return out
+
+
 @_on_device
-def stratified(rays, n_samples, lindisp=False, t_rand=None):
+def stratified(rays, n_samples, lindisp=False, t_rand=None, out=None):
     """rays (R,8) -> z (R,N).  SURVEY 8a row a3."""
     rays = _chk(rays, "rays")
     t_rand = _chk(t_rand, "t_rand")
@@ -79,7 +88,7 @@ def stratified(rays, n_samples, lindisp=False, t_rand=None):
     assert rays.shape[-1] == 8
     if t_rand is not None:
         assert tuple(t_rand.shape) == (R, n_samples)
-    z = torch.empty((R, n_samples), device=rays.device, dtype=torch.float32)
+    z = _own(out, (R, n_samples), torch.float32, rays.device, "stratified")
     lib = _lib.load()
     _lib.check(lib.pnr_stratified(_p(rays), R, n_samples, int(bool(lindisp)), _p(t_rand), _p(z), _stream()),
                "pnr_stratified")
@@ -323,8 +332,8 @@ def mlp_variant(variant=None):
 
 @_on_device
 def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, label_sem=None, label_inst=None,
-              sem_mode=0, white_bkgd=False, want_weights=True):
-    """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps."""
+              sem_mode=0, white_bkgd=False, want_weights=True, out=None):
+    """raw2outputs.  SURVEY 8a row a6.  Returns dict of maps (out: optional caller-owned tensors, see _maps)."""
     z, rays = _chk(z, "z"), _chk(rays, "rays")
     noise = _chk(noise, "noise")
     label_sem = _chk(label_sem, "label_sem", torch.int32)
@@ -338,18 +347,7 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
         assert tuple(raw.shape) == (R, N, ch)
         ss, sc = ch, 1
     dev = z.device
-    f32 = dict(device=dev, dtype=torch.float32)
-    out = {"rgb": torch.empty((R, 3), **f32), "depth": torch.empty((R,), **f32), "acc": torch.empty((R,), **f32)}
-    if want_weights:
-        out["weights"] = torch.empty((R, N), **f32)
-    if n_sem:
-        out["semantic"] = torch.empty((R, n_sem), **f32)
-        if label_sem is not None:
-            out["fix_semantic"] = torch.empty((R, n_sem), **f32)
-    if n_inst:
-        out["instance"] = torch.empty((R, n_inst), **f32)
-        if label_inst is not None:
-            out["fix_instance"] = torch.empty((R, n_inst), **f32)
+    out = _maps(out, R, N, n_sem, n_inst, label_sem, label_inst, want_weights, dev)
     g = out.get
     _lib.check(_lib.load().pnr_composite(_p(raw), ss, sc, _p(z), _p(rays), _p(noise), _p(label_sem), _p(label_inst),
                                          R, N, n_sem, n_inst, int(sem_mode), int(bool(white_bkgd)),
@@ -359,6 +357,33 @@ def composite(raw, z, rays, n_sem=0, n_inst=0, channel_major=True, noise=None, l
     return out
 
 
+def _maps(out, R, N, n_sem, n_inst, label_sem, label_inst, want_weights, dev):
+    """The per-ray output tensors of a compositing call.  `out`: optional dict of caller-owned tensors (e.g. row slices of
+    frame-sized maps: Renderer.render hands every chunk its slice, so a frame is never concatenated); anything it lacks is
+    allocated.  Caller-owned tensors must be contiguous fp32 of the exact shape on the right device."""
+    f32 = dict(device=dev, dtype=torch.float32)
+    shapes = {"rgb": (R, 3), "depth": (R,), "acc": (R,)}
+    if want_weights:
+        shapes["weights"] = (R, N)
+    if n_sem:
+        shapes["semantic"] = (R, n_sem)
+        if label_sem is not None:
+            shapes["fix_semantic"] = (R, n_sem)
+    if n_inst:
+        shapes["instance"] = (R, n_inst)
+        if label_inst is not None:
+            shapes["fix_instance"] = (R, n_inst)
+    res = {}
+    for k, shp in shapes.items():
+        t = out.get(k) if out else None
+        if t is None:
+            t = torch.empty(shp, **f32)
+        elif tuple(t.shape) != shp or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+            raise ValueError("out[%r] must be a contiguous fp32 tensor of shape %s on %s" % (k, shp, dev))
+        res[k] = t
+    return res
+
+
 def fused_supported(desc, n_samples, sem_mode=0, noise=None):
     """Can pnr_mlp_forward_composite take this level?  bf16, logits compositing, no sigma noise, N a multiple of 32."""
     return (desc.precision == _lib.PREC_BF16 and int(sem_mode) == 0 and noise is None and n_samples % 32 == 0
@@ -366,7 +391,7 @@ def fused_supported(desc, n_samples, sem_mode=0, noise=None):
 
 
 @_on_device
-def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True):
+def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True, out=None):
     """Rows a5 + a6 in one pass (inference): the fused MLP reduces every 32-sample tile to one compositing record in its
     epilogue and k_composite_combine finishes the rays -- the raw image (324 B per sample at 45 / 32 heads) is never
     written.  Same dict as composite().  Sums are associated per tile, so results equal mlp_forward + composite to fp32
@@ -382,18 +407,7 @@ def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None
     if nbytes < 0:
         raise RuntimeError("pnr_mlp_forward_composite: unsupported geometry (n_samples=%d must be a multiple of 32)" % N)
     ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
-    f32 = dict(device=dev, dtype=torch.float32)
-    out = {"rgb": torch.empty((R, 3), **f32), "depth": torch.empty((R,), **f32), "acc": torch.empty((R,), **f32)}
-    if want_weights:
-        out["weights"] = torch.empty((R, N), **f32)
-    if n_sem:
-        out["semantic"] = torch.empty((R, n_sem), **f32)
-        if label_sem is not None:
-            out["fix_semantic"] = torch.empty((R, n_sem), **f32)
-    if n_inst:
-        out["instance"] = torch.empty((R, n_inst), **f32)
-        if label_inst is not None:
-            out["fix_instance"] = torch.empty((R, n_inst), **f32)
+    out = _maps(out, R, N, n_sem, n_inst, label_sem, label_inst, want_weights, dev)
     g = out.get
     _lib.check(lib.pnr_mlp_forward_composite(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(label_sem), _p(label_inst),
                                              int(bool(white_bkgd)), _p(out["rgb"]), _p(out["depth"]), _p(out["acc"]),
@@ -474,13 +488,13 @@ def ce3d(raw, first_channel, n_classes, label):
 
 
 @_on_device
-def sample_pdf(z, weights, n_importance, u=None, want_samples=True):
+def sample_pdf(z, weights, n_importance, u=None, want_samples=True, out=None):
     """Coarse z, weights (R,Nc) -> z_fine (R,Nc+Nf) sorted [, z_samples (R,Nf), inds (R,Nf)].
     SURVEY 8a row a7."""
     z, weights, u = _chk(z, "z"), _chk(weights, "weights"), _chk(u, "u")
     R, Nc = z.shape
     dev = z.device
-    z_fine = torch.empty((R, Nc + n_importance), device=dev, dtype=torch.float32)
+    z_fine = _own(out, (R, Nc + n_importance), torch.float32, dev, "sample_pdf")
     zs = inds = None
     if want_samples:
         zs = torch.empty((R, n_importance), device=dev, dtype=torch.float32)

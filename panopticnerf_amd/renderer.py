@@ -51,13 +51,18 @@ class Renderer:
         if self.bbox_sampling not in ("none", "hull"):
             raise ValueError("cfg.bbox_sampling must be 'none' or 'hull', not %r" % (self.bbox_sampling,))
         self._overflow = None
+        # inference frames of several chunks are written into frame-sized maps chunk by chunk (no concatenation at the end);
+        # cfg.frame_outputs = False (or PNR_FRAME_OUT=0) restores per-chunk maps + torch.cat
+        self.frame_outputs = bool(_get(cfg, "frame_outputs", os.environ.get("PNR_FRAME_OUT", "1") != "0"))
         if self.N_importance > 0 and getattr(net, "nerf_1", None) is None and not getattr(net, "share_coarse_fine", False):
             raise ValueError("make_renderer: cfg asks for a fine pass (N_importance / cascade_samples = %d) but the network "
                              "was built without a fine NeRF -- build it with make_network(cfg) from the SAME cfg, or set "
                              "cfg.share_coarse_fine = True to evaluate one NeRF at both levels on purpose" % self.N_importance)
 
     # --- one chunk of rays: the reference's render_rays (row a2)
-    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False):
+    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False, out=None):
+        """out: optional {output key: caller-owned tensor of this chunk's shape} (inference only) -- render() passes row slices
+        of the frame-sized maps, so the chunks of a frame are never concatenated."""
         net, Nc, Nf = self.net, self.N_samples, self.N_importance
         n0 = net.nerf(0)
         C, K = n0.n_sem, n0.n_inst
@@ -73,7 +78,8 @@ class Renderer:
         if t_rand is None and self.perturb > 0 and train:
             t_rand = torch.rand((rays.shape[0], Nc), device=dev)
         rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and self.bbox_sampling == "hull") else rays
-        z = ops.stratified(rays_s, Nc, self.lindisp, t_rand)
+        own = (lambda key: out.get(key)) if (out and not grad) else (lambda key: None)
+        z = ops.stratified(rays_s, Nc, self.lindisp, t_rand, out=own("z_vals_0"))
 
         def level(lv, zz):
             ls = li = None
@@ -84,27 +90,29 @@ class Renderer:
                 noise = torch.randn(zz.shape, device=dev) * self.raw_noise_std
             if grad:
                 from . import train as _train       # autograd path
-                out = _train.level_train(self, lv, rays, zz, ls, li, noise)
+                res = _train.level_train(self, lv, rays, zz, ls, li, noise)
             else:
                 need_w = self.keep_weights or (lv == 0 and Nf > 0)
+                mine = {k: own(f"{k}_{lv}") for k in ("rgb", "depth", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance")}
+                mine = {k: v for k, v in mine.items() if v is not None}
                 if self.fuse and ops.fused_supported(net.nerf(lv).desc(net.precision), zz.shape[1], self.sem_mode, noise):
                     # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite, its own chunk order)
                     desc, img = net.packed(lv, dev, fused=True)
-                    out = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w)
+                    res = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w, out=mine)
                 else:
                     desc, img = net.packed(lv, dev)
                     raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
-                    out = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w)
-            for k, v in out.items():
+                    res = ops.composite(raw, zz, rays, C, K, True, noise, ls, li, self.sem_mode, self.white_bkgd, need_w, out=mine)
+            for k, v in res.items():
                 ret[f"{k}_{lv}"] = v
             ret[f"z_vals_{lv}"] = zz
-            return out
+            return res
 
         o0 = level(0, z)
         if Nf > 0:
             if u is None and self.perturb > 0 and train:
                 u = torch.rand((rays.shape[0], Nf), device=dev)
-            z_fine, _, _ = ops.sample_pdf(z, o0["weights"].detach().contiguous(), Nf, u, want_samples=False)
+            z_fine, _, _ = ops.sample_pdf(z, o0["weights"].detach().contiguous(), Nf, u, want_samples=False, out=own("z_vals_1"))
             level(1, z_fine)
         return ret
 
@@ -132,17 +140,30 @@ class Renderer:
         train = self.net.training
         self._overflow = None
         outs = []
+        frame = None        # inference frames of several chunks: frame-sized maps, every later chunk writes its own rows
         for s in range(0, R, self.chunk_size):
             e = min(R, s + self.chunk_size)
-            outs.append(self.render_rays(rays[s:e], box, box_ids,
-                                         None if t_rand is None else t_rand[s:e],
-                                         None if u is None else u[s:e], train, grad))
+            o = self.render_rays(rays[s:e], box, box_ids,
+                                 None if t_rand is None else t_rand[s:e],
+                                 None if u is None else u[s:e], train, grad,
+                                 out=None if frame is None else {k: v[s:e] for k, v in frame.items()})
+            if s == 0 and e < R and not grad and self.frame_outputs and all(v.dim() >= 1 and v.shape[0] == e for v in o.values()):
+                frame = {k: torch.empty((R,) + tuple(v.shape[1:]), device=v.device, dtype=v.dtype) for k, v in o.items()}
+                for k, v in o.items():
+                    frame[k][:e].copy_(v)
+            elif frame is not None:
+                for k, v in o.items():      # anything a chunk did not write in place (an output without an out= route)
+                    if v.data_ptr() != frame[k][s:e].data_ptr():
+                        frame[k][s:e].copy_(v)
+            outs.append(o)
         if self._overflow is not None:
             n_over, worst = (int(v) for v in self._overflow.tolist())         # the one device sync of strict_hits
             self._overflow = None
             if n_over > 0:
                 raise RuntimeError("Renderer.render: %d ray(s) cross more than max_hits = %d boxes (up to %d): the farthest "
                                    "intervals were dropped -- raise cfg.max_hits" % (n_over, self.max_hits, worst))
+        if frame is not None:
+            return {k: v.reshape(*lead, *v.shape[1:]) for k, v in frame.items()}
         ret = {}
         for k in outs[0]:
             if outs[0][k].dim() == 0:

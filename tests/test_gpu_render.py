@@ -9,7 +9,7 @@ import torch
 
 from oracle import c_oracle as co
 from oracle import torch_oracle as to
-from panopticnerf_amd import make_network, make_renderer, synthetic
+from panopticnerf_amd import make_network, make_renderer, ops, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -247,3 +247,23 @@ def test_strict_hits_reports_overflow_once_per_render(dev):
             make_renderer(NS(strict_hits=True, **cfg), net).render(batch)
         big = dict(cfg, max_hits=64)
         make_renderer(NS(strict_hits=True, **big), net).render(batch)        # room for every box: no complaint
+
+
+def test_chunked_frame_is_written_in_place_and_equals_one_chunk(dev):
+    # a frame of several chunks (ragged last one) is rendered into frame-sized maps, chunk by chunk, without concatenation:
+    # every key equals the one-chunk render bit for bit; ops refuse a caller-owned output of the wrong shape
+    C, K = 5, 3
+    cfg, net, oc, params = _setup(dev, C, K, "bf16", chunk_size=4096)
+    rays = synthetic.camera_rays()[::53][:1000].contiguous()
+    box, ids = synthetic.random_boxes(16, C, K)
+    b = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    with torch.no_grad():
+        one = make_renderer(cfg, net).render(b)
+        cfg.chunk_size = 384
+        many = make_renderer(cfg, net).render(b)
+    assert set(one) == set(many)
+    for k in one:
+        assert one[k].shape == many[k].shape and torch.equal(one[k], many[k]), k
+    with pytest.raises(ValueError):
+        ops.stratified(rays.to(dev), 64, out=torch.empty((999, 64), device=dev))
+
