@@ -163,6 +163,28 @@ def test_sample_pdf_bitexact(dev, Nc, Nf):
         assert np.array_equal(N_(zf), co.merge_sorted(z, zs_c))
 
 
+@pytest.mark.parametrize("Nc", [64, 66, 67, 128])
+def test_sample_pdf_cdf_paths_bitexact(dev, Nc):
+    # the CDF is torch's sequential f64 running sum; the kernel runs it as a parallel scan only where that is provably the
+    # same bits (<= 64 pdf values, each 0 or >= 2^-28, sum < 2) and in order otherwise: weights that leave the exact regime
+    # (one huge weight -> pdf values below 2^-28; denormal / 1e-30 weights; more than 64 values) must still match the C oracle
+    rng = np.random.default_rng(Nc)
+    R, Nf = 260, 96
+    rays = _rays(rng, R)
+    z = co.stratified(rays, Nc, t_rand=rng.random((R, Nc)).astype(np.float32))
+    w = rng.uniform(0, 1, (R, Nc)).astype(np.float32)
+    w[0::5, 7] = 3.0e4          # pdf of the floor = 1e-5 / 3e4 = 3e-10 < 2^-28: sequential path
+    w[1::5] = 1.0e-30           # all at the 1e-5 floor: uniform pdf
+    w[2::5, ::2] = 0.0
+    w[3::5, 3] = 1.0e9
+    u = rng.random((R, Nf)).astype(np.float32)
+    for uu in (None, u):
+        zf, zs, inds = ops.sample_pdf(T(z, dev), T(w, dev), Nf, None if uu is None else T(uu, dev))
+        zs_c, inds_c = co.sample_pdf(z, w, Nf, uu)
+        assert np.array_equal(N_(inds), inds_c) and np.array_equal(N_(zs), zs_c)
+        assert np.array_equal(N_(zf), co.merge_sorted(z, zs_c))
+
+
 def test_sample_pdf_golden(dev, golden):
     g = golden
     Nf = int(g["dims"][2])
