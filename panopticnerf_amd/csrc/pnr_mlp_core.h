@@ -248,11 +248,9 @@ struct Ctx {
     // L2 -> LDS copy of a chunk into slot `sl` (asynchronous LDS-DMA, 1 KiB per wave-instruction)
     __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int sl) const
     {
-        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
+        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES;
         char* dst = smem + sl * a.slot_bytes;
-        for (int f = wave; f < (int)e.nfrag; f += WAVES)
-            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
-                                             (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
+        for (int f = wave; f < (int)e.nfrag; f += WAVES) pnr_dma_piece(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
     }
     __device__ __forceinline__ void start()
     {

@@ -99,6 +99,8 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #ifndef PNR_PP_ABL
 #define PNR_PP_ABL 0
 #endif
+
+
 template <int WAVES>
 struct CtxPP {
     static constexpr int P = PNR_PP_RING;
@@ -137,11 +139,9 @@ struct CtxPP {
     // this wave's share (fragments wave, wave + WAVES, ...) of a chunk: L2 -> LDS, asynchronous
     __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int off) const
     {
-        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES + lane * 16;
+        const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES;
         char* dst = smem + off;
-        for (int f = wave; f < (int)e.nfrag; f += WAVES)
-            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)f * PNR_FRAG_BYTES),
-                                             (lds_void*)(dst + f * PNR_FRAG_BYTES), 16, 0, 0);
+        for (int f = wave; f < (int)e.nfrag; f += WAVES) pnr_dma_piece(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
     }
     __device__ __forceinline__ void barrier() const
     {
@@ -210,12 +210,14 @@ struct CtxPP {
     // epilogue's VALU work between the pieces: a wave blocks while the CU's LDS-DMA queue is full (100-200 cycles per
     // 1 KiB piece beside the partner's MFMA/ds_read stream), and the VALU work runs in exactly those gaps.
     const uint8_t* rf_src;
+    const uint8_t* rf_base;        // the wave-uniform part of rf_src: what the pieces address (pnr_dma_piece)
     char* rf_dst;
     int rf_f, rf_n;
     __device__ __forceinline__ void refill_begin()
     {
         stamp(0);
-        rf_src = a.data + (size_t)en.off_frag * PNR_FRAG_BYTES + lane * 16;
+        rf_base = a.data + (size_t)en.off_frag * PNR_FRAG_BYTES;
+        rf_src = rf_base + lane * 16;
         rf_dst = smem + wrap_slot(slot_off + (2 + grp) * a.slot_bytes);     // Q: chunk ci+3 takes over chunk ci's own slot
         rf_f = wave;
         rf_n = (int)en.nfrag;
@@ -233,8 +235,7 @@ struct CtxPP {
         const uint8_t* src = rf_src + (size_t)f * PNR_FRAG_BYTES;
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(abl_sink) : "v"(src) : "memory");
 #else
-        __builtin_amdgcn_global_load_lds((const void*)(rf_src + (size_t)f * PNR_FRAG_BYTES),
-                                         (lds_void*)(rf_dst + f * PNR_FRAG_BYTES), 16, 0, PNR_PP_DMA_AUX);
+        pnr_dma_piece<PNR_PP_DMA_AUX>(rf_base + (size_t)f * PNR_FRAG_BYTES, rf_dst + f * PNR_FRAG_BYTES, lane * 16);
 #endif
     }
     __device__ __forceinline__ void refill_one()

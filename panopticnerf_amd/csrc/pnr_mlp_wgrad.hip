@@ -148,9 +148,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
 
     // ---- LDS-DMA: a tile (WG_KT samples of a region) is contiguous in the saved-tensor layout (pnr_mlp_layout.h); it is
     // copied verbatim, 1 KiB (8 lines) per wave instruction.  Rows past S exist (S_pad) and hold zeros in dys.
-    const char* const srcA = reinterpret_cast<const char*>(Ag) + lane * 16;
-    const char* const srcA2 = STACK ? reinterpret_cast<const char*>(a.dys + a.job[jb].a2_off) + lane * 16 : srcA;
-    const char* const srcB = reinterpret_cast<const char*>(Bg) + lane * 16;
+    const char* const srcA = reinterpret_cast<const char*>(Ag);         // wave-uniform bases: pnr_dma_piece adds 16 * lane
+    const char* const srcA2 = STACK ? reinterpret_cast<const char*>(a.dys + a.job[jb].a2_off) : srcA;
+    const char* const srcB = reinterpret_cast<const char*>(Bg);
     auto issue = [&](int t, int buf, int q0, int q1) {
         const int64_t g0 = (s_begin + t * WG_KT) >> 3;              // first 8-sample group of the tile
         char* const dst = smem + buf * 2 * WG_TILE_BYTES;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             const int pp = isA ? p : p - piecesA;                   // LDS side: the sub-tiles of a stacked dY lie back to back
             const bool second = STACK && isA && p >= piecesS;
             const char* src = (isA ? (second ? srcA2 : srcA) + g0 * (cprA * 128) : srcB + g0 * (cprB * 128)) + (second ? pp - piecesS : pp) * 1024;
-            __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(dst + (isA ? 0 : WG_TILE_BYTES) + pp * 1024), 16, 0, WG_DMA_AUX);
+            pnr_dma_piece<WG_DMA_AUX>(src, dst + (isA ? 0 : WG_TILE_BYTES) + pp * 1024, lane * 16);
         }
     };
 

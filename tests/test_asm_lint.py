@@ -95,3 +95,28 @@ def test_mlp_kernels_never_touch_a_pending_lds_destination(tmp_path):
         assert all(op.startswith("global_load_dword") and "lds" not in op for op in vmem), vmem
         assert len(vmem) == want, (b, vmem, want)
         assert not any(op.startswith("s_cbranch") or op.startswith("s_branch") for op in body), "straight-line code between the markers"
+
+
+def _m0_accesses(text):
+    """(lines that write M0 with pnr_dma_piece's own s_mov, every other line that mentions m0) of an assembly listing."""
+    code = [l.split(";")[0].strip() for l in text]
+    mine = [l for l in code if re.match(r"s_mov_b32\s+m0,\s*s\d+$", l)]
+    other = [l for l in code if re.search(r"\bm0\b", l) and l not in mine]
+    return mine, other
+
+
+@pytest.mark.parametrize("name", ["pnr_mlp.hip", "pnr_mlp_bwd.hip", "pnr_mlp_wgrad.hip"])
+def test_the_dma_helper_is_the_only_user_of_m0(tmp_path, name):
+    # pnr_dma_piece (pnr_common.h) writes M0 inside inline asm.  M0 is reserved in the AMDGPU backend -- an asm clobber is
+    # ignored -- so this is only safe while the compiler itself never keeps a value in M0 in these objects (LDS-DMA builtins,
+    # v_movrel register indexing, s_sendmsg, ...): every access must be the helper's own s_mov, each directly followed by its
+    # LDS-DMA load in the scalar-base form.
+    text = _asm(tmp_path, name)
+    mine, other = _m0_accesses(text)
+    assert len(mine) >= 20 and other == [], other[:5]
+    code = [l.split(";")[0].strip() for l in text if l.split(";")[0].strip()]
+    for i, l in enumerate(code):
+        if l in mine:
+            assert code[i + 1].startswith("s_nop") and re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", code[i + 2]), code[i:i + 3]
+    assert not any(l.startswith("global_load_lds_dwordx4 v[") for l in code), "a per-lane 64-bit address crept back in"
+
