@@ -58,6 +58,11 @@ __device__ __forceinline__ int pnr_div_magic(int x, uint32_t magic, int shift)
 #ifndef PNR_ABL_NODMA
 #define PNR_ABL_NODMA 0
 #endif
+#ifndef PNR_CORE_DMA_AUX
+#define PNR_CORE_DMA_AUX 0      /* cache policy of the lock-step kernels' weight pieces (training forward, data-gradient pass): nt, which the
+                                   inference kernel gains 0.9 % from, costs the training forward +15 % (1.58 -> 1.82 ms) -- its write stream
+                                   sweeps the L2 and non-temporal weight lines go first */
+#endif
 // One 32-row block's share of lane (n, hi) -- 16 slots = chunks fb*4 + hi*2 + {0, 1} -- of padded sample row s into a
 // saved region (pnr_mlp_layout.h: the two chunks sit in neighbouring lines at the same position).  Unmasked: rows
 // S..S_pad are written as well.
@@ -250,7 +255,7 @@ struct Ctx {
     {
         const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES;
         char* dst = smem + sl * a.slot_bytes;
-        for (int f = wave; f < (int)e.nfrag; f += WAVES) pnr_dma_piece(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
+        for (int f = wave; f < (int)e.nfrag; f += WAVES) pnr_dma_piece<PNR_CORE_DMA_AUX>(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
     }
     __device__ __forceinline__ void start()
     {

@@ -81,9 +81,11 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #ifndef PNR_PP_PRIO
 #define PNR_PP_PRIO 1        /* s_setprio of the M phase: +1 % measured */
 #endif
-// cache policy bits of the refill's global_load_lds (0 = default, 1 = sc0, 2 = nt)
+// cache policy of the refill's LDS-DMA pieces (0 = default, 1 = sc0, 2 = nt).  Round 3, on the scalar-base pieces, same box,
+// two passes: default 11.079 / 11.065 ms @1795-1805 MHz, sc0 11.071 / 11.072, nt 10.985 / 10.992 @1818-1840 (-0.75 %, and
+// at a higher clock: less power) -> nt.  (Rounds 1-2, per-lane-pointer pieces: nt was +1 % -- re-measured, not assumed.)
 #ifndef PNR_PP_DMA_AUX
-#define PNR_PP_DMA_AUX 0
+#define PNR_PP_DMA_AUX 2
 #endif
 // timing-only ablations (A/B builds; results are wrong): 1 = no refill pieces, 2 = no fragment reads inside the MFMA loop
 // 1: the first fragments of a layer's 2nd, 3rd, ... chunk are read right after the previous chunk's M -> L barrier
