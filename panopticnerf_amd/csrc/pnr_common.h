@@ -61,7 +61,12 @@ static inline int pnr_grid_cap(int64_t wanted, int per_cu = 8)
 template <int AUX = 0>
 __device__ __forceinline__ void pnr_dma_piece(const void* src, void* dst, int lane16)
 {
-    const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dst;
+    // readfirstlane: a no-op on values the compiler already knows to be wave-uniform, and what keeps the "s" operands legal
+    // where its divergence analysis cannot prove it (e.g. -DPNR_TRACE builds); the CALLER guarantees uniformity either way
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dst);
+    const uint64_t sa = (uint64_t)(uintptr_t)src;
+    src = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa));
     if constexpr (AUX == 2)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(lane16), "s"(src), "s"(m0v) : "memory");
     else if constexpr (AUX == 1)
