@@ -152,8 +152,12 @@ class Network(nn.Module):
         (r"\.(instance_linear|instance_head)\.(\d+)\.", r".instance_linears.\2."),
     )
 
-    def load_reference_state_dict(self, sd, key_map=None, strict=True):
-        """Load a reference checkpoint's network state_dict.  key_map: sequence of (regex, replacement) applied in order
+    def load_reference_state_dict(self, sd, key_map=None, strict=True, skip_concat="input_first", views_concat="feature_first"):
+        """Load a reference checkpoint's network state_dict.  skip_concat / views_concat: the order in which the REFERENCE
+        concatenates the inputs of the skip layer and of the view layer (`cat(gamma(x), h)` vs
+        `cat(h, gamma(x))`, `cat(feature, gamma(d))` vs `cat(gamma(d), feature)` -- unverifiable here).  This network is
+        "input_first" / "feature_first" (canonical NeRF); for "hidden_first" / "dir_first" the columns of those two weights
+        are rotated on load, which is the whole difference.  key_map: sequence of (regex, replacement) applied in order
         to every key (default: DEFAULT_KEY_MAP -- guesses at the reference's naming; the real names
         cannot be checked here, pass the right table once they can).  Shapes must match exactly: a (out,in) weight of
         the wrong size is an error, never a silent reshape.  Returns {'loaded': [...], 'missing': [...],
@@ -168,7 +172,7 @@ class Network(nn.Module):
             if nk in own:
                 if tuple(v.shape) != tuple(own[nk].shape):
                     raise ValueError(f"{k} -> {nk}: shape {tuple(v.shape)} != {tuple(own[nk].shape)}")
-                mapped[nk] = v
+                mapped[nk] = self._concat_order(nk, v, skip_concat, views_concat)
             else:
                 unexpected.append(k)
         missing = [k for k in own if k not in mapped]
@@ -178,6 +182,23 @@ class Network(nn.Module):
         self.load_state_dict(mapped, strict=False)
         self.invalidate_packed()             # the packed images are rebuilt from the new parameters
         return {"loaded": sorted(mapped), "missing": missing, "unexpected": unexpected}
+
+    def _concat_order(self, name, w, skip_concat, views_concat):
+        """Columns of a reference weight in this network's order (see load_reference_state_dict)."""
+        if skip_concat not in ("input_first", "hidden_first") or views_concat not in ("feature_first", "dir_first"):
+            raise ValueError("skip_concat: 'input_first' | 'hidden_first'; views_concat: 'feature_first' | 'dir_first'")
+        m = name.split(".")
+        if len(m) < 3 or m[-1] != "weight":
+            return w
+        nerf = getattr(self, m[0], None)
+        if nerf is None:
+            return w
+        if skip_concat == "hidden_first" and m[1] == "pts_linears" and nerf.skip >= 0 and int(m[2]) == nerf.skip + 1:
+            return torch.cat([w[:, nerf.W:], w[:, :nerf.W]], 1)          # [h | gamma(x)] -> [gamma(x) | h]
+        if views_concat == "dir_first" and m[1] == "views_linears":
+            ed = w.shape[1] - nerf.W
+            return torch.cat([w[:, ed:], w[:, :ed]], 1)                  # [gamma(d) | feature] -> [feature | gamma(d)]
+        return w
 
     def forward(self, *a, **k):
         raise RuntimeError("Network is evaluated by Renderer.render() through the fused HIP kernel; "

@@ -230,6 +230,32 @@ def test_reference_checkpoint_key_map():
     assert rep["missing"] and all(m.startswith("nerf_1.") for m in rep["missing"])
 
 
+def test_reference_checkpoint_concat_order_switches():
+    """a checkpoint of a network that concatenates [h, gamma(x)] at the skip layer and [gamma(d), feature] at
+    the view layer loads into this ([gamma(x), h] / [feature, gamma(d)]) network with the columns rotated -- and only those."""
+    cfg = NS(D=4, W=128, skips=[1], num_classes=3, N_importance=8)
+    src, dst = make_network(cfg), make_network(cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.normal_()
+    W, ex, ed = 128, 63, 27
+    ref = {k: v.clone() for k, v in src.state_dict().items()}
+    for lv in ("nerf_0", "nerf_1"):
+        k = f"{lv}.pts_linears.2.weight"                  # the layer behind skip = 1: 63 + 128 columns
+        assert ref[k].shape == (W, ex + W)
+        ref[k] = torch.cat([ref[k][:, ex:], ref[k][:, :ex]], 1)            # what a [h | gamma(x)] reference would hold
+        k = f"{lv}.views_linears.0.weight"
+        ref[k] = torch.cat([ref[k][:, W:], ref[k][:, :W]], 1)              # [gamma(d) | feature]
+    rep = dst.load_reference_state_dict(ref, key_map=(), skip_concat="hidden_first", views_concat="dir_first")
+    assert not rep["missing"] and not rep["unexpected"]
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    dst.load_reference_state_dict(ref, key_map=())        # default order: those two weights differ, nothing else
+    diff = [k for k, a, b in zip(src.state_dict(), src.state_dict().values(), dst.state_dict().values()) if not torch.equal(a, b)]
+    assert sorted(diff) == sorted(f"{lv}.{n}" for lv in ("nerf_0", "nerf_1") for n in ("pts_linears.2.weight", "views_linears.0.weight"))
+    with pytest.raises(ValueError):
+        dst.load_reference_state_dict(ref, key_map=(), skip_concat="sideways")
+
+
 # ----------------------------------------------------------------------------- bench.py launch contract (SURVEY.md 8e)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
