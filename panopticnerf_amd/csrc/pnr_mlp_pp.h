@@ -84,6 +84,7 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 // cache policy of the refill's LDS-DMA pieces (0 = default, 1 = sc0, 2 = nt).  Round 3, on the scalar-base pieces, same box,
 // two passes: default 11.079 / 11.065 ms @1795-1805 MHz, sc0 11.071 / 11.072, nt 10.985 / 10.992 @1818-1840 (-0.75 %, and
 // at a higher clock: less power) -> nt.  (Rounds 1-2, per-lane-pointer pieces: nt was +1 % -- re-measured, not assumed.)
+// sc0 nt / sc1 nt / sc0 sc1 nt: the same as nt (10.95-10.99 ms where nt gives 10.97); sc1 alone: 11.09.
 #ifndef PNR_PP_DMA_AUX
 #define PNR_PP_DMA_AUX 2
 #endif
