@@ -446,7 +446,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         if (cb == 0 || !PNR_PP_EARLY_BIAS) CH::bias_issue(c.bias_addr(), q);
         f32x16 acc[FBC];
         CH::bias_finish(q, acc);                                // waits for every LDS read of the phase
-        CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });      // L -> M (barrier inside, see mma)
+        CH::mma(c.frag_addr(), A, inA, inB, acc, [&](auto... k) { if constexpr (sizeof...(k) == 0) { c.stamp(6); c.barrier(); c.stamp(2); } else c.stamp(k...); });      // L -> M (barrier inside, see mma)
         auto epilogue = [&](int b) {
             const int fb = cb * FBC + b;
 #pragma unroll
@@ -493,10 +493,10 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
         const bool logits_t = FUSE && PNR_FUSE_TRANSPOSED && ch_base != 0;      // wave-uniform
         if (logits_t) {
             CH::prologue_swapped(c.frag_addr(), c.bias_addr() - c.hi * 16, c.lane, A, acc);
-            CH::template mma<true>(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });
+            CH::template mma<true>(c.frag_addr(), A, inA, inB, acc, [&](auto... k) { if constexpr (sizeof...(k) == 0) { c.stamp(6); c.barrier(); c.stamp(2); } else c.stamp(k...); });
         } else {
             CH::prologue(c.frag_addr(), c.bias_addr(), A, acc);
-            CH::mma(c.frag_addr(), A, inA, inB, acc, [&]() { c.stamp(6); c.barrier(); c.stamp(2); });
+            CH::mma(c.frag_addr(), A, inA, inB, acc, [&](auto... k) { if constexpr (sizeof...(k) == 0) { c.stamp(6); c.barrier(); c.stamp(2); } else c.stamp(k...); });
         }
         c.m_done();          // its vmcnt(0) precedes the stores below: it never waits for an HBM write issued in this phase
         c.refill_begin();

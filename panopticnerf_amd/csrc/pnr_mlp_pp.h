@@ -102,6 +102,12 @@ __device__ __forceinline__ void pp_wait(u32x4& a)
 #ifndef PNR_PP_ABL
 #define PNR_PP_ABL 0
 #endif
+#ifndef PNR_TRACE_MID
+#define PNR_TRACE_MID 0
+#endif
+#ifndef PNR_ABL_INB
+#define PNR_ABL_INB 0
+#endif
 
 
 template <int WAVES>
@@ -218,7 +224,9 @@ struct CtxPP {
     int rf_f, rf_n;
     __device__ __forceinline__ void refill_begin()
     {
+#if !PNR_TRACE_MID          /* -DPNR_TRACE_MID=1: stamps 0 / 7 / 1 mark the quarters of the M phase instead (tools/mlp_trace_m.py) */
         stamp(0);
+#endif
         rf_base = a.data + (size_t)en.off_frag * PNR_FRAG_BYTES;
         rf_src = rf_base + lane * 16;
         rf_dst = smem + wrap_slot(slot_off + (2 + grp) * a.slot_bytes);     // Q: chunk ci+3 takes over chunk ci's own slot
@@ -251,7 +259,9 @@ struct CtxPP {
     __device__ __forceinline__ void refill_rest()
     {
         for (; !(PNR_PP_ABL & 1) && rf_f < rf_n; rf_f += WAVES) piece(rf_f);
+#if !PNR_TRACE_MID
         stamp(1);
+#endif
     }
     __device__ __forceinline__ void advance()
     {
@@ -356,6 +366,11 @@ struct PPChunk {
                 __builtin_amdgcn_s_setprio(PNR_PP_PRIO);
 #endif
             }
+#if PNR_TRACE_MID
+            if constexpr (i == NF / 4) barrier(0);          // trace builds: the callers' functor stamps when given a number
+            if constexpr (i == NF / 2) barrier(7);
+            if constexpr (i == 3 * NF / 4) barrier(1);
+#endif
             pp_wait<younger>(A[i % P]);
             if constexpr (SWAP) {
                 const uint32_t* act = ks < KSA ? &inA[4 * (ks < KSA ? ks : 0)] : &inB[4 * (ks >= KSA ? ks - KSA : 0)];
@@ -364,7 +379,11 @@ struct PPChunk {
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, A[i % P]),
                                                                   acc[b], 0, 0, 0);
             } else if constexpr (ks < KSA) acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inA[4 * ks], acc[b]);
+#if PNR_ABL_INB
+            else acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inA[4 * (ks - KSA)], acc[b]);      // ablation (results invalid): no second operand segment
+#else
             else acc[b] = kstep<PNR_PREC_BF16>(A[i % P], &inB[4 * (ks - KSA)], acc[b]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (i + P - 1 < NF && !(PNR_PP_ABL & 2)) {
                 pp_lds_read<frag_off(i + P - 1)>(A[(i + P - 1) % P], fa);
