@@ -75,8 +75,11 @@ typedef struct pnr_mlp_desc {
                           pnr_mlp_fused_plan (only pnr_mlp_forward_composite accepts it) */
     int32_t head_tap;  /* what the semantic / instance heads read: 0 = the trunk output h (default), 1 = the feature_linear
                           output (the reference's tap point cannot be checked here, so it is a switch) */
-    int32_t head_depth;/* 0 or 2 = W -> head_W -> n (ReLU between; default), 1 = one Linear W -> n (inference only) */
-    int32_t reserved[4];
+    int32_t head_depth;/* 0 or 2 = W -> head_W -> n (ReLU between; default), 1 = one Linear W -> n */
+    int32_t schedule;  /* time structure of the bf16 weight stream (tests and A/B tools; the arithmetic, the packed image and the
+                          results are identical bit for bit): 0 = default (ping-pong k_mlp_pp for inference launches, lock-step
+                          k_mlp_fused for the training forward), 1 = lock-step everywhere, 2 = ping-pong everywhere */
+    int32_t reserved[3];
 } pnr_mlp_desc;
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
@@ -188,6 +191,27 @@ int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd, const flo
 int64_t pnr_mlp_wgrad_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_samples);
 int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const void* dys, int64_t n_samples,
                   const pnr_mlp_params_host* grads_dev, void* workspace, void* stream);
+
+/* ---- a9, fp32 PARITY MODE of the training path (precision = "fp32" with autograd): the same three steps in plain fp32 -- the
+ * mode in which a parameter gradient can be checked to 1e-4 against fp32 autograd of the reference arithmetic, and in which a
+ * user can tell the precision of the bf16 path from a defect.  Not a performance path (one generic strided fp32 GEMM kernel per
+ * Linear and direction, deterministic fixed-order reductions).  Parameters are NOT packed: params_dev is a pnr_mlp_params_host
+ * in host memory whose pointers are DEVICE pointers to the dense (out,in) row-major fp32 parameters (the nn.Parameter tensors
+ * themselves), as for pnr_mlp_pack_device.  head_depth 1 | 2 and head_tap 0 | 1 are supported; desc.precision is ignored.
+ *   acts      : fp32, pnr_mlp_fp32_acts_floats(desc, n_rays * n_samples) floats -- gamma(x), gamma(d), every layer's output,
+ *               dense [S][width] (opaque to callers);
+ *   raw       : as pnr_mlp_forward (any strides);   d_raw: channel-major (4+n_sem+n_inst, >= S) fp32, channel stride given;
+ *   grads_dev : like pnr_mlp_wgrad's -- DEVICE pointers to the fp32 gradient buffers, every one fully overwritten;
+ *   workspace : pnr_mlp_backward_fp32_workspace_bytes device bytes.
+ * Replaces torch autograd of the reference's Network for the fp32 case. */
+int64_t pnr_mlp_fp32_acts_floats(const pnr_mlp_desc* desc, int64_t n_samples);
+int64_t pnr_mlp_backward_fp32_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_samples);
+int pnr_mlp_forward_train_fp32(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, const float* rays,
+                               const float* z, int64_t n_rays, int n_samples, float* raw, int64_t raw_stride_s,
+                               int64_t raw_stride_c, float* acts, void* stream);
+int pnr_mlp_backward_fp32(const pnr_mlp_desc* desc, const pnr_mlp_params_host* params_dev, const float* d_raw,
+                          int64_t d_raw_stride_c, const float* acts, int64_t n_rays, int n_samples,
+                          const pnr_mlp_params_host* grads_dev, void* workspace, void* stream);
 
 /* ---- a6: raw2outputs.  raw strides as above.  noise (R,N) or NULL; label_* (R,N) int32 or
  * NULL (fixed bbox-prior field, -1 = none).  sem_mode 0: composite logits; 1: softmax first.
@@ -317,11 +341,6 @@ int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float
  * workgroup 0's first wave to two_u64_dev (16 device bytes; their ratio = the mean shader clock during the launch); NULL
  * switches it off.  A thread-local setter: no device work, no synchronisation. */
 int pnr_mlp_set_clock_probe(void* two_u64_dev);
-/* Time structure of the fused bf16 MLP's weight stream (tests and A/B tools only; the arithmetic, the packed image and
- * the results are identical bit for bit): 0 = lock-step double buffer (k_mlp_fused), 1 = ping-pong (k_mlp_pp) for
- * inference launches [default], 2 = ping-pong for the training forward as well.  Returns the previous value; a negative
- * argument only queries.  The environment variable PNR_MLP_VARIANT sets the initial value. */
-int pnr_mlp_set_variant(int variant);
 
 #ifdef __cplusplus
 }

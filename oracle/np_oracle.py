@@ -196,11 +196,12 @@ def bbox_hits(rays, box, max_hits):
 # ---- SURVEY.md 8f rank 4 (post-processing / evaluator counters), plain numpy.  Parity unpinned: the reference's
 # evaluator is not in the mount; the conventions are documented in include/pnr.h.
 def panoptic_labels(sem, inst=None, is_thing=None):
-    sem = np.asarray(sem, np.float32)
+    nan_low = lambda a: np.where(np.isnan(a), -np.inf, a)      # a NaN logit never wins (the kernel reads it as -inf)
+    sem = nan_low(np.asarray(sem, np.float32))
     sl = np.argmax(sem, 1).astype(np.int32)                    # first maximum = lowest index on ties
     il = np.full(sem.shape[0], -1, np.int32)
     if inst is not None and inst.shape[1] > 0:
-        ia = np.argmax(np.asarray(inst, np.float32), 1).astype(np.int32)
+        ia = np.argmax(nan_low(np.asarray(inst, np.float32)), 1).astype(np.int32)
         thing = np.ones(sem.shape[0], bool) if is_thing is None else (np.asarray(is_thing)[sl] != 0)
         il = np.where(thing, ia, -1).astype(np.int32)
     pan = np.where(il >= 0, sl * 1000 + il, sl).astype(np.int32)

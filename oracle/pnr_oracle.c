@@ -13,8 +13,10 @@
  * Why C and a fixed op order: BASELINE.json asks for bit-exact sample indices and
  * ray-bbox hits.  searchsorted flips at bin edges when the CDF differs by one ulp, so the
  * order of every fp32 operation has to be pinned.  Since round 3 the order pinned here is
- * TORCH'S OWN, as its CPU kernels (torch 2.10, this container) evaluate the reference's
- * expressions -- restated from measurements against torch, bit for bit
+ * TORCH'S OWN, as its CPU kernels (torch 2.10, this container, dispatched at
+ * torch.backends.cpu.get_cpu_capability() == "AVX512": ATen vectorises per CPU capability, so
+ * "as written" is a statement about THAT build -- tests/test_oracle.py asserts the capability)
+ * evaluate the reference's expressions -- restated from measurements against torch, bit for bit
  * (tests/test_oracle.py::test_c_oracle_is_torch_as_written):
  *   torch.linspace(0, 1, N)   step = 1/(N-1);  t_i = step*i for i < N/2, else 1 - step*(N-1-i) with ONE rounding (fma)
  *   torch.sum(x, -1)          8-lane vector partial sums, 4 of them interleaved (pnro_torch_sum below)

@@ -97,16 +97,47 @@ def embed(x, L):
 
 
 # ------------------------------------------------------------------ a5 NeRF MLP + heads
+class _LinearBf16(torch.autograd.Function):
+    """One Linear of the bf16 MFMA path WITH its backward (emulate_bf16 = "bwd"): the arithmetic of k_mlp_fused<TRAIN>,
+    k_mlp_bwd and k_wgrad up to accumulation order.  Forward: bf16(x) bf16(W)^T + b, fp32 accumulate.  Backward: the incoming
+    gradient dY (already summed over its consumers in fp32 and ReLU-gated by autograd, as the d h chain of k_mlp_bwd does) is
+    rounded ONCE to bf16 -- that is the dY the kernel stores and feeds on --, then dX = bf16(dY) bf16(W), dW = bf16(dY)^T
+    bf16(x), db = sum bf16(dY), each with fp32 accumulation.  hi_lo=True keeps dY as a bf16 hi + lo pair (16 mantissa bits instead of
+    8): the student that shows what a higher-precision dY in the kernels would buy (tests/_students.py: nothing measurable)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, hi_lo):
+        xq, wq = bf16_round(x), bf16_round(w)
+        ctx.save_for_backward(xq, wq)
+        ctx.hi_lo = hi_lo
+        return F.linear(xq, wq, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        xq, wq = ctx.saved_tensors
+        gq = bf16_round(g)
+        if ctx.hi_lo:
+            gq = gq + bf16_round(g - gq)
+        g2, x2 = gq.reshape(-1, gq.shape[-1]), xq.reshape(-1, xq.shape[-1])
+        return gq @ wq, g2.t() @ x2, g2.sum(0), None
+
+
 def mlp_forward(p, cfg, pts, viewdirs, emulate_bf16=False):
     """pts (S,3), viewdirs (S,3) already normalised (!) -> raw (S, 4+n_sem+n_inst) =
     [rgb(3) sigma(1) semantic logits instance logits].
     emulate_bf16 rounds every Linear's input activations and weights to bf16 (RNE) and
     keeps fp32 accumulation + fp32 bias: the arithmetic of the MFMA bf16 kernel up to
-    accumulation order."""
+    accumulation order.  emulate_bf16 = "bwd" / "bwd_hilo" also emulates the bf16 BACKWARD of the HIP training path
+    (_LinearBf16: every dY rounded to bf16 / to a bf16 hi + lo pair before it is used) -- the student that separates
+    "precision of a bf16 backward" from "defect" in tests/test_gpu_convergence.py."""
     q = bf16_round if emulate_bf16 else (lambda t: t)
 
-    def lin(name, x):
-        return F.linear(q(x), q(p[name + ".weight"]), p[name + ".bias"])
+    if emulate_bf16 in ("bwd", "bwd_hilo"):
+        def lin(name, x):
+            return _LinearBf16.apply(x, p[name + ".weight"], p[name + ".bias"], emulate_bf16 == "bwd_hilo")
+    else:
+        def lin(name, x):
+            return F.linear(q(x), q(p[name + ".weight"]), p[name + ".bias"])
 
     ex = embed(pts, cfg.xyz_L)
     ed = embed(viewdirs, cfg.dir_L)

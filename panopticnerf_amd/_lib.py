@@ -27,7 +27,7 @@ class MlpDesc(ctypes.Structure):
                 ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
                 ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
                 ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("head_tap", ctypes.c_int32),
-                ("head_depth", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("head_depth", ctypes.c_int32), ("schedule", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -64,6 +64,12 @@ SIGNATURES = {
     "pnr_mlp_backward": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_f, c_i64, c_int, c_f]),
     "pnr_mlp_wgrad_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
     "pnr_mlp_wgrad": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, ctypes.POINTER(MlpParamsHost), c_f, c_f]),
+    "pnr_mlp_fp32_acts_floats": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
+    "pnr_mlp_backward_fp32_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64]),
+    "pnr_mlp_forward_train_fp32": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), c_f, c_f, c_i64, c_int, c_f, c_i64,
+                                           c_i64, c_f, c_f]),
+    "pnr_mlp_backward_fp32": (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpParamsHost), c_f, c_i64, c_f, c_i64, c_int,
+                                      ctypes.POINTER(MlpParamsHost), c_f, c_f]),
     "pnr_mlp_fused_plan": (c_int, [ctypes.POINTER(MlpDesc)]),
     "pnr_mlp_forward_composite_workspace_bytes": (c_i64, [ctypes.POINTER(MlpDesc), c_i64, c_int, c_int]),
     "pnr_mlp_forward_composite": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
@@ -88,7 +94,6 @@ SIGNATURES = {
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_restrict_rays": (c_int, [c_f, c_i64, c_f, c_f, c_int, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
-    "pnr_mlp_set_variant": (c_int, [c_int]),
     "pnr_mlp_set_clock_probe": (c_int, [c_f]),
     "pnr_mlp_forward_tiles": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f]),
     "pnr_composite_combine": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, c_int, c_f, c_f, c_int,

@@ -54,7 +54,8 @@ static inline int pnr_grid_cap(int64_t wanted, int per_cu = 8)
 // target written to M0 by hand -- instead of what __builtin_amdgcn_global_load_lds makes of a per-lane pointer (a 64-bit VALU
 // add per piece and a 64-bit address per lane): measured on the fused MLP launch, same box, outputs bit-identical:
 // 11.50 -> 11.08 ms (-3.7 %, -7.7 % in cycles).  AUX: cache policy, 0 default, 1 sc0, 2 nt.  M0 is reserved in the
-// backend (a clobber would be ignored): tests/test_asm_lint.py checks that these s_mov are the ONLY M0 accesses of the objects.
+// backend (a clobber is rejected with a warning and ignored): tools/asm_lint.py
+// -- run by `make all` on every object -- checks that these s_mov are the ONLY M0 accesses of the library.
 // Also measured: the piece with NO vector register (buffer_load_dwordx4 off, srd, soffset lds through a resource with
 // ADD_TID_ENABLE and stride 16): bit-identical outputs, same time as this form (11.36 vs 11.37 ms) -- not kept.
 #ifdef __HIPCC__
@@ -67,6 +68,12 @@ __device__ __forceinline__ void pnr_dma_piece(const void* src, void* dst, int la
     const uint64_t sa = (uint64_t)(uintptr_t)src;
     src = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa >> 32)) << 32) |
                                    (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa));
+#ifdef PNR_DEBUG_UNIFORM        /* debug builds: a caller that breaks wave-uniformity traps instead of copying lane 0's addresses */
+    if ((uint64_t)(uintptr_t)src != sa || (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dst != m0v) __builtin_trap();
+#endif
+    // no "m0" in the clobber list: hipcc answers it with "inline asm clobber list contains reserved registers: m0" (the backend
+    // reserves M0 and ignores the declaration) -- the lint over EVERY object's assembly (tools/asm_lint.py, run by `make all`)
+    // is the enforcement
     if constexpr (AUX == 2)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(lane16), "s"(src), "s"(m0v) : "memory");
     else if constexpr (AUX == 1)

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 #pragma unroll
                 for (int i = 0; i < HR; ++i) cur[t][i] = nxt[t][i];
         }
-        if (a.head_depth == 1) {          // one Linear per head (inference only)
+        if (a.head_depth == 1) {          // one Linear per head, straight from the tap (nothing more to save: the tap is saved)
             if (a.n_sem) layer_out<PREC, TILES, CTX, HR, 0>(c, cur, dummy, a.n_sem, 4, samp);
             if (a.n_inst) layer_out<PREC, TILES, CTX, HR, 0>(c, cur, dummy, a.n_inst, 4 + a.n_sem, samp);
         } else {
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
                 for (int i = 0; i < GR; ++i) shi[i] = 0;
             }
             pp_logits_merged<NBS, NBI>(c, A, shs, shi, fst);
-        } else if (a.head_depth == 1) {     // one Linear per head (inference only)
+        } else if (a.head_depth == 1) {     // one Linear per head, straight from the tap
             if (a.n_sem) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_sem, 4, samp, &fst);
             if (a.n_inst) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_inst, 4 + a.n_sem, samp, &fst);
         } else {
@@ -855,25 +855,8 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
     return PNR_OK;
 }
 
-// PNR_MLP_VARIANT (A/B builds and tools only): 0 = lock-step double buffer, 1 = ping-pong (default: PNR_MLP_DEFAULT_VARIANT)
-#ifndef PNR_MLP_DEFAULT_VARIANT
-#define PNR_MLP_DEFAULT_VARIANT 1
-#endif
-static int g_mlp_variant = -1;
-static int mlp_variant()
-{
-    if (g_mlp_variant < 0) {
-        const char* e = getenv("PNR_MLP_VARIANT");
-        g_mlp_variant = e ? atoi(e) : PNR_MLP_DEFAULT_VARIANT;
-    }
-    return g_mlp_variant;
-}
-PNR_EXPORT int pnr_mlp_set_variant(int variant)
-{
-    const int prev = mlp_variant();
-    if (variant >= 0 && variant <= 2) g_mlp_variant = variant;
-    return prev;
-}
+// pnr_mlp_desc::schedule (tests and A/B tools): 0 = ping-pong for inference / lock-step for the training forward, 1 = lock-step
+// everywhere, 2 = ping-pong everywhere.  A descriptor field: the library keeps no mutable process-global (include/pnr.h).
 
 // diagnostics: where the MLP kernels of this thread's next launches leave {shader cycles, 100 MHz ticks} of workgroup 0's first
 // wave (their ratio = the mean shader clock during the launch); null = off.  A setter, no synchronisation: libpnr_bench.so arms it
@@ -900,7 +883,6 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
                 "pnr_mlp_forward: rays / packed / acts must be 16-byte aligned");
     PNR_REQUIRE(!acts || desc->precision == PNR_PREC_BF16, "pnr_mlp_forward_train: the training path is bf16 only");
     PNR_REQUIRE(desc->plan == 0, "pnr_mlp_forward: plan=%d images are for pnr_mlp_forward_composite only", desc->plan);
-    PNR_REQUIRE(!acts || desc->head_depth != 1, "pnr_mlp_forward_train: head_depth = 1 is inference only");
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     MlpArgs a;
@@ -925,9 +907,9 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
     // fp32 parity mode: 4 waves x 1 tile, one wave per SIMD (its activations need ~300 registers)
     if (desc->precision == PNR_PREC_BF16) {
         // ping-pong form (pnr_mlp_pp.h): variant 1 = inference launches, 2 = the training forward as well
-        if (mlp_variant() >= 1 && !acts)
+        if (desc->schedule != 1 && !acts)
             return desc->W == 256 ? launch_mlp_pp<256, false>(a, st) : launch_mlp_pp<128, false>(a, st);
-        if (mlp_variant() == 2 && acts)
+        if (desc->schedule == 2 && acts)
             return desc->W == 256 ? launch_mlp_pp<256, true>(a, st) : launch_mlp_pp<128, true>(a, st);
         if (acts)
             return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2, true>(a, st)

@@ -176,6 +176,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
                 load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
 #pragma unroll
                 for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &ds[0][b * 8]);
+                if (a.head_depth == 1) {        // one Linear per head: the logit gradients ARE the segment (zero-extended to H slots)
+#pragma unroll
+                    for (int i = 0; i < OBR; ++i) c3[0][GR + i] = ds[0][i];
+                } else
                 layer_bwd<TILES, CTX, OBR, HFB, C3, GR>(c, ds, c3, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp, srow);
             }
             if (a.n_inst) {
@@ -183,6 +187,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
                 load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
 #pragma unroll
                 for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &di[0][b * 8]);
+                if (a.head_depth == 1) {
+#pragma unroll
+                    for (int i = 0; i < OBR; ++i) c3[0][2 * GR + i] = di[0][i];
+                } else
                 layer_bwd<TILES, CTX, OBR, HFB, C3, 2 * GR>(c, di, c3, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
             }
             // d F = W_views[:, :W]^T dY_views + W_sem0^T dY_sem0 + W_inst0^T dY_inst0   (feature_linear has no activation)
@@ -201,6 +209,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4, a.n_sem, ds[0]);
 #pragma unroll
             for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[5 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &ds[0][b * 8]);
+            if (a.head_depth == 1) {            // one Linear per head: the logit gradients ARE the segment (zero-extended to H slots)
+#pragma unroll
+                for (int i = 0; i < OBR; ++i) cat[0][HR + 8 + i] = ds[0][i];
+            } else
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8>(c, ds, cat, acts + a.gate_off[4 + D], dys + a.dys_off[2], samp, srow);
         }
         if (a.n_inst) {
@@ -208,6 +220,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
             load_draw<PNR_BWD_OUT_SLOTS / 32>(a, samp[0], c.hi, 4 + a.n_sem, a.n_inst, di[0]);
 #pragma unroll
             for (int b = 0; b < PNR_BWD_OUT_SLOTS / 32; ++b) store_slots(dys + a.dys_off[6 + D], PNR_BWD_OUT_SLOTS, srow[0], b, c.hi, &di[0][b * 8]);
+            if (a.head_depth == 1) {
+#pragma unroll
+                for (int i = 0; i < OBR; ++i) cat[0][HR + 8 + GR + i] = di[0][i];
+            } else
             layer_bwd<TILES, CTX, OBR, HFB, CATR, HR + 8 + GR>(c, di, cat, acts + a.gate_off[5 + D], dys + a.dys_off[3], samp, srow);
         }
         // d h = W_feature^T dY_feature + alpha^T d sigma + W_sem0^T dY_sem0 + W_inst0^T dY_inst0 ; gate by h = X_D
@@ -266,7 +282,6 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_backward: bf16 only");
-    PNR_REQUIRE(desc->head_depth != 1, "pnr_mlp_backward: head_depth = 1 is inference only");
     PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS,
                 "pnr_mlp_backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
     PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_mlp_backward: bad size");
@@ -285,7 +300,7 @@ PNR_EXPORT int pnr_mlp_backward(const pnr_mlp_desc* desc, const void* packed_bwd
     a.slot_bytes = plan.max_chunk_frags * PNR_FRAG_BYTES;
     a.S = (int)(n_rays * n_samples); a.N = n_samples;
     a.D = desc->D; a.skip = desc->skip; a.n_sem = desc->n_sem; a.n_inst = desc->n_inst;
-    a.head_tap = desc->head_tap; a.head_depth = 2;
+    a.head_tap = desc->head_tap; a.head_depth = desc->head_depth == 1 ? 1 : 2;
     a.acts = (uint16_t*)acts; a.d_raw = d_raw; a.dys = (uint16_t*)dys;
     pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
 #if PNR_TRACE

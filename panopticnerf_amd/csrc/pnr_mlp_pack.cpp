@@ -28,6 +28,7 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
                 d->precision);
     PNR_REQUIRE(d->head_tap == 0 || d->head_tap == 1, "pnr_mlp: head_tap=%d must be 0 (trunk output) or 1 (feature)", d->head_tap);
     PNR_REQUIRE(d->head_depth >= 0 && d->head_depth <= 2, "pnr_mlp: head_depth=%d must be 1 or 2", d->head_depth);
+    PNR_REQUIRE(d->schedule >= 0 && d->schedule <= 2, "pnr_mlp: schedule=%d must be 0 (default), 1 (lock-step) or 2 (ping-pong)", d->schedule);
     PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)),
                 "pnr_mlp: plan=%d is not available for this geometry (ask pnr_mlp_fused_plan)", d->plan);
     return PNR_OK;
@@ -47,7 +48,6 @@ static int bwd_validate(const pnr_mlp_desc* d)
     int rc = pnr_mlp_validate(d);
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(d->plan == 0, "pnr_mlp backward: plan must be 0");
-    PNR_REQUIRE(pnr_head_depth(*d) == 2, "pnr_mlp backward: head_depth = 1 is inference only");
     PNR_REQUIRE(d->precision == PNR_PREC_BF16, "pnr_mlp backward: bf16 only");
     PNR_REQUIRE(d->n_sem <= PNR_BWD_OUT_SLOTS && d->n_inst <= PNR_BWD_OUT_SLOTS,
                 "pnr_mlp backward: n_sem / n_inst must be <= %d", PNR_BWD_OUT_SLOTS);
@@ -191,8 +191,16 @@ static void describe_backward(const pnr_mlp_desc& d, const pnr_mlp_params_host& 
                     case PNR_K_SEM1: f.src = d.n_sem ? p.sem1_w : nullptr; f.ld = H; f.lo = 0; f.hi = d.n_sem; break;
                     case PNR_K_INST1: f.src = d.n_inst ? p.inst1_w : nullptr; f.ld = H; f.lo = 0; f.hi = d.n_inst; break;
                     case PNR_K_FEATURE: f.src = p.feature_w; f.ld = W; f.lo = 0; f.hi = W; break;
-                    case PNR_K_SEM0: f.src = d.n_sem ? p.sem0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; break;
-                    case PNR_K_INST0: f.src = d.n_inst ? p.inst0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; break;
+                    // head_depth 1: the segment carries the logit gradients themselves (n <= 64 valid k-slots, the rest zero)
+                    // against the single Linear (n, W) of the head
+                    case PNR_K_SEM0:
+                        if (pnr_head_depth(d) == 1) { f.src = d.n_sem ? p.sem1_w : nullptr; f.ld = W; f.lo = 0; f.hi = d.n_sem; }
+                        else { f.src = d.n_sem ? p.sem0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; }
+                        break;
+                    case PNR_K_INST0:
+                        if (pnr_head_depth(d) == 1) { f.src = d.n_inst ? p.inst1_w : nullptr; f.ld = W; f.lo = 0; f.hi = d.n_inst; }
+                        else { f.src = d.n_inst ? p.inst0_w : nullptr; f.ld = W; f.lo = 0; f.hi = H; }
+                        break;
                     case PNR_K_TRUNK: {
                         const bool sk = (L.index - 1 == d.skip);
                         f.src = p.pts_w[L.index]; f.ld = sk ? EX + W : W; f.col_off = sk ? EX : 0; f.lo = 0; f.hi = W;

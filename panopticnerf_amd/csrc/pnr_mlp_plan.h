@@ -143,18 +143,22 @@ static inline void pnr_build_bwd_plan(const pnr_mlp_desc& d, PnrBPlan& plan)
     };
     plan.layers.clear();
     plan.chunks.clear();
+    // head_depth 1 (one Linear W -> n per head): no hidden head layer, so no DSHS / DSHI step; the logit gradients themselves
+    // (64 slots, zero-extended to H) take the place of dY_sem0 / dY_inst0 in the chain that reaches the tap, and the packer fills
+    // the PNR_K_SEM0 / PNR_K_INST0 segments from the single Linear's transposed weights (describe_backward)
+    const bool deep = pnr_head_depth(d) == 2;
     add(PNR_B_DG, 0, H, {{PNR_K_RGBS, 32}});
     if (d.head_tap == 1) {
         // the head gradients reach the FEATURE: d F = views^T dY_views + sem0^T dY_sem0 + inst0^T dY_inst0 (all three segments
         // always present: an absent head's fragments are zeros), then d h = feature^T d F + alpha^T d sigma
-        if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
-        if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_sem && deep) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_inst && deep) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
         add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
         add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}});
     } else {
         add(PNR_B_DF, 0, W, {{PNR_K_VIEWS, H}});
-        if (d.n_sem) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
-        if (d.n_inst) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_sem && deep) add(PNR_B_DSHS, 0, H, {{PNR_K_SEM1, PNR_BWD_OUT_SLOTS}});
+        if (d.n_inst && deep) add(PNR_B_DSHI, 0, H, {{PNR_K_INST1, PNR_BWD_OUT_SLOTS}});
         add(PNR_B_DH, 0, W, {{PNR_K_FEATURE, W}, {PNR_K_RGBS, 32}, {PNR_K_SEM0, H}, {PNR_K_INST0, H}});
     }
     for (int l = d.D - 1; l >= 1; --l) add(PNR_B_DX, l, W, {{PNR_K_TRUNK, W}});

@@ -446,6 +446,13 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     const int64_t Xtap = d.head_tap ? ao[2 + D] : Xh;       // what the heads read: the feature (head_tap 1) or h
     // the first Linear of both heads reads the same X: one pass over it with the two dY regions stacked (X read once instead
     // of twice: 512 of the ~13.8 KB a sample costs this kernel).  The stacked shape exists for 128 + 128 rows x 256 only.
+    if (d.head_depth == 1) {
+        // one Linear W -> n per head: dW = (the logit gradients, 64 slots)^T x (the tap), one 64 x W job per head
+        if (d.n_sem) add(dof[5 + D], 64, Xtap, W, 0, d.n_sem, PNR_SEG_FEAT, 0, W, have ? F(g->sem1_w) : nullptr, W, 0, have ? F(g->sem1_b) : nullptr);
+        if (d.n_inst) add(dof[6 + D], 64, Xtap, W, 0, d.n_inst, PNR_SEG_FEAT, 0, W, have ? F(g->inst1_w) : nullptr, W, 0, have ? F(g->inst1_b) : nullptr);
+        pl.partial_floats = po;
+        return;
+    }
     const bool stack = d.n_sem && d.n_inst && H == 128 && W == 256 && WG_STACK_HEADS;
     if (stack) {
         const int64_t p = add_job(dof[2], dof[3], 2 * H, Xtap, W);
@@ -478,7 +485,6 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
 {
     int rc = pnr_mlp_validate(desc);
     if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(desc->head_depth != 1, "pnr_mlp_wgrad: head_depth = 1 is inference only");
     PNR_REQUIRE(desc->precision == PNR_PREC_BF16, "pnr_mlp_wgrad: the training path is bf16 only");
     PNR_REQUIRE(desc->n_sem <= PNR_BWD_OUT_SLOTS && desc->n_inst <= PNR_BWD_OUT_SLOTS, "pnr_mlp_wgrad: n_sem, n_inst <= %d", PNR_BWD_OUT_SLOTS);
     PNR_REQUIRE(n_samples >= 1 && n_samples < ((int64_t)1 << 31) - 65536, "pnr_mlp_wgrad: bad sample count");

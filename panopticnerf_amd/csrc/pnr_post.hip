@@ -15,13 +15,17 @@
 // 16 lanes per ray (4 rays per wave): a ray's row of the map is contiguous, so a lane group reads it as coalesced 64-byte
 // pieces (one thread per ray walked the rows with a stride of C floats: 0.58 ms per 529,408-ray frame at 45 / 32, now ~0.1).
 // Each lane scans its columns c = l, l + 16, ... in increasing order with a strict >, the butterfly keeps the larger value and,
-// on equal values, the lower index: the first maximum of the row, as the sequential scan finds it.
+// on equal values, the lower index: the first maximum of the row, as the sequential scan finds it.  A NaN logit is read as
+// -inf (a NaN kept as a lane's running maximum would shadow every later column of that lane -- `v > NaN` is never true -- and
+// the lanes of a group could then disagree on the winner): the result is the first maximum of the row's non-NaN values,
+// index 0 for a row without any, identical on every lane of the group.
 __device__ __forceinline__ void pnr_argmax16(const float* __restrict__ row, int n, int l, float& bv, int& bi)
 {
     bv = -INFINITY;
     bi = 0x7fffffff;
     for (int c = l; c < n; c += 16) {
-        const float v = row[c];
+        float v = row[c];
+        v = (v == v) ? v : -INFINITY;
         if (v > bv || bi == 0x7fffffff) { bv = v; bi = c; }
     }
 #pragma unroll
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(256) void k_panoptic_labels(const float* __restrict
         float bv, iv;
         int best, ib = -1;
         pnr_argmax16(sem + r * C, C, l, bv, best);
+        best = __shfl(best, 0, 16);                  // one winner per lane group, whatever the butterfly left in the other lanes
         if (inst && K > 0 && (!is_thing || is_thing[best] != 0)) pnr_argmax16(inst + r * K, K, l, iv, ib);
         if (l == 0 && g < R) {
             if (sem_label) sem_label[r] = best;

@@ -69,11 +69,12 @@ class Evaluator:
             comp = torch.full_like(ids, -1)
             comp[ok] = inv.int()
             cls = torch.where(uniq >= 1000, uniq // 1000, uniq).long()
-            # out-of-range classes are dropped on the device (clamped into an overflow row that summarize() reports) instead
-            # of a host round trip per frame
-            bad = cls >= C
+            # out-of-range classes go to a real OVERFLOW row (index C of a C + 1 row table, dropped before it is accumulated), so
+            # they never count in a real class's terms; their number is kept on the device and summarize() reports it -- no host
+            # round trip per frame
+            bad = (cls >= C) | (cls < 0)
             self._bad_ids = bad.sum() if self._bad_ids is None else self._bad_ids + bad.sum()
-            return comp.contiguous(), cls.clamp(max=C - 1)
+            return comp.contiguous(), torch.where(bad, torch.full_like(cls, C), cls)
 
         seg_p, cls_p = segments(pred_id)
         seg_g, cls_g = segments(gt_id)
@@ -89,14 +90,22 @@ class Evaluator:
         iou = torch.where(union > 0, pair / union.clamp(min=1), torch.zeros_like(pair))
         match = (iou > 0.5) & (cls_g[:, None] == cls_p[None, :])
         tp_g, tp_p = match.any(1), match.any(0)
-        terms = torch.zeros((C, 4), device=dev, dtype=torch.float64)
+        terms = torch.zeros((C + 1, 4), device=dev, dtype=torch.float64)          # row C: the overflow row (dropped)
         terms[:, 0].index_add_(0, cls_g, (iou * match).sum(1))
         terms[:, 1].index_add_(0, cls_g, tp_g.double())
         terms[:, 2].index_add_(0, cls_p, ((area_p > 0) & ~tp_p).double())
         terms[:, 3].index_add_(0, cls_g, ((area_g > 0) & ~tp_g).double())
+        terms = terms[:C]
         self.pq = terms if self.pq is None else self.pq + terms
 
     def summarize(self):
+        """The metrics accumulated since the last call; the accumulators are reset in every case (also when it raises)."""
+        try:
+            return self._summarize()
+        finally:
+            self.mse, self.conf, self.pq, self._bad_ids = [], None, None, None
+
+    def _summarize(self):
         out = {}
         if self.mse:
             mse = torch.stack(self.mse).double().cpu()
@@ -122,5 +131,4 @@ class Evaluator:
             out["pq"] = float(pq[seen].mean()) if seen.any() else math.nan
             out["sq"] = float((t[:, 0][seen] / t[:, 1][seen].clamp(min=1e-12))[t[:, 1][seen] > 0].mean()) if (t[:, 1] > 0).any() else math.nan
             out["rq"] = float((t[:, 1] / denom.clamp(min=1e-12))[seen].mean()) if seen.any() else math.nan
-        self.mse, self.conf, self.pq, self._bad_ids = [], None, None, None
         return out

@@ -114,10 +114,19 @@ def embed(x, L):
     return out
 
 
+def default_schedule():
+    """pnr_mlp_desc.schedule of new descriptors: 0 (ping-pong inference / lock-step training forward) unless the A/B tools'
+    environment variable PNR_MLP_VARIANT asks otherwise (its historical values: 0 = lock-step everywhere -> schedule 1,
+    1 = the default -> 0, 2 = ping-pong everywhere -> 2).  Read here, on the Python side: libpnr.so keeps no process-global."""
+    import os
+    return {"0": 1, "1": 0, "2": 2}.get(os.environ.get("PNR_MLP_VARIANT", "1"), 0)
+
+
 def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=None, precision="bf16", head_tap="trunk",
-              head_depth=2):
+              head_depth=2, schedule=None):
     """head_tap: what the semantic / instance heads read -- 'trunk' (the trunk output h) or 'feature' (the feature_linear
-    output); head_depth: 2 (W -> head_W -> n) or 1 (one Linear W -> n, inference only).  SURVEY.md 9 item 4 as switches."""
+    output); head_depth: 2 (W -> head_W -> n) or 1 (one Linear W -> n).  SURVEY.md 9 item 4 as switches.
+    schedule: pnr_mlp_desc.schedule (tests / A/B tools: 1 = lock-step kernels everywhere, 2 = ping-pong everywhere)."""
     d = MlpDesc()
     d.D, d.W, d.skip, d.xyz_L, d.dir_L = D, W, skip, xyz_L, dir_L
     d.n_sem, d.n_inst = n_sem, n_inst
@@ -125,6 +134,7 @@ def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=N
     d.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_FP32}[precision]
     d.head_tap = {"trunk": 0, "feature": 1}[head_tap]
     d.head_depth = {1: 1, 2: 2}[int(head_depth)]
+    d.schedule = default_schedule() if schedule is None else int(schedule)
     return d
 
 
@@ -278,6 +288,47 @@ def mlp_wgrad(desc, acts, dys, n_samples, shapes):
     return grads
 
 
+@_on_device
+def mlp_forward_train_fp32(desc, params, rays, z):
+    """fp32 parity mode of the training forward (pnr_mlp_forward_train_fp32): params = dict name -> fp32 GPU parameter
+    tensor (read in place, nothing is packed).  Returns (raw (ch,S) channel-major, acts fp32)."""
+    rays, z = _chk(rays, "rays"), _chk(z, "z")
+    R, N = z.shape
+    S = R * N
+    lib = _lib.load()
+    n = lib.pnr_mlp_fp32_acts_floats(ctypes.byref(desc), S)
+    if n < 0:
+        raise RuntimeError("pnr_mlp_fp32_acts_floats: " + lib.pnr_last_error().decode(errors="replace"))
+    raw = torch.empty((n_channels(desc), S), device=z.device, dtype=torch.float32)
+    acts = torch.empty((int(n),), device=z.device, dtype=torch.float32)
+    P, keep = _param_struct(desc, params, z.device)
+    _lib.check(lib.pnr_mlp_forward_train_fp32(ctypes.byref(desc), ctypes.byref(P), _p(rays), _p(z), R, N, _p(raw), 1, S, _p(acts),
+                                              _stream()), "pnr_mlp_forward_train_fp32")
+    return raw, acts
+
+
+@_on_device
+def mlp_backward_fp32(desc, params, d_raw, acts, n_rays, n_samples):
+    """fp32 parity mode of the data-gradient + weight-gradient passes (pnr_mlp_backward_fp32).  d_raw (ch,S) channel-major
+    fp32.  Returns dict name -> fp32 gradient tensor for every parameter in `params`."""
+    d_raw, acts = _chk(d_raw, "d_raw"), _chk(acts, "acts")
+    S = int(n_rays) * int(n_samples)
+    if tuple(d_raw.shape) != (n_channels(desc), S):
+        raise ValueError(f"d_raw: expected {(n_channels(desc), S)}, got {tuple(d_raw.shape)}")
+    lib = _lib.load()
+    dev = acts.device
+    nbytes = lib.pnr_mlp_backward_fp32_workspace_bytes(ctypes.byref(desc), S)
+    if nbytes < 0:
+        raise RuntimeError("pnr_mlp_backward_fp32_workspace_bytes: " + lib.pnr_last_error().decode(errors="replace"))
+    ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
+    grads = {k: torch.empty_like(v, dtype=torch.float32, memory_format=torch.contiguous_format) for k, v in params.items()}
+    P, keep = _param_struct(desc, params, dev)
+    G, keep2 = _param_struct(desc, grads, dev)
+    _lib.check(lib.pnr_mlp_backward_fp32(ctypes.byref(desc), ctypes.byref(P), _p(d_raw), d_raw.stride(0), _p(acts), int(n_rays),
+                                         int(n_samples), ctypes.byref(G), _p(ws), _stream()), "pnr_mlp_backward_fp32")
+    return grads
+
+
 def n_channels(desc):
     return 4 + desc.n_sem + desc.n_inst
 
@@ -321,13 +372,6 @@ def mlp_forward(desc, packed, rays, z, channel_major=True, out=None):
     _lib.check(_lib.load().pnr_mlp_forward(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(raw), ss, sc,
                                            _stream()), "pnr_mlp_forward")
     return raw
-
-
-def mlp_variant(variant=None):
-    """Which form of the fused bf16 MLP pnr_mlp_forward launches: 0 lock-step (k_mlp_fused), 1 ping-pong (k_mlp_pp) for
-    inference launches (default), 2 ping-pong for the training forward as well.  Returns the setting in force BEFORE the
-    call; variant=None only queries."""
-    return int(_lib.load().pnr_mlp_set_variant(-1 if variant is None else int(variant)))
 
 
 @_on_device

@@ -27,6 +27,32 @@ def _get(cfg, name, default):
     return getattr(cfg, name, default) if cfg is not None else default
 
 
+CHUNK_QUANTUM = 1024     # rays: at 64 and at 192 samples per ray a multiple of 1024 rays is a whole number of rounds of the
+                         # MLP kernels' persistent grid (256 workgroups x 256 samples)
+
+
+def chunk_plan(n_rays, chunk_size):
+    """[(start, end)] of the ray chunks of one render() call: BALANCED chunks instead of `chunk_size` pieces plus a tail.
+    cfg.chunk_size bounds the working set, it is not a hard limit: a tail smaller than half a chunk joins the other chunks
+    (n = round(R / chunk_size)), and every chunk but the last is rounded up to CHUNK_QUANTUM rays so that its MLP launches
+    are whole rounds of the persistent grid.  A rank's 66,176-ray share of a 1408 x 376 frame over 8 ranks is then ONE chunk
+    (not 65,536 + a 640-ray chunk with its own ~14 launches), the full frame 7 x 66,560 + 63,488 rays (every launch whole
+    rounds) instead of 8 x 65,536 + 5,120."""
+    n_rays, chunk_size = int(n_rays), max(1, int(chunk_size))
+    if n_rays <= 0:
+        return []
+    n = max(1, int(n_rays / chunk_size + 0.5))
+    size = -(-n_rays // n)
+    if n > 1 and chunk_size >= CHUNK_QUANTUM:
+        size = -(-size // CHUNK_QUANTUM) * CHUNK_QUANTUM
+    out, s = [], 0
+    while s < n_rays:
+        e = min(n_rays, s + size)
+        out.append((s, e))
+        s = e
+    return out
+
+
 class Renderer:
     def __init__(self, net, cfg=None):
         self.net = net
@@ -122,8 +148,8 @@ class Renderer:
         if not rays.is_cuda:
             raise RuntimeError("Renderer.render: batch['rays'] must be on the GPU (no CPU fallback)")
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
-        if grad and self.net.precision != "bf16":
-            raise NotImplementedError("Renderer.render: the backward kernels are bf16; set precision='bf16' to train")
+        if grad and self.net.precision not in ("bf16", "fp32"):
+            raise ValueError("Renderer.render: precision must be 'bf16' (the training path) or 'fp32' (its parity mode)")
         lead = rays.shape[:-1]
         rays = rays.reshape(-1, 8).float().contiguous()
         R = rays.shape[0]
@@ -141,8 +167,7 @@ class Renderer:
         self._overflow = None
         outs = []
         frame = None        # inference frames of several chunks: frame-sized maps, every later chunk writes its own rows
-        for s in range(0, R, self.chunk_size):
-            e = min(R, s + self.chunk_size)
+        for s, e in chunk_plan(R, self.chunk_size):
             o = self.render_rays(rays[s:e], box, box_ids,
                                  None if t_rand is None else t_rand[s:e],
                                  None if u is None else u[s:e], train, grad,

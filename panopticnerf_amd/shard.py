@@ -21,7 +21,7 @@ def shard_rays(rays, rank, world):
 
 def gather_maps(local, n_rays, rank, world, group=None):
     """Inverse of shard_rays for a dict of per-ray tensors (first dim = local ray count): ONE collective per frame.  Every
-    map is flattened to 4-byte columns (int32 maps bit-cast) and packed side by side into one (n_max, F) buffer; one
+    map is flattened to 4-byte columns (int32 maps bit-cast, other widths through an exact carrier: _to_carrier) and packed side by side into one (n_max, F) buffer; one
     all_gather_into_tensor brings the (world, n_max, F) block to every rank, and because the sharding is interleaved
     (ray = i * world + r) a permute to (n_max, world, F) IS the frame order -- no per-rank scatter.  On xGMI a collective is
     latency-bound at these sizes (a few MB), so one flat bucket beats one all_gather per map."""
@@ -31,24 +31,48 @@ def gather_maps(local, n_rays, rank, world, group=None):
     keys = list(local)
     cols, parts = [], []
     for k in keys:
-        v = local[k]
-        if v.element_size() != 4:
-            raise TypeError("gather_maps: %s has dtype %s; only 4-byte maps (float32 / int32) travel" % (k, v.dtype))
-        flat = v.reshape(v.shape[0], -1).contiguous().view(torch.float32)
+        flat = _to_carrier(local[k].reshape(local[k].shape[0], -1).contiguous(), k)
         cols.append(flat.shape[1])
         parts.append(flat)
     first = local[keys[0]]
     buf = torch.zeros((n_max, sum(cols)), dtype=torch.float32, device=first.device)
     buf[: first.shape[0]] = torch.cat(parts, 1) if len(parts) > 1 else parts[0]
     out_all = torch.empty((world * n_max, buf.shape[1]), dtype=torch.float32, device=first.device)    # rank-major concatenation
-    dist.all_gather_into_tensor(out_all, buf, group=group)
+    try:
+        dist.all_gather_into_tensor(out_all, buf, group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        # a backend without the flat form (older gloo builds): the list form into views of the same block -- still one collective
+        dist.all_gather(list(out_all.view(world, n_max, buf.shape[1]).unbind(0)), buf, group=group)
     full = out_all.view(world, n_max, buf.shape[1]).permute(1, 0, 2).reshape(world * n_max, buf.shape[1])[:n_rays]   # (i, r) -> ray i * world + r
     out, c0 = {}, 0
     for k, c in zip(keys, cols):
         v = local[k]
-        out[k] = full[:, c0:c0 + c].contiguous().view(v.dtype).reshape((n_rays,) + tuple(v.shape[1:]))
+        out[k] = _from_carrier(full[:, c0:c0 + c].contiguous(), v.dtype).reshape((n_rays,) + tuple(v.shape[1:]))
         c0 += c
     return out
+
+
+def _to_carrier(flat, name):
+    """(n, c) map of any dtype -> (n, c') float32 columns that carry it EXACTLY: 4-byte types are bit-cast, 8-byte types are
+    bit-cast into two columns per element, narrower types are widened (bool / 8- / 16-bit integers -> int32, bf16 / fp16 ->
+    float32: both exact) -- so render_sharded(keys=None) gathers whatever maps a renderer returns."""
+    es = flat.element_size()
+    if es == 4 or es == 8:
+        return flat.view(torch.float32)
+    if flat.dtype in (torch.bfloat16, torch.float16):
+        return flat.float()
+    if flat.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16):
+        return flat.to(torch.int32).view(torch.float32)
+    raise TypeError("gather_maps: %s has dtype %s, which has no exact 4-byte carrier" % (name, flat.dtype))
+
+
+def _from_carrier(cols, dtype):
+    es = torch.empty((), dtype=dtype).element_size()
+    if es == 4 or es == 8:
+        return cols.view(dtype)
+    if dtype in (torch.bfloat16, torch.float16):
+        return cols.to(dtype)
+    return cols.view(torch.int32).to(dtype)
 
 
 def render_sharded(render_fn, rays, rank, world, gather=True, group=None, keys=None, reduce_fn=None):

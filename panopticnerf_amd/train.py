@@ -28,9 +28,14 @@ class LevelFn(torch.autograd.Function):
         net = rend.net
         nerf = net.nerf(lv)
         dev = rays.device
-        desc, img = net.packed(lv, dev, "bf16")
         C, K = nerf.n_sem, nerf.n_inst
-        raw, acts = ops.mlp_forward_train(desc, img, rays, z)
+        ctx.fp32 = net.precision == "fp32"
+        if ctx.fp32:
+            # parity mode (pnr_mlp_forward_train_fp32): the live fp32 parameters, nothing packed, plain fp32 arithmetic
+            raw, acts = ops.mlp_forward_train_fp32(nerf.desc("fp32"), {n: p.detach() for n, p in nerf.named_parameters()}, rays, z)
+        else:
+            desc, img = net.packed(lv, dev, "bf16")
+            raw, acts = ops.mlp_forward_train(desc, img, rays, z)
         out = ops.composite(raw, z, rays, C, K, True, noise, ls, li, rend.sem_mode, rend.white_bkgd, True)
         empty = torch.zeros(0, device=dev)
         ce_s = ops.ce3d(raw, 4, C, ls) if (C and ls is not None) else None
@@ -69,10 +74,14 @@ class LevelFn(torch.autograd.Function):
         sc_i = (g_cei / ce_i[1].clamp(min=1.0)) if (g_cei is not None and ce_i.numel()) else None
         d_raw = ops.composite_backward(raw, z, rays, C, K, grads, noise if ctx.has_noise else None,
                                        ls if ctx.has_ls else None, li if ctx.has_li else None, sc_s, sc_i, rend.sem_mode)
-        desc, img_b = net.packed_bwd(lv, rays.device)
-        dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
-        shapes = {n: p.shape for n, p in nerf.named_parameters()}
-        wg = ops.mlp_wgrad(desc, acts, dys, R * N, shapes)          # pnr_mlp_wgrad (cross-check: tests/_wgrad_ref.py)
+        if ctx.fp32:
+            wg = ops.mlp_backward_fp32(nerf.desc("fp32"), {n: p.detach() for n, p in nerf.named_parameters()}, d_raw.contiguous(),
+                                       acts, R, N)
+        else:
+            desc, img_b = net.packed_bwd(lv, rays.device)
+            dys = ops.mlp_backward(desc, img_b, d_raw, acts, R, N)
+            shapes = {n: p.shape for n, p in nerf.named_parameters()}
+            wg = ops.mlp_wgrad(desc, acts, dys, R * N, shapes)      # pnr_mlp_wgrad (cross-check: tests/_wgrad_ref.py)
         return (None,) * 8 + tuple(wg[n].to(p_dtype) for n, p_dtype in ctx.names)
 
 

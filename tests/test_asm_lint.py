@@ -13,6 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_lds_pending as lint  # noqa: E402
+import asm_lint  # noqa: E402
 
 
 def test_lint_detects_a_read_before_its_wait():
@@ -84,39 +85,44 @@ def test_mlp_kernels_never_touch_a_pending_lds_destination(tmp_path):
     # m_done() wait with `s_waitcnt vmcnt(N)`, N = the number of vector-memory instructions of that request (they complete in
     # order, so "all but the youngest N" = every LDS-DMA piece).  N is a constant in the source; the compiler decides how many
     # instructions the request becomes.  The source brackets it with markers: between them there must be exactly N loads and no
-    # LDS-DMA piece -- otherwise a piece could still be in flight when its chunk is read.
-    begins = [i for i, l in enumerate(text) if "PNR_FETCH_BEGIN" in l]
-    assert len(begins) >= 6, "every k_mlp_pp instantiation carries the marker"
-    for b in begins:
-        e = next(i for i in range(b + 1, len(text)) if "PNR_FETCH_END" in text[i])
-        want = int(re.search(r"PNR_FETCH_END (\d+)", text[e]).group(1))
-        body = [l.split()[0] for l in text[b + 1:e] if l.strip() and not l.strip().startswith(";")]
-        vmem = [op for op in body if op.startswith(("global_", "buffer_", "flat_", "scratch_"))]
-        assert all(op.startswith("global_load_dword") and "lds" not in op for op in vmem), vmem
-        assert len(vmem) == want, (b, vmem, want)
-        assert not any(op.startswith("s_cbranch") or op.startswith("s_branch") for op in body), "straight-line code between the markers"
+    # LDS-DMA piece -- otherwise a piece could still be in flight when its chunk is read.  (tools/asm_lint.py: the SAME check
+    # fails `make all` on the assembly of the compile that produced the object.)
+    assert sum("PNR_FETCH_BEGIN" in l for l in text) >= 6, "every k_mlp_pp instantiation carries the marker"
+    assert asm_lint.fetch_markers(text) == []
+    # and the checker does fire: one load fewer than the wait assumes
+    b = next(i for i, l in enumerate(text) if "PNR_FETCH_BEGIN" in l)
+    e = next(i for i in range(b + 1, len(text)) if "PNR_FETCH_END" in text[i])
+    k = next(i for i in range(b + 1, e) if text[i].strip().startswith("global_load_dword"))
+    assert any("the wait assumes" in m for m in asm_lint.fetch_markers(text[:k] + text[k + 1:]))
 
 
-def _m0_accesses(text):
-    """(lines that write M0 with pnr_dma_piece's own s_mov, every other line that mentions m0) of an assembly listing."""
-    code = [l.split(";")[0].strip() for l in text]
-    mine = [l for l in code if re.match(r"s_mov_b32\s+m0,\s*s\d+$", l)]
-    other = [l for l in code if re.search(r"\bm0\b", l) and l not in mine]
-    return mine, other
+DMA_USERS = ("pnr_mlp.hip", "pnr_mlp_bwd.hip", "pnr_mlp_wgrad.hip")
+ALL_HIP = sorted(f for f in os.listdir(os.path.join(ROOT, "panopticnerf_amd", "csrc")) if f.endswith(".hip"))
 
 
-@pytest.mark.parametrize("name", ["pnr_mlp.hip", "pnr_mlp_bwd.hip", "pnr_mlp_wgrad.hip"])
+@pytest.mark.parametrize("name", ALL_HIP)
 def test_the_dma_helper_is_the_only_user_of_m0(tmp_path, name):
-    # pnr_dma_piece (pnr_common.h) writes M0 inside inline asm.  M0 is reserved in the AMDGPU backend -- an asm clobber is
-    # ignored -- so this is only safe while the compiler itself never keeps a value in M0 in these objects (LDS-DMA builtins,
-    # v_movrel register indexing, s_sendmsg, ...): every access must be the helper's own s_mov, each directly followed by its
-    # LDS-DMA load in the scalar-base form.
+    # pnr_dma_piece (pnr_common.h) writes M0 inside inline asm (M0 is reserved in the AMDGPU backend: a clobber is warned about
+    # and ignored).  Safe only while the compiler itself never keeps a value in M0 in ANY
+    # object of the library (LDS-DMA builtins, v_movrel register indexing, s_sendmsg, ...): every access must be the helper's
+    # own s_mov, each directly followed by its LDS-DMA load in the scalar-base form.  Every .hip of the library is checked.
     text = _asm(tmp_path, name)
-    mine, other = _m0_accesses(text)
-    assert len(mine) >= 20 and other == [], other[:5]
-    code = [l.split(";")[0].strip() for l in text if l.split(";")[0].strip()]
-    for i, l in enumerate(code):
-        if l in mine:
-            assert code[i + 1].startswith("s_nop") and re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", code[i + 2]), code[i:i + 3]
-    assert not any(l.startswith("global_load_lds_dwordx4 v[") for l in code), "a per-lane 64-bit address crept back in"
+    mine, other = asm_lint.m0_accesses(text)
+    assert other == [], other[:5]
+    assert asm_lint.m0_rule(text) == []
+    if name in DMA_USERS:
+        assert len(mine) >= 20
+    else:
+        assert mine == []
 
+
+def test_build_time_lint_runs_on_every_object():
+    """`make all` lints the assembly each .hip object was built from (panopticnerf_amd/csrc/Makefile: -save-temps=obj +
+    tools/asm_lint.py, a finding deletes the object and fails the build)."""
+    mk = open(os.path.join(ROOT, "panopticnerf_amd", "csrc", "Makefile")).read()
+    assert "-save-temps=obj" in mk and "tools/asm_lint.py" in mk and "rm -f $@; exit 1" in mk
+    saved = [os.path.join(ROOT, "build", "obj", f[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s") for f in ALL_HIP]
+    have = [p for p in saved if os.path.exists(p)]
+    if not have:
+        pytest.skip("no saved assembly (the library was not built on this host)")
+    assert asm_lint.main(have) == 0

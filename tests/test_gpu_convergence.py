@@ -105,114 +105,72 @@ def test_training_converges_like_the_oracle(dev):
     assert abs(psnr_hip - psnr_ora) < 0.05, (psnr_hip, psnr_ora)              # north_star: PSNR within 0.05 dB
 
 
-def test_training_at_the_benched_geometry_matches_the_oracle_student(dev):
-    """The same comparison at the geometry bench.py runs: 8x256 NeRFs with skip, semantic 45 + instance
-    32 heads, 64 + 128 samples, the 3D bbox prior, and the trainer's loss wrapper (NetworkWrapper: rgb, depth, 2D CE on the
-    learned and the fixed fields, per-sample 3D CE) -- 100 Adam steps on 192-ray batches.  The oracle student runs torch autograd
-    through oracle/torch_oracle.py (fp32, CPU) with the same terms.  Checked: the total loss and the colour term of the two
-    students agree (1 % / 25 %) step for step, the HIP-trained checkpoint renders to the same held-out PSNR through the HIP path
-    and through the oracle (0.05 dB: north_star), the two students' semantic argmax maps agree on >= 99 % of the held-out rays."""
-    from panopticnerf_amd import NetworkWrapper, synthetic
-    Cc, Kk, Nc, Nf, steps, batch = 45, 32, 64, 128, 150, 192
-    oc = to.mlp_config(n_sem=Cc, n_inst=Kk)
-    teacher = {"coarse": to.init_params(oc, 51, sigma_bias=0.05), "fine": to.init_params(oc, 52, sigma_bias=0.05)}
-    for p in teacher.values():
-        p["rgb_linear.weight"] *= 6.0
-        p["semantic_linears.1.weight"] *= 4.0
-        p["instance_linears.1.weight"] *= 4.0
-    frame = synthetic.camera_rays()
-    g = torch.Generator().manual_seed(11)
-    pool = frame[torch.randint(0, frame.shape[0], (1536,), generator=g)].contiguous()
-    held = frame[torch.randint(0, frame.shape[0], (384,), generator=g)].contiguous()
-    box, ids = synthetic.random_boxes(48, Cc, Kk, seed=5)
+def _cpu_family(jobs, procs):
+    """CPU students (tests/_students.py), each in its own process with its own OpenMP team; returns an AsyncResult."""
+    import multiprocessing as mp
+    import _students as S
+    pool = mp.get_context("spawn").Pool(procs)
+    return pool, pool.map_async(S.run_job, jobs)
+
+
+def test_training_at_the_benched_geometry_against_the_fp32_family(dev):
+    """Training at the geometry bench.py runs (8x256 NeRFs with skip, semantic 45 + instance 32 heads, 64 + 128 samples, the 3D
+    bbox prior, the trainer's loss wrapper with every term), HIP student against fp32 oracle students -- with the fp32 student's
+    OWN spread measured in the same run.  Two weightings: "unit" (the wrapper's defaults: the six
+    cross-entropy terms dominate; 100 Adam steps) and "image" (the colour term in charge; 150 steps).  Students per weighting:
+      fp32          torch autograd through the oracle, the HIP student's batches
+      fp32:jitter   the same from an initialisation perturbed by 1e-6 RELATIVE (far below one bf16 ulp)
+      fp32:order1   the same on another batch order
+      bf16_bwd      the HIP path's arithmetic restated on the CPU (bf16 forward, every dY rounded to bf16)
+      hip           NetworkWrapper on the MI355X, bf16 training kernels
+    What is asserted: |PSNR_hip - PSNR_fp32| <= max(0.3 dB, spread of the fp32 family) -- this is the bound the round-3 verdict
+    set, replacing the fixed 1.5 dB / 25 % --, total losses agree to 1 %, the HIP student's colour term lies inside the fp32
+    family's range (10 % margin), the two renderers give the HIP-trained checkpoint the same PSNR to 0.05 dB (north_star),
+    semantic argmax maps agree.  What the run SHOWS (profiles/r04a_*.json, measured on the CPU beforehand): at unit weights a
+    1e-6 perturbation of the initialisation moves the fp32 student's held-out PSNR by several dB after 100 steps (20.0 vs 27.8
+    dB; other batch orders 16.8 ... 28.8 dB) -- round 3's 1.58 dB between the HIP student and ONE fp32 student was inside that
+    spread, and so is every bf16 variant (22.9 ... 26.5 dB); the per-step picture is pinned by
+    test_gpu_backward.py::test_hip_gradient_is_the_emulated_bf16_gradient_at_the_benched_geometry."""
+    import _students as S
+    from panopticnerf_amd import make_renderer  # noqa: F401  (the HIP student imports the package)
+    plan = {"unit": 100, "image": 150}
+    names = ("fp32", "fp32:jitter", "fp32:order1", "bf16_bwd")
+    jobs = [(n, plan[w], 16, w) for w in plan for n in names]
     n_thr = torch.get_num_threads()
-    torch.set_num_threads(min(32, n_thr))
-    with torch.no_grad():
-        t_pool = to.render_rays(teacher, oc, pool, Nc, Nf, box=box, box_ids=ids)
-        t_held = to.render_rays(teacher, oc, held, Nc, Nf, box=box, box_ids=ids)
-    tgt = {"rgb": t_pool["rgb_1"], "depth": t_pool["depth_1"], "semantic": t_pool["semantic_1"].argmax(-1).int(),
-           "instance": t_pool["instance_1"].argmax(-1).int()}
-    init = {"coarse": to.init_params(oc, 61, sigma_bias=0.03), "fine": to.init_params(oc, 62, sigma_bias=0.03)}
-    batches = [torch.randint(0, pool.shape[0], (batch,), generator=g) for _ in range(steps)]
-    # loss weights that keep the image term in charge (with unit weights the six cross-entropy terms, ~60 at the start, bury the
-    # colour gradient ~100-fold: in bf16 gradients it then sits at the rounding level and the HIP student's PSNR trails by >1 dB
-    # after 100 steps although total losses agree to 0.05 % -- measured; it is the precision of a bf16 backward, not a defect)
-    W = {"rgb": 20.0, "depth": 0.2, "semantic": 0.1, "fix_semantic": 0.1, "instance": 0.1, "fix_instance": 0.1}
-    w3d, lr = 0.02, 5e-4
-
-    # ---- HIP student through the trainer's wrapper
-    cfg = NS(N_samples=Nc, N_importance=Nf, num_classes=Cc, num_instances=Kk, precision="bf16", chunk_size=4096,
-             w_rgb=W["rgb"], w_depth=W["depth"], w_sem=W["semantic"], w_fix_sem=W["fix_semantic"], w_inst=W["instance"],
-             w_fix_inst=W["fix_instance"], w_sem3d=w3d, w_inst3d=w3d)
-    net = make_network(cfg)
-    net.nerf_0.load_state_dict(init["coarse"])
-    net.nerf_1.load_state_dict(init["fine"])
-    net = net.to(dev).train()
-    wrap = NetworkWrapper(net, cfg)
-    opt = torch.optim.Adam(net.parameters(), lr=lr)
-    bx, bi = box.to(dev), ids.to(dev)
-    hip_losses, hip_rgb, ora_rgb = [], [], []
-    for idx in batches:
-        b = {"rays": pool[idx][None].to(dev), "bbox": bx, "bbox_ids": bi, "rgb": tgt["rgb"][idx][None].to(dev),
-             "depth": tgt["depth"][idx][None].to(dev), "pseudo_label": tgt["semantic"][idx][None].to(dev),
-             "instance_label": tgt["instance"][idx][None].to(dev)}
-        _, loss, st, _ = wrap(b)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        hip_losses.append(loss.item())
-        hip_rgb.append(float(st["rgb_loss_1"]))
-    with torch.no_grad():
-        hip_eval = make_renderer(cfg, net.eval()).render({"rays": held[None].to(dev), "bbox": bx, "bbox_ids": bi})
-
-    # ---- oracle student: same init, batches and terms; fp32 torch autograd on the CPU
-    prm = {lv: {k: v.clone().requires_grad_(True) for k, v in init[lv].items()} for lv in ("coarse", "fine")}
-    opt_o = torch.optim.Adam([p for d in prm.values() for p in d.values()], lr=lr)
-    ora_losses = []
-    for idx in batches:
-        out = to.render_rays(prm, oc, pool[idx], Nc, Nf, box=box, box_ids=ids, keep_raw=True)
-        hits = to.bbox_hits(pool[idx], box, 8)
-        loss = 0
-        for lv in (0, 1):
-            maps = {k: out[f"{k}_{lv}"] for k in ("rgb", "depth", "semantic", "fix_semantic", "instance", "fix_instance")}
-            terms, total = to.losses(maps, {k: v[idx] for k, v in tgt.items()}, W, Cc, Kk)
-            if lv == 1:
-                ora_rgb.append(float(terms["rgb"]))
-            ls, li = to.sample_labels(out[f"z_vals_{lv}"].detach(), hits[0], hits[1], hits[2], ids)
-            raw = out[f"raw_{lv}"].reshape(-1, 4 + Cc + Kk)
-            ce_s, _ = to.ce3d(raw[:, 4:4 + Cc], ls.reshape(-1))
-            ce_i, _ = to.ce3d(raw[:, 4 + Cc:], li.reshape(-1))
-            loss = loss + total + w3d * ce_s + w3d * ce_i
-        opt_o.zero_grad(set_to_none=True)
-        loss.backward()
-        opt_o.step()
-        ora_losses.append(loss.item())
-    with torch.no_grad():
-        ora_eval = to.render_rays({lv: {k: v.detach() for k, v in d.items()} for lv, d in prm.items()}, oc, held, Nc, Nf, box=box, box_ids=ids)
-    torch.set_num_threads(n_thr)
-
-    # the HIP-trained weights rendered by the reference path (oracle, fp32, CPU): what "PSNR within 0.05 dB of reference" means
-    # for a checkpoint -- the same weights, the two renderers
-    with torch.no_grad():
-        sd = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
-              "fine": {k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}}
-        same_w = to.render_rays(sd, oc, held, Nc, Nf, box=box, box_ids=ids)
-    psnr_hip = _psnr(hip_eval["rgb_1"][0].cpu(), t_held["rgb_1"])
-    psnr_same = _psnr(same_w["rgb_1"], t_held["rgb_1"])
-    psnr_ora = _psnr(ora_eval["rgb_1"], t_held["rgb_1"])
-    agree = float((hip_eval["semantic_1"][0].cpu().argmax(-1) == ora_eval["semantic_1"].argmax(-1)).float().mean())
-    first, last = np.mean(hip_losses[:5]), np.mean(hip_losses[-5:])
-    print("rgb term (fine level), first / last 10 steps: HIP %.5f -> %.5f, oracle %.5f -> %.5f" % (
-        np.mean(hip_rgb[:10]), np.mean(hip_rgb[-10:]), np.mean(ora_rgb[:10]), np.mean(ora_rgb[-10:])))
-    print(f"benched geometry: HIP loss {first:.4f} -> {last:.4f}; oracle loss {np.mean(ora_losses[:5]):.4f} -> {np.mean(ora_losses[-5:]):.4f}; "
-          f"held-out PSNR HIP {psnr_hip:.3f} dB vs oracle-trained {psnr_ora:.3f} dB; semantic argmax agreement {agree:.4f}")
-    print(f"HIP-trained weights: held-out PSNR rendered by HIP (bf16) {psnr_hip:.3f} dB, by the oracle (fp32) {psnr_same:.3f} dB")
-    assert last < 0.6 * first                                                 # it learns
-    assert abs(last - np.mean(ora_losses[-5:])) < 0.01 * abs(np.mean(ora_losses[-5:]))      # ... the same thing at the same rate
-    assert abs(np.mean(hip_rgb[-10:]) - np.mean(ora_rgb[-10:])) < 0.25 * np.mean(ora_rgb[-10:])    # the colour term too
-    # north_star "PSNR within 0.05 dB of reference": one checkpoint, the two renderers
-    assert abs(psnr_hip - psnr_same) < 0.05, (psnr_hip, psnr_same)
-    # two independently trained 8x256 students 150 steps in are ~33 dB networks still moving by tenths of a dB per step on 384
-    # held-out rays; their gap is bounded, not pinned (the 4x128 test above converges and pins 0.05 dB)
-    assert abs(psnr_hip - psnr_ora) < 1.5, (psnr_hip, psnr_ora)
-    assert agree >= 0.99, agree
+    pool, pending = _cpu_family(jobs, len(jobs))
+    try:
+        torch.set_num_threads(min(16, n_thr))
+        hip = {}
+        for w, steps in plan.items():
+            sc = S.scene(steps=steps)
+            W, w3d = S.WEIGHTS[w]
+            hip[w] = (sc, S.hip_student(sc, dev, W, w3d))
+        rows = pending.get(timeout=1500)
+    finally:
+        pool.terminate()
+        torch.set_num_threads(n_thr)
+    fam = {w: {r["name"]: r for r in rows if r["weights"] == w} for w in plan}
+    for w in plan:
+        sc, h = hip[w]
+        f = fam[w]
+        f32 = [f[n] for n in ("fp32", "fp32:jitter", "fp32:order1")]
+        spread = max(r["psnr"] for r in f32) - min(r["psnr"] for r in f32)
+        rgb_lo, rgb_hi = min(r["rgb_last10"] for r in f32), max(r["rgb_last10"] for r in f32)
+        hs = S.summary(h)
+        print(f"[{w}] held-out PSNR: hip {hs['psnr']:.3f} | fp32 {f['fp32']['psnr']:.3f}  jitter {f['fp32:jitter']['psnr']:.3f}  "
+              f"order1 {f['fp32:order1']['psnr']:.3f} (spread {spread:.3f} dB) | bf16_bwd (CPU emulation) {f['bf16_bwd']['psnr']:.3f}")
+        print(f"[{w}] total loss: hip {hs['loss_last5']:.4f} fp32 {f['fp32']['loss_last5']:.4f}; colour term: hip {hs['rgb_last10']:.6f} "
+              f"fp32 family [{rgb_lo:.6f}, {rgb_hi:.6f}] bf16_bwd {f['bf16_bwd']['rgb_last10']:.6f}")
+        first, last = np.mean(h["losses"][:5]), np.mean(h["losses"][-5:])
+        assert last < (0.8 if w == "unit" else 0.6) * first, (w, first, last)                       # it learns
+        assert abs(hs["loss_last5"] - f["fp32"]["loss_last5"]) < 0.01 * abs(f["fp32"]["loss_last5"]), w   # the same thing at the same rate
+        assert abs(hs["psnr"] - f["fp32"]["psnr"]) <= max(0.3, spread), (w, hs["psnr"], f["fp32"]["psnr"], spread)
+        assert rgb_lo / 1.1 <= hs["rgb_last10"] <= rgb_hi * 1.1, (w, hs["rgb_last10"], rgb_lo, rgb_hi)
+        # north_star "PSNR within 0.05 dB of reference": one checkpoint (the HIP-trained one), the two renderers
+        with torch.no_grad():
+            same_w = to.render_rays(h["params"], sc.oc, sc.held, sc.Nc, sc.Nf, box=sc.box, box_ids=sc.ids)
+        psnr_same = S.psnr(same_w["rgb_1"], sc.t_held["rgb_1"])
+        print(f"[{w}] HIP-trained weights rendered by HIP (bf16) {hs['psnr']:.3f} dB, by the oracle (fp32) {psnr_same:.3f} dB")
+        assert abs(hs["psnr"] - psnr_same) < 0.05, (w, hs["psnr"], psnr_same)
+        agree = float((h["eval"]["semantic_1"].argmax(-1) == torch.tensor(f["fp32"]["sem_argmax"])).float().mean())
+        assert agree >= 0.99, (w, agree)

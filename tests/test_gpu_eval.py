@@ -18,6 +18,14 @@ def test_panoptic_labels_bit_exact(dev, R, C, K):
     sem = torch.randn(R, C, generator=g)
     sem[::7] = sem[::7].round()                       # ties: lowest index wins
     inst = torch.randn(R, K, generator=g).round() if K else None
+    # NaN logits never win and never hide a later column of the same lane (columns c and c + 16 share a lane): ADVICE r3
+    sem[1::11, 0] = float("nan")
+    if C > 16:
+        sem[3::13, 2] = float("nan")
+        sem[3::13, 18] = 50.0                         # the row maximum sits 16 columns behind a NaN
+    sem[5::17] = float("nan")                         # rows without any number: index 0
+    if K:
+        inst[2::9, 0] = float("nan")
     thing = (torch.arange(C) % 3 == 0).int()
     sl, il, pan = ops.panoptic_labels(sem.to(dev), None if inst is None else inst.to(dev), thing.to(dev))
     rs, ri, rp = no.panoptic_labels(sem.numpy(), None if inst is None else inst.numpy(), thing.numpy())
@@ -92,3 +100,32 @@ def test_panoptic_quality_matches_oracle(dev):
     den = ref[:, 1] + 0.5 * ref[:, 2] + 0.5 * ref[:, 3]
     assert abs(s["pq"] - np.mean(ref[den > 0, 0] / den[den > 0])) < 1e-12
 
+
+
+def test_out_of_range_panoptic_ids_go_to_the_overflow_row_and_reset(dev):
+    """A ground-truth segment whose class index is >= n_classes is counted in NO real class (it lands in an overflow row that
+    is dropped), summarize() reports it -- and resets every accumulator before raising, so the next frame set starts clean
+    (the ids used to be clamped into class C-1 and the polluted table survived the exception)."""
+    C, K, H, W = 4, 3, 20, 30
+    ev = Evaluator(NS(num_classes=C, num_instances=K), is_thing=[0, 1, 1, 0])
+    sem = torch.nn.functional.one_hot(torch.randint(0, C, (H * W,), generator=torch.Generator().manual_seed(3)), C).float()[None] * 5
+    ins = torch.zeros(1, H * W, K)
+    out = {"rgb_1": torch.zeros(1, H * W, 3, device=dev), "semantic_1": sem.to(dev), "instance_1": ins.to(dev)}
+    res = ev.evaluate(out, {})
+    good = res["panoptic_id"].clone().reshape(1, -1)
+    ev.summarize()
+    # the same frame twice: once with a clean ground truth, once with a band of class-index 7 (>= C) segments
+    ev.evaluate(out, {"panoptic_gt": good})
+    clean = ev.pq.clone()
+    ev.summarize()
+    bad = good.clone()
+    bad[:, : 5 * W] = 7 * 1000 + 1
+    ev.evaluate(out, {"panoptic_gt": bad})
+    # exactly the terms of a table with room for class 7, cut back to the real classes: the segment took no real row
+    want = no.panoptic_quality_terms(res["panoptic_id"].cpu().numpy(), bad.reshape(-1).cpu().numpy(), 8)[:C]
+    assert np.allclose(ev.pq.cpu().numpy(), want, atol=1e-9), (ev.pq, want)
+    with pytest.raises(ValueError, match="class index"):
+        ev.summarize()
+    assert ev.pq is None and ev._bad_ids is None and ev.summarize() == {}      # reset although it raised
+    ev.evaluate(out, {"panoptic_gt": good})
+    assert torch.equal(ev.pq, clean)                                           # and the next accumulation is unpolluted

@@ -267,3 +267,27 @@ def test_chunked_frame_is_written_in_place_and_equals_one_chunk(dev):
     with pytest.raises(ValueError):
         ops.stratified(rays.to(dev), 64, out=torch.empty((999, 64), device=dev))
 
+
+
+def test_a_ranks_share_of_the_frame_is_one_chunk(dev):
+    # strong scaling over 8 ranks hands every rank 66,176 rays: with the balanced plan (renderer.chunk_plan) that is ONE chunk per
+    # level -- not a 65,536-ray chunk plus a 640-ray chunk with its own launches -- and it equals the two-chunk render bit for bit
+    from panopticnerf_amd import renderer as R_
+    C, K = 5, 3
+    cfg, net, oc, params = _setup(dev, C, K, "bf16", chunk_size=65536)
+    rays = synthetic.camera_rays()[::8][:66176].contiguous()
+    assert rays.shape[0] == 66176
+    box, ids = synthetic.random_boxes(16, C, K)
+    b = {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    calls = []
+    rend = make_renderer(cfg, net)
+    inner = rend.render_rays
+    rend.render_rays = lambda r, *a, **k: (calls.append(r.shape[0]), inner(r, *a, **k))[1]
+    with torch.no_grad():
+        one = rend.render(b)
+        assert calls == [66176]
+        cfg.chunk_size = 40000
+        assert [e - s for s, e in R_.chunk_plan(66176, 40000)] == [33792, 32384]
+        two = make_renderer(cfg, net).render(b)
+    for k in one:
+        assert torch.equal(one[k], two[k]), k

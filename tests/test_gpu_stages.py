@@ -418,17 +418,14 @@ def test_mlp_pingpong_equals_lockstep_bit_for_bit(dev, R, N, train):
             return raw.clone(), acts.view(torch.int16).clone()
         return ops.mlp_forward(desc, img, rays, z).clone(), None
 
-    prev = lib.pnr_mlp_set_variant(0)
-    try:
-        want = run()
-        lib.pnr_mlp_set_variant(2)
-        for rep in range(4):
-            got = run()
-            assert torch.equal(got[0], want[0]), (rep, int((got[0] != want[0]).any(0).sum()))
-            if train:
-                assert torch.equal(got[1], want[1]), rep
-    finally:
-        lib.pnr_mlp_set_variant(prev)
+    desc.schedule = 1                # lock-step everywhere (pnr_mlp_desc.schedule: same image, same arithmetic)
+    want = run()
+    desc.schedule = 2                # ping-pong everywhere
+    for rep in range(4):
+        got = run()
+        assert torch.equal(got[0], want[0]), (rep, int((got[0] != want[0]).any(0).sum()))
+        if train:
+            assert torch.equal(got[1], want[1]), rep
 
 
 # ----------------------------------------------------------------------------- a5 + a6 fused: no raw image round trip

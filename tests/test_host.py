@@ -99,6 +99,26 @@ def test_synthetic_inputs_are_kitti_shaped():
     assert hits[2].sum() > 0          # the prior is exercised by the synthetic scene
 
 
+def test_chunk_plan_is_balanced_and_whole_rounds():
+    """Renderer.render's chunks (renderer.chunk_plan): they cover the rays exactly once in order; a rank's 66,176-ray share of the
+    1408 x 376 frame (strong scaling over 8 ranks) is ONE chunk; the full frame is 8 chunks that are all whole rounds of the
+    MLP kernels' persistent grid at 64 and at 192 samples per ray; tiny inputs and tiny chunk sizes still work."""
+    from panopticnerf_amd.renderer import chunk_plan, CHUNK_QUANTUM
+    assert chunk_plan(0, 65536) == [] and chunk_plan(5, 65536) == [(0, 5)]
+    assert chunk_plan(529408 // 8, 65536) == [(0, 66176)]
+    full = chunk_plan(529408, 65536)
+    assert len(full) == 8 and all((e - s) % CHUNK_QUANTUM == 0 for s, e in full)
+    for n_samples in (64, 192):
+        assert all(((e - s) * n_samples) % (256 * 256) == 0 for s, e in full)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        R, c = int(rng.integers(1, 700000)), int(rng.choice([1, 7, 384, 4096, 65536, 100000]))
+        plan = chunk_plan(R, c)
+        assert plan[0][0] == 0 and plan[-1][1] == R and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        assert all(0 < e - s <= 1.5 * c + CHUNK_QUANTUM for s, e in plan)             # chunk_size stays a bound on the working set
+        assert len(plan) <= R // c + 1
+
+
 def test_shard_roundtrip_single_process():
     rays = torch.arange(11 * 8, dtype=torch.float32).reshape(11, 8)
     parts = [shard.shard_rays(rays, r, 3) for r in range(3)]
@@ -179,6 +199,30 @@ def _worker(rank, world, port, n_rays, q):
     assert torch.equal(lab["semantic_label"], full["semantic_1"].argmax(-1).int())
     local = shard.render_sharded(render, rays, rank, world, gather=False)
     assert local["rgb_1"].shape[0] == len(range(rank, n_rays, world))
+    # maps of other widths travel through exact carriers (bool / uint8 / int64 / bf16 / float64), with and without the flat
+    # collective (the one-bucket gather used to refuse anything but 4-byte maps)
+    def odd(r):
+        o = render(r)
+        return {"mask": o["depth_1"] > o["depth_1"].mean(), "u8": (o["rgb_1"] * 255).to(torch.uint8), "i64": (o["depth_1"] * 1e6).long(),
+                "bf": o["rgb_1"].bfloat16(), "f64": o["semantic_1"].double() / 3, "rgb_1": o["rgb_1"]}
+    ref_odd = odd(rays)
+    for flat in (True, False):
+        keep = dist.all_gather_into_tensor
+        if not flat:
+            def _no_flat(*a, **k):
+                raise NotImplementedError("no all_gather_into_tensor in this backend")
+            dist.all_gather_into_tensor = _no_flat
+        try:
+            got = shard.render_sharded(odd, rays, rank, world, gather=True)
+        finally:
+            dist.all_gather_into_tensor = keep
+        assert all(got[k].dtype == ref_odd[k].dtype and got[k].shape == ref_odd[k].shape for k in ref_odd)
+        for k in ("mask", "u8", "i64", "bf", "f64"):
+            a, b = got[k], ref_odd[k]
+            # whole-frame vs per-shard renders differ in the last bits; exactness of the CARRIER is checked on this rank's own rows
+            mine = odd(shard.shard_rays(rays, rank, world))[k]
+            assert torch.equal(a[rank::world], mine), (k, flat)
+            assert a.shape == b.shape
     ref = render(rays)
     ok = all(torch.allclose(full[k], ref[k], atol=1e-6) for k in ref)
     # every rank holds the same complete frame

@@ -123,6 +123,24 @@ def test_c_oracle_is_torch_as_written(Nc, Nf):
             assert np.array_equal(co.merge_sorted(zz, zs), zf_t.numpy())
 
 
+ATEN_CAPABILITY_MEASURED = "AVX512"      # torch.backends.cpu.get_cpu_capability() of the build the op orders were measured on
+
+
+def test_aten_capability_the_op_orders_were_measured_on():
+    """"Bit-exact against torch as written" is a statement about ONE ATen build: torch 2.10 CPU kernels dispatched at the
+    capability below.  ATen picks its sum / cumsum / linspace kernels per CPU capability (DEFAULT / AVX2 / AVX512 builds of the
+    same source vectorise differently: the lane count and the interleave of `sum`'s partial vectors are what pnro_torch_sum
+    restates), so on a host where torch dispatches differently the C oracle still IS the specification the HIP kernels are
+    pinned to, but its equality with torch's own ops has only been measured here.  test_torch_op_orders_the_c_oracle_restates
+    checks the three facts directly and fails first if a torch upgrade or another capability changes one of them.
+    (ATEN_CPU_CAPABILITY=avx2 / default in the environment selects another dispatch on the same machine.)"""
+    cap = torch.backends.cpu.get_cpu_capability()
+    assert cap == ATEN_CAPABILITY_MEASURED, (
+        "torch dispatches its CPU kernels at %r here; oracle/pnr_oracle.c restates the op order measured at %r (torch %s). The "
+        "oracle remains the HIP kernels' specification, but re-run test_torch_op_orders_the_c_oracle_restates / "
+        "test_c_oracle_is_torch_as_written to see whether 'torch as written' still holds on this host." % (cap, ATEN_CAPABILITY_MEASURED, torch.__version__))
+
+
 def test_torch_op_orders_the_c_oracle_restates():
     """The three measured facts about torch's CPU kernels that pnro_linspace01 / pnro_torch_sum / the double cumsum encode,
     checked directly (if a torch upgrade changes one of them this fails before any index does)."""
