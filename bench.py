@@ -240,12 +240,20 @@ def cpu_leg(config, params, rays_c, box, ids, seconds, keep_first, chunk=8192):
             raise RuntimeError("cpu child failed: " + cp.stderr[-400:])
         return json.loads(line[-1])
 
-    cands = sorted({min(k, avail) for k in (8, 16, 32, 64, 128)})      # up to half of a 256-CPU host: "the node's own host cores"
-    probe, k = {}, 0
+    # thread counts up to half of the host's CPUs ("the node's own host cores"), probed in ascending order; the ladder stops once
+    # a count is more than 10 % SLOWER than the best so far (on the pool's EPYC 9575F hosts 32 threads already lose to 16, and one
+    # 8192-ray chunk at 64 / 128 threads takes 21 s / 60 s: measured once, profiles/README.md round 4 -- not paid in every run)
+    cands = sorted({min(k, avail) for k in (8, 16, 32, 64, 128)})
+    probe, k, stopped = {}, 0, None
     for n in cands:
         r = child(n, k, 0.0)                   # exactly one chunk
         probe[n] = r
         k = r["next_chunk"]
+        if r["msamples"] < 0.9 * max(v["msamples"] for v in probe.values()):
+            stopped = "%d threads were %.0f %% slower than the best so far: larger counts not run" % (
+                n, 100 * (1 - r["msamples"] / max(v["msamples"] for v in probe.values())))
+            break
+    cands = [n for n in cands if n in probe]
     best = max(probe, key=lambda n: probe[n]["msamples"])
     tot_rays, tot_s = probe[best]["rays"], probe[best]["seconds"]
     if seconds > tot_s:
@@ -262,7 +270,7 @@ def cpu_leg(config, params, rays_c, box, ids, seconds, keep_first, chunk=8192):
             "sample": "%d rays of the frame in %d-ray chunks (frame order), %s, fp32, oracle/torch_oracle.py, %.1f s at the fastest of the "
                       "probed thread counts; every run in its own process pinned (sched_setaffinity) to `cores` of the %d host CPUs"
                       % (tot_rays, chunk, cc["name"], tot_s, avail),
-            "thread_probe_msamples": {str(n): round(probe[n]["msamples"], 4) for n in cands},
+            "thread_probe_msamples": {str(n): round(probe[n]["msamples"], 4) for n in cands}, "thread_probe_stopped": stopped,
             "torch_threads": probe[best]["threads"], "parallel_info": probe[best]["parallel_info"], "cpu_model": cpu_model(),
             "host_cpus": avail}, first
 

@@ -38,7 +38,9 @@ struct f4 { float v[4]; };
 #endif
 #define CMP_FIX_SCALE 1073741824.0f   // 2^30
 #ifndef CMP_PREFETCH
-#define CMP_PREFETCH 0      /* z / sigma of the next ray group requested one group ahead: -2.5..-5 % at N = 192 (registers 126 -> 160), +-0 at N = 64 */
+#define CMP_PREFETCH 0      /* 1 = z / sigma of the next ray group requested one group ahead.  SLOWER, so off: N = 192 0.782 -> 0.813 ms with
+                               labels (5.54 -> 5.33 TB/s), 0.720 -> 0.729 without; N = 64 +-0 (round 4, same process, same buffers,
+                               tools/composite_ab.py; registers 126 -> 160 cost a wave per SIMD) */
 #endif
 
 template <bool CH_MAJOR>

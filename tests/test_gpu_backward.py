@@ -498,8 +498,15 @@ def test_hip_gradient_is_the_emulated_bf16_gradient_at_the_benched_geometry(dev)
                      n(hip[k] - ref["fp32"][k]) / max(n(g_rgb[k]), 1e-30)))
     print("%-36s %9s %9s | %8s %8s | err / |g_rgb|: %7s %7s %7s" % ("weight", "|g|", "|g_rgb|", "hip~emu", "hip~f32", "fwd", "bwd", "hip"))
     for r in rows:
-        print("%-36s %9.2e %9.2e | %8.4f %8.4f | %22.3f %7.3f %7.3f" % r)
-    # (1) HIP = its emulation, far closer than either is to fp32
+        if r[2] > 0:
+            print("%-36s %9.2e %9.2e | %8.4f %8.4f | %22.3f %7.3f %7.3f" % r)
+        else:       # the heads: the colour term has no gradient there
+            print("%-36s %9.2e %9s | %8.4f %8.4f |" % (r[0], r[1], "-", r[3], r[4]))
+    # (1) HIP = its emulation (pass A, round 4: 1e-4 ... 2e-4 at the coarse level, whose sample positions are bit-identical; <= 1e-2
+    #     at the fine level, whose positions come from two bf16 coarse passes that differ in accumulation order), far closer than
+    #     either is to fp32 (0.5 ... 6 %)
+    coarse = [r for r in rows if r[0].startswith("coarse")]
+    assert max(r[3] for r in coarse) < 2e-3, max(r[3] for r in coarse)
     assert worst_emu < 2e-2, worst_emu
     trunk = [r for r in rows if "pts_linears" in r[0] and r[0].startswith("fine")]
     assert np.mean([r[3] for r in trunk]) < 0.5 * np.mean([r[4] for r in trunk])

@@ -105,72 +105,70 @@ def test_training_converges_like_the_oracle(dev):
     assert abs(psnr_hip - psnr_ora) < 0.05, (psnr_hip, psnr_ora)              # north_star: PSNR within 0.05 dB
 
 
-def _cpu_family(jobs, procs):
-    """CPU students (tests/_students.py), each in its own process with its own OpenMP team; returns an AsyncResult."""
-    import multiprocessing as mp
-    import _students as S
-    pool = mp.get_context("spawn").Pool(procs)
-    return pool, pool.map_async(S.run_job, jobs)
+def _family(weights):
+    """The CPU students of tests/golden/students_cpu.json: fp32 (the HIP student's batches), fp32:jitter (initialisation perturbed by
+    1e-6 relative), fp32:order1.. (other batch orders), bf16_bwd (the HIP arithmetic restated on the CPU).  Made by
+    `python tools/train_fidelity.py --weights W --students ... --out ...` (tests/golden/make_students.sh) in the build container:
+    CPU students need no GPU, and on the GPU box's shared host eight of them took 11 minutes of the GPU budget (round 4, pass A)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "students_cpu.json")) as f:
+        d = json.load(f)[weights]
+    return d["steps"], {r["name"]: r for r in d["rows"]}
 
 
-def test_training_at_the_benched_geometry_against_the_fp32_family(dev):
+@pytest.mark.parametrize("weights", ["unit", "image"])
+def test_training_at_the_benched_geometry_against_the_fp32_family(dev, weights):
     """Training at the geometry bench.py runs (8x256 NeRFs with skip, semantic 45 + instance 32 heads, 64 + 128 samples, the 3D
-    bbox prior, the trainer's loss wrapper with every term), HIP student against fp32 oracle students -- with the fp32 student's
-    OWN spread measured in the same run.  Two weightings: "unit" (the wrapper's defaults: the six
-    cross-entropy terms dominate; 100 Adam steps) and "image" (the colour term in charge; 150 steps).  Students per weighting:
-      fp32          torch autograd through the oracle, the HIP student's batches
-      fp32:jitter   the same from an initialisation perturbed by 1e-6 RELATIVE (far below one bf16 ulp)
-      fp32:order1   the same on another batch order
+    bbox prior, the trainer's loss wrapper with every term): the HIP students against the fp32 oracle students AND against the
+    fp32 student's OWN spread.  Two weightings: "unit" (the wrapper's defaults: the six cross-entropy terms
+    dominate; 100 Adam steps) and "image" (the colour term in charge; 150 steps).  Students:
+      fp32, fp32:jitter, fp32:order1..   torch autograd through the oracle (CPU; committed: _family)
       bf16_bwd      the HIP path's arithmetic restated on the CPU (bf16 forward, every dY rounded to bf16)
-      hip           NetworkWrapper on the MI355X, bf16 training kernels
-    What is asserted: |PSNR_hip - PSNR_fp32| <= max(0.3 dB, spread of the fp32 family) -- this is the bound the round-3 verdict
-    set, replacing the fixed 1.5 dB / 25 % --, total losses agree to 1 %, the HIP student's colour term lies inside the fp32
-    family's range (10 % margin), the two renderers give the HIP-trained checkpoint the same PSNR to 0.05 dB (north_star),
-    semantic argmax maps agree.  What the run SHOWS (profiles/r04a_*.json, measured on the CPU beforehand): at unit weights a
-    1e-6 perturbation of the initialisation moves the fp32 student's held-out PSNR by several dB after 100 steps (20.0 vs 27.8
-    dB; other batch orders 16.8 ... 28.8 dB) -- round 3's 1.58 dB between the HIP student and ONE fp32 student was inside that
-    spread, and so is every bf16 variant (22.9 ... 26.5 dB); the per-step picture is pinned by
+      hip           NetworkWrapper on the MI355X, bf16 training kernels            } trained here, same initialisation and
+      hip fp32      the same through the fp32 PARITY MODE of the training kernels  } batches as "fp32"
+    Asserted, for both HIP students: |PSNR - PSNR_fp32| <= max(0.3 dB, spread of the fp32 family) -- the bound the round-3 verdict
+    set in place of the fixed 1.5 dB / 25 % --, the total loss within max(1 %, the family's spread), the colour term inside the
+    family's range (10 % margin); for the bf16 student: the two renderers give its checkpoint the same PSNR to 0.05 dB
+    (north_star) and its semantic argmax map is the fp32 student's.
+    What the numbers SHOW (profiles/README.md, round 4): at unit weights the fp32 student is chaotic -- 1e-6 on the initialisation
+    moves its held-out PSNR by dB after 100 steps (25.3 vs 26.4 dB on the GPU host, 20.0 vs 27.8 dB in the build container; other
+    batch orders 16.8 ... 28.8 dB), and the HIP fp32-mode student, which differs from "fp32" in summation order only, lands 5.8 dB
+    away from it.  Round 3's 1.58 dB between the bf16 HIP student and ONE fp32 student was inside that spread, as is every bf16
+    variant.  The per-step statement -- the HIP gradient IS the emulated bf16 gradient, to 1e-4 at the coarse level -- is pinned by
     test_gpu_backward.py::test_hip_gradient_is_the_emulated_bf16_gradient_at_the_benched_geometry."""
     import _students as S
-    from panopticnerf_amd import make_renderer  # noqa: F401  (the HIP student imports the package)
-    plan = {"unit": 100, "image": 150}
-    names = ("fp32", "fp32:jitter", "fp32:order1", "bf16_bwd")
-    jobs = [(n, plan[w], 16, w) for w in plan for n in names]
+    steps, f = _family(weights)
+    W, w3d = S.WEIGHTS[weights]
     n_thr = torch.get_num_threads()
-    pool, pending = _cpu_family(jobs, len(jobs))
+    torch.set_num_threads(min(16, n_thr))
     try:
-        torch.set_num_threads(min(16, n_thr))
-        hip = {}
-        for w, steps in plan.items():
-            sc = S.scene(steps=steps)
-            W, w3d = S.WEIGHTS[w]
-            hip[w] = (sc, S.hip_student(sc, dev, W, w3d))
-        rows = pending.get(timeout=1500)
-    finally:
-        pool.terminate()
-        torch.set_num_threads(n_thr)
-    fam = {w: {r["name"]: r for r in rows if r["weights"] == w} for w in plan}
-    for w in plan:
-        sc, h = hip[w]
-        f = fam[w]
-        f32 = [f[n] for n in ("fp32", "fp32:jitter", "fp32:order1")]
-        spread = max(r["psnr"] for r in f32) - min(r["psnr"] for r in f32)
-        rgb_lo, rgb_hi = min(r["rgb_last10"] for r in f32), max(r["rgb_last10"] for r in f32)
-        hs = S.summary(h)
-        print(f"[{w}] held-out PSNR: hip {hs['psnr']:.3f} | fp32 {f['fp32']['psnr']:.3f}  jitter {f['fp32:jitter']['psnr']:.3f}  "
-              f"order1 {f['fp32:order1']['psnr']:.3f} (spread {spread:.3f} dB) | bf16_bwd (CPU emulation) {f['bf16_bwd']['psnr']:.3f}")
-        print(f"[{w}] total loss: hip {hs['loss_last5']:.4f} fp32 {f['fp32']['loss_last5']:.4f}; colour term: hip {hs['rgb_last10']:.6f} "
-              f"fp32 family [{rgb_lo:.6f}, {rgb_hi:.6f}] bf16_bwd {f['bf16_bwd']['rgb_last10']:.6f}")
-        first, last = np.mean(h["losses"][:5]), np.mean(h["losses"][-5:])
-        assert last < (0.8 if w == "unit" else 0.6) * first, (w, first, last)                       # it learns
-        assert abs(hs["loss_last5"] - f["fp32"]["loss_last5"]) < 0.01 * abs(f["fp32"]["loss_last5"]), w   # the same thing at the same rate
-        assert abs(hs["psnr"] - f["fp32"]["psnr"]) <= max(0.3, spread), (w, hs["psnr"], f["fp32"]["psnr"], spread)
-        assert rgb_lo / 1.1 <= hs["rgb_last10"] <= rgb_hi * 1.1, (w, hs["rgb_last10"], rgb_lo, rgb_hi)
-        # north_star "PSNR within 0.05 dB of reference": one checkpoint (the HIP-trained one), the two renderers
-        with torch.no_grad():
+        sc = S.scene(steps=steps)
+        h = S.hip_student(sc, dev, W, w3d)
+        h32 = S.hip_student(sc, dev, W, w3d, precision="fp32")
+        with torch.no_grad():       # north_star "PSNR within 0.05 dB of reference": one checkpoint (the HIP-trained one), the two renderers
             same_w = to.render_rays(h["params"], sc.oc, sc.held, sc.Nc, sc.Nf, box=sc.box, box_ids=sc.ids)
-        psnr_same = S.psnr(same_w["rgb_1"], sc.t_held["rgb_1"])
-        print(f"[{w}] HIP-trained weights rendered by HIP (bf16) {hs['psnr']:.3f} dB, by the oracle (fp32) {psnr_same:.3f} dB")
-        assert abs(hs["psnr"] - psnr_same) < 0.05, (w, hs["psnr"], psnr_same)
-        agree = float((h["eval"]["semantic_1"].argmax(-1) == torch.tensor(f["fp32"]["sem_argmax"])).float().mean())
-        assert agree >= 0.99, (w, agree)
+    finally:
+        torch.set_num_threads(n_thr)
+    f32 = [r for n, r in f.items() if n.startswith("fp32")]
+    assert len(f32) >= 3
+    spread = max(r["psnr"] for r in f32) - min(r["psnr"] for r in f32)
+    loss_spread = max(r["loss_last5"] for r in f32) - min(r["loss_last5"] for r in f32)
+    rgb_lo, rgb_hi = min(r["rgb_last10"] for r in f32), max(r["rgb_last10"] for r in f32)
+    hs, h32s = S.summary(h), S.summary(h32)
+    print(f"[{weights}] held-out PSNR: hip bf16 {hs['psnr']:.3f}  hip fp32 mode {h32s['psnr']:.3f} | " +
+          "  ".join("%s %.3f" % (n, r["psnr"]) for n, r in sorted(f.items())) + f" | fp32 family spread {spread:.3f} dB")
+    print(f"[{weights}] total loss: hip bf16 {hs['loss_last5']:.4f}  hip fp32 mode {h32s['loss_last5']:.4f}  fp32 {f['fp32']['loss_last5']:.4f} "
+          f"(family spread {loss_spread:.4f}); colour term: hip bf16 {hs['rgb_last10']:.6f}  hip fp32 mode {h32s['rgb_last10']:.6f}  "
+          f"fp32 family [{rgb_lo:.6f}, {rgb_hi:.6f}]  bf16_bwd {f['bf16_bwd']['rgb_last10']:.6f}")
+    for tag, st, run in (("bf16", hs, h), ("fp32 mode", h32s, h32)):
+        first, last = np.mean(run["losses"][:5]), np.mean(run["losses"][-5:])
+        assert last < (0.8 if weights == "unit" else 0.6) * first, (tag, first, last)                    # it learns
+        assert abs(st["psnr"] - f["fp32"]["psnr"]) <= max(0.3, spread), (tag, st["psnr"], f["fp32"]["psnr"], spread)
+        assert abs(st["loss_last5"] - f["fp32"]["loss_last5"]) <= max(0.01 * abs(f["fp32"]["loss_last5"]), loss_spread), (tag, st["loss_last5"])
+        assert rgb_lo / 1.1 <= st["rgb_last10"] <= rgb_hi * 1.1, (tag, st["rgb_last10"], rgb_lo, rgb_hi)
+    psnr_same = S.psnr(same_w["rgb_1"], sc.t_held["rgb_1"])
+    print(f"[{weights}] HIP-trained (bf16) weights rendered by HIP (bf16) {hs['psnr']:.3f} dB, by the oracle (fp32) {psnr_same:.3f} dB")
+    assert abs(hs["psnr"] - psnr_same) < 0.05, (hs["psnr"], psnr_same)
+    agree = float((h["eval"]["semantic_1"].argmax(-1) == torch.tensor(f["fp32"]["sem_argmax"])).float().mean())
+    assert agree >= 0.99, agree

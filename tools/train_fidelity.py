@@ -50,8 +50,7 @@ def main():
         with mp.get_context("spawn").Pool(a.procs) as pool:
             for s in pool.imap_unordered(_run, jobs):
                 rows.append(s)
-                s.pop("sem_argmax", None)
-                print(json.dumps({k: v for k, v in s.items() if k != "rgb_curve"}), flush=True)
+                print(json.dumps({k: v for k, v in s.items() if k not in ("rgb_curve", "sem_argmax")}), flush=True)
     rows.sort(key=lambda r: r["name"])
     print("\n%-14s %9s %11s %11s" % ("student", "PSNR dB", "loss", "rgb term"))
     for r in rows:
