@@ -35,8 +35,6 @@
 int pnr_mlp_validate(const pnr_mlp_desc* d);
 
 #include "pnr_mlp_core.h"
-#include <type_traits>
-
 #include "pnr_mlp_pp.h"
 #ifndef PNR_FUSE_TRANSPOSED
 #define PNR_FUSE_TRANSPOSED 1      /* fused epilogue: logit blocks computed transposed (operands swapped), see PPChunk::mma<SWAP> */
@@ -426,50 +424,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 // Same arithmetic, same packed image, same register-resident activations as k_mlp_fused<bf16, W, 1 tile, 8 waves>;
 // only the time structure of the weight stream differs (two wave groups in phase opposition, 3 LDS slots).
 struct NoSide { __device__ __forceinline__ void operator()(int) const {} };
-// next(fa, A): issued in the LAST chunk's L phase where the same-layer early read would sit: the first fragments of the NEXT
-// LAYER's first chunk (whose geometry only the caller knows), so that they land under the refill / epilogue / hand-over work
-// instead of being requested -- and drained -- at the very end of that L phase (PNR_PP_NEXT_EARLY; the callee of the next layer
-// is told with FIRST_EARLY that its first fragments are already in flight)
-struct NoNext { template <class AR> __device__ __forceinline__ void operator()(uint32_t, AR&) const {} };
-// PPChunk<FBC, ..>::first_frags for a k-step count known only at run time (wave-uniform): fragment i sits at
-// ((i % FBC) * ks + i / FBC) KiB.  ONE instruction stream for both geometries a trunk layer can have -- an if / else with the
-// reads in both arms compiles to two guarded blocks, which the assembly lint cannot tell apart from "both executed".
-// The first fragments requested for the NEXT layer stay in the ring across the layer hand-over -- in the trunk loop across a loop
-// back-edge, where the register allocator is free to insert copies of A[] (it did: v_mov_b64 of ring registers whose reads were
-// still pending; the assembly lint caught it).  The requests went out at the START of this L phase, a thousand cycles of refill /
-// epilogue ago: waiting for them here costs nothing, and it makes the ring registers ordinary, defined values for the compiler.
-template <int P>
-__device__ __forceinline__ void pp_settle(u32x4 (&A)[P])
-{
-    static_assert(P == 4, "the ring holds P - 1 = 3 early fragments");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]));
-}
-template <int FBC, int P>
-__device__ __forceinline__ void pp_first_frags_ks(uint32_t fa, u32x4 (&A)[P], int ks)
-{
-    pp_static_for<P - 1>([&](auto I) {
-        constexpr int i = I;
-        pp_lds_read<(i / FBC) * PNR_FRAG_BYTES>(A[i % P], fa + (uint32_t)((i % FBC) * ks) * (uint32_t)PNR_FRAG_BYTES);
-    });
-}
-#ifndef PNR_PP_NEXT_EARLY
-#define PNR_PP_NEXT_EARLY 0
-#endif
-#ifndef PNR_PP_EPI0_IN_M
-#define PNR_PP_EPI0_IN_M 0      /* layer 0's pack / ReLU before its M -> L barrier (in the wait for the partner's group-boundary L phase) */
-#endif
-#ifndef PNR_PP_LOGITS_IN_M
-#define PNR_PP_LOGITS_IN_M 0    /* plan 1: the logit chunk's weighted sums before its M -> L barrier; only the record stores stay in L */
-#endif
 // side(slot): work that is not this layer's, placed between the refill pieces of the L phases (slot = cb * FBC + b, one per
 // output block; -1 - cb: behind the last piece of chunk cb's L phase): a wave blocks ~100-200 cycles per LDS-DMA piece while
 // the CU's queue is full, and beside a hidden layer's M phase the SIMD's VALU is ~80 % idle -- VALU work parked here costs
 // next to nothing.
-template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT, int FBC_PLAN = 0, bool FIRST_EARLY = false, class SIDE = NoSide,
-          class NEXT = NoNext>
+template <class CTX, int KIND, int NA, int NB, int NFB_OUT, int MODE, int NOUT, int FBC_PLAN = 0, class SIDE = NoSide>
 __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&inA)[NA],
                                               const uint32_t (&inB)[NB > 0 ? NB : 1], uint32_t (&out)[NOUT],
-                                              uint16_t* save, int srow, SIDE&& side = NoSide{}, NEXT&& next = NoNext{})
+                                              uint16_t* save, int srow, SIDE&& side = NoSide{})
 {
     constexpr int FBC0 = pnr_layer_fbc(KIND, PNR_PREC_BF16);
     constexpr int FBC = FBC_PLAN > 0 ? FBC_PLAN : (NFB_OUT % FBC0 == 0) ? FBC0 : 1;      // mirrors pnr_build_plan
@@ -480,7 +442,7 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
     for (int cb = 0; cb < NFB_OUT / FBC; ++cb) {
         // L of chunk cb, last part.  For the layer's 2nd, 3rd, ... chunk the first fragments and the bias were already
         // requested (below) in the shadow of the previous chunk's refill / epilogue; only the drain is left.
-        if ((cb == 0 && !FIRST_EARLY) || (cb > 0 && !PNR_PP_EARLY)) CH::first_frags(c.frag_addr(), A);
+        if (cb == 0 || !PNR_PP_EARLY) CH::first_frags(c.frag_addr(), A);
         if (cb == 0 || !PNR_PP_EARLY_BIAS) CH::bias_issue(c.bias_addr(), q);
         f32x16 acc[FBC];
         CH::bias_finish(q, acc);                                // waits for every LDS read of the phase
@@ -497,21 +459,16 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         };
         // The M wave reaches the barrier ~200 cycles before its partner finishes L: the pack / ReLU of the chunk's first
         // PNR_PP_EPI_IN_M blocks (complete one MFMA before the chunk's last) is done here, in that slack, instead of in L.
-        // Layer 0 (PNR_PP_EPI0_IN_M): its M phase runs beside the partner's LONGEST L phase -- the sample-group boundary, ~3000
-        // cycles against ~1130 of MFMAs (per-chunk trace: the M wave waits ~1900 cycles at this barrier) -- so the whole epilogue
-        // of its blocks fits into that wait instead of lengthening the next L phase, which is on the critical path.
-        constexpr int EIM = (KIND == PNR_L_TRUNK0 && PNR_PP_EPI0_IN_M) ? FBC : (PNR_PP_EPI_IN_M < FBC ? PNR_PP_EPI_IN_M : FBC);
 #pragma unroll
-        for (int b = 0; b < EIM; ++b) epilogue(b);
+        for (int b = 0; b < (PNR_PP_EPI_IN_M < FBC ? PNR_PP_EPI_IN_M : FBC); ++b) epilogue(b);
         c.m_done();                                             // M -> L of the next chunk; own refill pieces landed
         const bool nxt_same = cb + 1 < NFB_OUT / FBC;           // the next chunk has this chunk's shape
         if (PNR_PP_EARLY && nxt_same) CH::first_frags(c.next_frag_addr(), A);
-        else if (!nxt_same) next(c.next_frag_addr(), A);
         c.refill_begin();
 #pragma unroll
         for (int b = 0; b < FBC; ++b) {
             c.refill_one();                                     // one LDS-DMA piece, then a block's pack / ReLU in its shadow
-            if (b >= EIM) epilogue(b);
+            if (b >= PNR_PP_EPI_IN_M) epilogue(b);
             if (save) store_slots(save, NFB_OUT * 32, srow, cb * FBC + b, c.hi, &out[(cb * FBC + b) * 8]);
             side(cb * FBC + b);                                 // a constant once the loops are unrolled
         }
@@ -520,7 +477,6 @@ __device__ __forceinline__ void pp_layer_regs(CTX& c, u32x4 (&A)[CTX::P], const 
         side(-1 - cb);                                          // end of chunk cb's refill: behind every piece of this L phase
         c.advance();
     }
-    if constexpr (!std::is_same_v<std::decay_t<NEXT>, NoNext>) pp_settle(A);
 }
 
 // FUSE: the block is not stored; it is reduced into the tile's compositing record (pnr_mlp_fuse.h), all in the L phase
@@ -636,35 +592,16 @@ __device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], con
 #if PNR_PP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-#if PNR_PP_LOGITS_IN_M
-    // the weighted sums over the tile (16 FMAs + one half-wave exchange per block) while this wave still waits for its partner's L
-    // phase: the group Q half of the workgroup idles ~1900 cycles at this barrier (the partner is in the group-boundary L phase)
-    float sums[FB];
-#pragma unroll
-    for (int b = 0; b < FB; ++b) sums[b] = fuse_logits_t_sum(st, acc[b]);
-#endif
     c.m_done();
-#if PNR_PP_NEXT_EARLY && PNR_PLAN1_TRUNK0_MERGE
-    // the NEXT sample group's layer 0 (plan 1: one chunk of 8 blocks x 4 k-steps): its first fragments fly under this epilogue
-    PPChunk<8, 16, 0>::first_frags(c.next_frag_addr(), A);
-#endif
     c.refill_begin();
     pp_static_for<FB>([&](auto B) {
         constexpr int b = B;
         c.refill_one();
-#if PNR_PP_LOGITS_IN_M
-        if constexpr (b < NBS) fuse_logits_t_store(st, c.hi, c.lane, b, c.a.n_sem, PNR_FUSE_REC_LOGITS, sums[b]);
-        else fuse_logits_t_store(st, c.hi, c.lane, b - NBS, c.a.n_inst, PNR_FUSE_REC_LOGITS + c.a.n_sem, sums[b]);
-#else
         if constexpr (b < NBS) fuse_logits_t(st, c.hi, c.lane, b, c.a.n_sem, PNR_FUSE_REC_LOGITS, acc[b]);
         else fuse_logits_t(st, c.hi, c.lane, b - NBS, c.a.n_inst, PNR_FUSE_REC_LOGITS + c.a.n_sem, acc[b]);
-#endif
     });
     c.refill_rest();
     c.advance();
-#if PNR_PP_NEXT_EARLY && PNR_PLAN1_TRUNK0_MERGE
-    pp_settle(A);           // layer 0's first fragments: defined values before the sample-group loop's back-edge
-#endif
 }
 
 // TAIL (FUSE only): 0 = classic plan (runtime loops over the logit blocks); 4 NBS + NBI = plan 1 with NBS semantic and NBI
@@ -732,12 +669,6 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         embed_lane<PNR_PREC_BF16, 5, 32, GXR>(px, py, pz, c.hi, ex);
     }
 
-#if PNR_PP_NEXT_EARLY
-    if constexpr (TAIL > 0 && PNR_PLAN1_TRUNK0_MERGE) {      // the first group's layer 0 (later groups: the previous group's logit chunk)
-        PPChunk<NFB, GXR, 0>::first_frags(c.frag_addr(), A);
-        pp_settle(A);
-    }
-#endif
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int s0 = (grp * WAVES + c.wave) * 32 + n;
         const int samp = s0 < a.S ? s0 : -1, srow = s0;
@@ -753,30 +684,6 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
             if constexpr (TRAIN) save_gates(a.acts + a.gate_off[idx], srow, c.hi, regs);
         };
         uint32_t cur[HR], nxt[HR];
-#if PNR_PP_NEXT_EARLY
-        // the first fragments of layer l_next's first chunk (a trunk layer, or -- l_next == D -- the feature layer, which has a plain
-        // trunk layer's geometry), requested from the previous layer's last L phase
-        constexpr int TFBC = (NFB % pnr_layer_fbc(PNR_L_TRUNK, PNR_PREC_BF16) == 0) ? pnr_layer_fbc(PNR_L_TRUNK, PNR_PREC_BF16) : 1;
-        constexpr int VFBC = (HFB % pnr_layer_fbc(PNR_L_VIEWS, PNR_PREC_BF16) == 0) ? pnr_layer_fbc(PNR_L_VIEWS, PNR_PREC_BF16) : 1;
-        auto early_layer = [&](int l_next) {
-            return [&, l_next](uint32_t fa, u32x4 (&Ar)[CTX::P]) {
-                static_assert(PPChunk<TFBC, HR, 0>::NF >= CTX::P - 1, "a trunk chunk has at least P - 1 fragments");
-                pp_first_frags_ks<TFBC>(fa, Ar, (l_next < a.D && l_next - 1 == a.skip) ? (GXR + HR) / 4 : HR / 4);
-            };
-        };
-        auto early_views = [&](uint32_t fa, u32x4 (&Ar)[CTX::P]) { PPChunk<VFBC, HR, GDR>::first_frags(fa, Ar); };
-        // plan 1: the previous group's logit chunk (or, for the first group, the kernel's prologue) requested layer 0's first fragments
-        pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR, (TAIL > 0 && PNR_PLAN1_TRUNK0_MERGE ? NFB : 0), (TAIL > 0 && PNR_PLAN1_TRUNK0_MERGE)>(
-            c, A, ex, dummy, cur, sv(2), srow, NoSide{}, early_layer(1));
-        gv(2, cur);
-        auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
-            if (l - 1 == a.skip)
-                pp_layer_regs<CTX, PNR_L_TRUNK, GXR, HR, NFB, MODE_RELU, HR, 0, true>(c, A, ex, in, out, sv(2 + l), srow, NoSide{}, early_layer(l + 1));
-            else
-                pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR, 0, true>(c, A, in, dummy, out, sv(2 + l), srow, NoSide{}, early_layer(l + 1));
-            gv(2 + l, out);
-        };
-#else
         pp_layer_regs<CTX, PNR_L_TRUNK0, GXR, 0, NFB, MODE_RELU, HR, (TAIL > 0 && PNR_PLAN1_TRUNK0_MERGE ? NFB : 0)>(c, A, ex, dummy, cur, sv(2), srow);
         gv(2, cur);
         auto trunk = [&](int l, const uint32_t (&in)[HR], uint32_t (&out)[HR]) {
@@ -786,7 +693,6 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
                 pp_layer_regs<CTX, PNR_L_TRUNK, HR, 0, NFB, MODE_RELU, HR>(c, A, in, dummy, out, sv(2 + l), srow);
             gv(2 + l, out);
         };
-#endif
 #if PNR_PP_UNROLL2
         // two layers per trip, cur -> nxt -> cur: no 64-register hand-over copy per layer (it sat in the L phase of every
         // layer's first chunk); one copy per sample group remains when D-1 is odd
@@ -843,18 +749,10 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #pragma unroll
             for (int j = 0; j < PER; ++j) stage(slot * PER + j);
         };
-#if PNR_PP_NEXT_EARLY
-        pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR, 0, true>(c, A, cur, dummy, nxt, sv(2 + a.D), srow, side, early_views);
-#else
         pp_layer_regs<CTX, PNR_L_FEATURE, HR, 0, NFB, MODE_LINEAR, HR>(c, A, cur, dummy, nxt, sv(2 + a.D), srow, side);
-#endif
         if constexpr (TRAIN) store_slots(a.acts + a.acts_off[1], 32, srow, 0, c.hi, ed);   // ED: 32 slots
         uint32_t g[GR];
-#if PNR_PP_NEXT_EARLY
-        pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR, 0, true>(c, A, nxt, ed, g, sv(3 + a.D), srow);
-#else
         pp_layer_regs<CTX, PNR_L_VIEWS, HR, GDR, HFB, MODE_RELU, GR>(c, A, nxt, ed, g, sv(3 + a.D), srow);
-#endif
         gv(3 + a.D, g);
         pp_layer_out<TRAIN, FUSE, CTX, GR, HR>(c, A, g, cur, 4, 0, samp, &fst);
         // the heads read the trunk output h = cur, or -- head_tap 1 -- the feature_linear output: h is dead once sigma is out, so

@@ -98,19 +98,12 @@ __device__ __forceinline__ void fuse_logits(FuseState& st, int hi, int n, int fb
 // a 32-channel logit block computed TRANSPOSED (PPChunk::mma<SWAP>: lane = channel fb*32 + (lane & 31), register r = sample
 // row(r, hi)): the weighted sum over the tile's samples is 16 FMAs against the lane's weight registers lwr, one exchange between
 // the half-waves, and one contiguous 128-byte store
-__device__ __forceinline__ float fuse_logits_t_sum(const FuseState& st, const f32x16& acc)
+__device__ __forceinline__ void fuse_logits_t(FuseState& st, int hi, int lane, int fb, int n_out, int rec_base, const f32x16& acc)
 {
     float s = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s = fmaf(st.lwr[r], acc[r], s);
-    return s + __shfl_xor(s, 32, 64);
-}
-__device__ __forceinline__ void fuse_logits_t_store(FuseState& st, int hi, int lane, int fb, int n_out, int rec_base, float s)
-{
+    s += __shfl_xor(s, 32, 64);
     const int ch = fb * 32 + (lane & 31);
     if (hi == 0 && ch < n_out) st.rec[rec_base + ch] = s;
-}
-__device__ __forceinline__ void fuse_logits_t(FuseState& st, int hi, int lane, int fb, int n_out, int rec_base, const f32x16& acc)
-{
-    fuse_logits_t_store(st, hi, lane, fb, n_out, rec_base, fuse_logits_t_sum(st, acc));
 }
