@@ -33,6 +33,9 @@ struct CompositeArgs {
 };
 
 struct f4 { float v[4]; };
+#ifndef CMP_GRID_PER_CU
+#define CMP_GRID_PER_CU 8      /* resident 256-thread workgroups per CU the grid is capped at (grid-stride over the rest) */
+#endif
 #ifndef CMP_UB
 #define CMP_UB 8        // channel rows per batch
 #endif
@@ -517,7 +520,7 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
         const size_t hb = (size_t)4 * rpw2 * (n_sem + n_inst) * sizeof(uint32_t);
         if (!want_fix || hb <= 48 * 1024) {
             const int64_t ng = (n_rays + rpw2 - 1) / rpw2;
-            const int grid2 = pnr_grid_cap((ng + 3) / 4, 8);
+            const int grid2 = pnr_grid_cap((ng + 3) / 4, CMP_GRID_PER_CU);
             a.use_hist = want_fix ? 1 : 0;
             if (sem_mode) launch_composite2<true>(L, m4, grid2, want_fix ? hb : 0, st, a); else launch_composite2<false>(L, m4, grid2, want_fix ? hb : 0, st, a);
             PNR_CHECK_LAUNCH("pnr_composite");
@@ -525,7 +528,7 @@ PNR_EXPORT int pnr_composite(const float* raw, int64_t raw_stride_s, int64_t raw
         }
     }
     const int64_t n_groups = (n_rays + rpw - 1) / rpw;
-    const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
+    const int grid = pnr_grid_cap((n_groups + 3) / 4, CMP_GRID_PER_CU);
     if (ch_major) { if (sem_mode) launch_composite<true, true>(sub, grid, lds, st, a); else launch_composite<true, false>(sub, grid, lds, st, a); }
     else { if (sem_mode) launch_composite<false, true>(sub, grid, lds, st, a); else launch_composite<false, false>(sub, grid, lds, st, a); }
     PNR_CHECK_LAUNCH("pnr_composite");
