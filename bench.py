@@ -77,7 +77,9 @@ def traffic(kernel, n_rays_launch, config):
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)[kernel]
-        return int(t["hbm_bytes_per_launch"]) if (n_rays_launch == 65536 and config == 5) else None
+        # recorded for the profiled frame's largest dispatch (rays_per_launch; 65536 in older records); per-ray traffic is constant
+        # (records + per-sample quadruples + z), so the timed launch's figure is the recorded one scaled by its ray count
+        return int(t["hbm_bytes_per_launch"] * n_rays_launch / t.get("rays_per_launch", 65536)) if config == 5 else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -584,12 +586,23 @@ def main():
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic(tkey, Rc, args.config),
                         "traffic_source": "profiles/latest_traffic.json: rocprofv3 PMC passes of this command, recorded (not measured in this run)",
+                        "traffic_note": None,
                         "ms_per_launch": round(ms, 4), "flop_per_launch": flops,
                         "shader_mhz_during_kernel": round(kernel_mhz, 0),
                         "mfma_sustained": {"note": "register-only bf16 MFMA loop on every SIMD of this device, measured in this run",
                                            "constant_operands_tflops": round(pk_const, 1), "constant_operands_mhz": round(mhz_const, 0),
                                            "random_operands_tflops": round(pk_rand, 1), "random_operands_mhz": round(mhz_rand, 0)},
                         "frac_of_sustained_random_operand_peak": round(ach / pk_rand, 4) if (pk_rand > 0 and args.precision == "bf16") else None}
+            if fused and roofline["traffic"]:
+                # algorithmic HBM bytes of the fused launch: per sample the (lw, r, g, b) quadruple written + z read, per 32-sample tile
+                # one record (Q + the C + K logit sums, padded to a multiple of 4 floats) written
+                rec_b = 4 * (((1 + N_SEM + N_INST) + 3) // 4 * 4)
+                alg = S * (16 + 4) + (S // 32) * rec_b
+                roofline["traffic_algorithmic"] = alg
+                roofline["traffic_note"] = ("%.1fx the algorithmic %.2f GB: the weight pieces are requested with the `nt` policy (-0.9 %% launch time at "
+                                            "a higher clock), so ~3 %% of the 69 GB L2 -> LDS weight stream misses the L2 and is re-fetched over the "
+                                            "fabric (0.2 TB/s: nowhere near a bound); with the default policy the launch moved 1.07x its algorithmic "
+                                            "bytes (profiles/r03d)" % (roofline["traffic"] / alg, alg / 1e9))
             if fused or (ops.default_schedule() != 1 and args.precision == "bf16"):
                 # the weight stream of the same launch: every workgroup (256 samples: 8 waves x one 32-sample tile in registers)
                 # streams the whole packed image L2 -> LDS by LDS-DMA once per group.  NOT a ceiling: reported next to what the

@@ -17,6 +17,9 @@ def biggest(db, counter, pat):
 
 
 fetch_db, write_db, note = sys.argv[1:4]
+sys.path.insert(0, ROOT)
+from panopticnerf_amd.renderer import chunk_plan      # the largest dispatch of a full frame is the renderer's first chunk
+LAUNCH_RAYS = {"k_mlp_pp_fused": chunk_plan(1408 * 376, 65536)[0][1], "k_composite": 65536}
 try:      # kernels that did not run in these passes keep their last recorded entry (e.g. k_composite when the step is fused)
     out = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
 except (OSError, ValueError):
@@ -25,8 +28,8 @@ for key, pat in (("k_mlp_pp_fused", "%k_mlp_pp%"), ("k_composite", "%k_composite
     f, w = biggest(fetch_db, "FETCH_SIZE", pat), biggest(write_db, "WRITE_SIZE", pat)
     if f is None or w is None:
         continue
-    out[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024),
-                "note": "fine-level launch (65536 rays x 192); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128 B requests "
-                        "as 64 B on wide coalesced reads); WRITE_SIZE as reported (uncalibrated); profiles/" + note}
+    out[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024), "rays_per_launch": LAUNCH_RAYS[key],
+                "note": "fine-level launch (%d rays x 192: the largest dispatch); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128 B requests "
+                        "as 64 B on wide coalesced reads); WRITE_SIZE as reported (uncalibrated); profiles/" % LAUNCH_RAYS[key] + note}
 json.dump(out, open(os.path.join(ROOT, "profiles", "latest_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
