@@ -272,7 +272,7 @@ __device__ __forceinline__ void embed_lane(float p0, float p1, float p2, int hi,
 template <int PREC, int W, int TILES, int WAVES, int MINW, bool TRAIN>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_mlp_fused(const MlpArgs a)
 {
-    using CTX = Ctx<WAVES, 4>;
+    using CTX = Ctx<WAVES, 4, 2, (TRAIN && WAVES == 8) ? PNR_TRAIN_FWD_ISSUERS : 0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPB = PrecT<PREC>::RPB;
     constexpr int NFB = W / 32, HFB = W / 64;

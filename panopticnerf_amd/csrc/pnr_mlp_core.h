@@ -58,6 +58,9 @@ __device__ __forceinline__ int pnr_div_magic(int x, uint32_t magic, int shift)
 #ifndef PNR_ABL_NODMA
 #define PNR_ABL_NODMA 0
 #endif
+#ifndef PNR_TRAIN_FWD_ISSUERS
+#define PNR_TRAIN_FWD_ISSUERS 4 /* waves that copy the weight pieces in the TRAINING forward (Ctx::issue); 8 = every wave (round 3) */
+#endif
 #ifndef PNR_CORE_DMA_AUX
 #define PNR_CORE_DMA_AUX 0      /* cache policy of the lock-step kernels' weight pieces (training forward, data-gradient pass): nt, which the
                                    inference kernel gains 0.9 % from, costs the training forward +15 % (1.58 -> 1.82 ms) -- its write stream
@@ -215,7 +218,7 @@ __device__ __forceinline__ f32x16 kstep(const u32x4& a, const uint32_t* b, f32x1
 // ---- weight stream: NSLOT LDS slots; chunk c + NSLOT - 1 is copied in (LDS-DMA) while chunk c feeds the MFMAs.
 // Two slots everywhere.  Three (two chunks ahead) were tried for the data-gradient pass on the suspicion that its chunk
 // hand-overs wait for weight pieces delayed behind the gradient stores: +-0 (profiles/README.md, round 2 training notes).
-template <int WAVES, int GDB_, int NSLOT = 2>
+template <int WAVES, int GDB_, int NSLOT = 2, int ISSUERS_ = 0>
 struct Ctx {
     static constexpr int GDB = GDB_;   // A-fragment read-ahead (fragments per tile in flight)
     static constexpr int DIST = NSLOT - 1;
@@ -251,11 +254,21 @@ struct Ctx {
         return e;
     }
     // L2 -> LDS copy of a chunk into slot `sl` (asynchronous LDS-DMA, 1 KiB per wave-instruction)
+    // ISSUERS_ > 0: only waves < ISSUERS_ copy weight pieces.  vmcnt is ONE in-order counter for LDS-DMA loads and stores, so a
+    // wave that waits for its pieces also waits for every older store of its own: with all waves issuing pieces, each wave keeps
+    // at most ~2 chunks of activation stores in flight.  A wave that never issues a piece never has to wait on vmcnt at a chunk
+    // hand-over (the pieces are covered by their issuers' waits plus the barrier), so its stores stay in flight as long as they
+    // need.  Training forward, 4 of 8 waves (same box, tools/fwd_train_time.py, outputs bit-identical): 1.3205 -> 1.2681 ms at 786 K
+    // samples (-4.0 %), 0.450 -> 0.434 at 262 K; 2 of 8: -1.9 % (the two issuers' own 16 pieces per chunk get long).  The
+    // data-gradient pass loads gate words in every layer -- the compiler's wait for those loads drains the stores anyway -- and
+    // measured slower with 4 issuers: it keeps all 8.
+    static constexpr int ISSUERS = (ISSUERS_ > 0 && ISSUERS_ < WAVES) ? ISSUERS_ : WAVES;
     __device__ __forceinline__ void issue(const pnr_chunk_entry& e, int sl) const
     {
         const uint8_t* src = a.data + (size_t)e.off_frag * PNR_FRAG_BYTES;
         char* dst = smem + sl * a.slot_bytes;
-        for (int f = wave; f < (int)e.nfrag; f += WAVES) pnr_dma_piece<PNR_CORE_DMA_AUX>(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
+        if (ISSUERS < WAVES && wave >= ISSUERS) return;
+        for (int f = wave; f < (int)e.nfrag; f += ISSUERS) pnr_dma_piece<PNR_CORE_DMA_AUX>(src + (size_t)f * PNR_FRAG_BYTES, dst + f * PNR_FRAG_BYTES, lane * 16);
     }
     __device__ __forceinline__ void start()
     {
@@ -276,7 +289,7 @@ struct Ctx {
 #if !PNR_ABL_NODMA              /* ablation: the weight stream stops after start() (results invalid) */
         issue(e1, sl);
 #endif
-        if constexpr (NSLOT > 2) n_last = wave < (int)e1.nfrag ? ((int)e1.nfrag - wave + WAVES - 1) / WAVES : 0;
+        if constexpr (NSLOT > 2) n_last = (wave < ISSUERS && wave < (int)e1.nfrag) ? ((int)e1.nfrag - wave + ISSUERS - 1) / ISSUERS : 0;
         stamp(1);
     }
     // Chunk hand-over: this wave's share of the next chunk has landed, every wave is done reading this one.
@@ -298,6 +311,8 @@ struct Ctx {
                 default: if (allow > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
 #undef PNR_VM
+        } else if (ISSUERS < WAVES && wave >= ISSUERS) {
+            // this wave issued no piece: nothing of its own to wait for -- its stores fly on
         } else {
             if (st_full && nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (st_full && nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
