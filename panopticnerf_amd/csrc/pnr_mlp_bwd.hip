@@ -27,6 +27,12 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 #ifndef PNR_BWD_WAVES
 #define PNR_BWD_WAVES 8
 #endif
+#ifndef PNR_ABL_NOGATE
+#define PNR_ABL_NOGATE 0
+#endif
+#ifndef PNR_BWD_ISSUERS
+#define PNR_BWD_ISSUERS 0       /* waves that copy the weight pieces (0 = all 8): 4 measured SLOWER here, see Ctx::issue */
+#endif
 
 // One backward layer.  in: NA B registers (k-segments concatenated).  out[t][OFF + fb*8 + p].
 // gate  : the ReLU gate BITS of the layer's forward output ([S][NFB_OUT] dwords, pnr_train_layout; nullptr: linear):
@@ -44,8 +50,15 @@ __device__ __forceinline__ void layer_bwd(CTX& c, const uint32_t (&in)[TILES][NA
     uint32_t dummy[TILES][1];
     uint32_t gw[TILES][NFB_OUT / 2];
     if constexpr (GATED) {
+#if PNR_ABL_NOGATE              /* ablation (results invalid): no gate-word loads -- what the per-layer global loads cost through the in-order vmcnt */
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int i = 0; i < NFB_OUT / 2; ++i) gw[t][i] = 0xffffffffu;
+#else
 #pragma unroll
         for (int t = 0; t < TILES; ++t) load_gates<NFB_OUT / 2>(gate, NFB_OUT * 32, samp[t], c.hi, gw[t]);
+#endif
     }
 #pragma unroll
     for (int cb = 0; cb < NFB_OUT / FBC; ++cb) {
@@ -122,7 +135,7 @@ __device__ __forceinline__ void load_draw(const MlpArgs& a, int s, int hi, int c
 template <int W, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_mlp_bwd(const MlpArgs a)
 {
-    using CTX = Ctx<WAVES, 4, PNR_BWD_SLOTS>;
+    using CTX = Ctx<WAVES, 4, PNR_BWD_SLOTS, PNR_BWD_ISSUERS>;
     constexpr int TILES = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NFB = W / 32, HFB = W / 64;

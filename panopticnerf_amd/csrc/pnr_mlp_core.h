@@ -258,7 +258,7 @@ struct Ctx {
     // wave that waits for its pieces also waits for every older store of its own: with all waves issuing pieces, each wave keeps
     // at most ~2 chunks of activation stores in flight.  A wave that never issues a piece never has to wait on vmcnt at a chunk
     // hand-over (the pieces are covered by their issuers' waits plus the barrier), so its stores stay in flight as long as they
-    // need.  Training forward, 4 of 8 waves (same box, tools/fwd_train_time.py, outputs bit-identical): 1.3205 -> 1.2681 ms at 786 K
+    // need.  Training forward, 4 of 8 waves (same box, tools/train_kernels_time.py, outputs bit-identical): 1.3205 -> 1.2681 ms at 786 K
     // samples (-4.0 %), 0.450 -> 0.434 at 262 K; 2 of 8: -1.9 % (the two issuers' own 16 pieces per chunk get long).  The
     // data-gradient pass loads gate words in every layer -- the compiler's wait for those loads drains the stores anyway -- and
     // measured slower with 4 issuers: it keeps all 8.
