@@ -360,6 +360,8 @@ PNR_EXPORT int pnr_mlp_backward_fp32(const pnr_mlp_desc* desc, const pnr_mlp_par
     PNR_REQUIRE(d_raw && acts && workspace, "pnr_mlp_backward_fp32: null pointer");
     const int64_t S = n_rays * n_samples;
     PNR_REQUIRE(S < ((int64_t)1 << 31) - 4096, "pnr_mlp_backward_fp32: R*N exceeds 2^31");
+    PNR_REQUIRE((S + KSLAB - 1) / KSLAB <= 65535, "pnr_mlp_backward_fp32: R*N=%lld needs more than 65535 slabs of %d samples (grid limit); "
+                "split the batch", (long long)S, KSLAB);
     PNR_REQUIRE(d_raw_stride_c >= S, "pnr_mlp_backward_fp32: d_raw is channel-major, its channel stride must be >= R*N");
     const pnr_mlp_desc& d = *desc;
     const pnr_mlp_params_host& p = *params_dev;

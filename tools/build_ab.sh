@@ -11,4 +11,17 @@ for cfg in "$@"; do
     $C/*.hip -x hip $C/pnr_api.cpp $C/pnr_mlp_pack.cpp 2>&1 | grep -E "error" &
 done
 wait
+# the same assembly lint `make all` runs, on the variant's flags (a finding is reported, the library is kept: ablation builds
+# break the fetch-marker count on purpose)
+for cfg in "$@"; do
+  name=${cfg%%:*}; flags=${cfg#*:}
+  T=$(mktemp -d)
+  for f in pnr_mlp pnr_mlp_bwd pnr_mlp_wgrad; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+      -fvisibility=hidden -I$R/include -I$C $flags -Wno-unused-command-line-argument -S --cuda-device-only -o $T/$f.s $C/$f.hip 2>/dev/null &
+  done
+  wait
+  python3 $R/tools/asm_lint.py $T/*.s && echo "asm_lint $name: clean" || echo "asm_lint $name: FINDINGS (see above)"
+  rm -rf $T
+done
 ls -la $R/build/ab/
