@@ -44,7 +44,7 @@ def fetch_markers(text):
 def m0_accesses(text):
     """(lines that write M0 with pnr_dma_piece's own s_mov, every other line that mentions m0)."""
     code = [l.split(";")[0].strip() for l in text]
-    mine = [l for l in code if re.match(r"s_mov_b32\s+m0,\s*s\d+$", l)]
+    mine = [l for l in code if re.match(r"s_mov_b32\s+m0,\s*(s\d+|vcc_lo|vcc_hi)$", l)]
     other = [l for l in code if re.search(r"\bm0\b", l) and l not in mine]
     return mine, other
 
