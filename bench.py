@@ -660,11 +660,15 @@ def main():
             opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
             tb = make_train_batch(cfg, rays, box, ids, args.train_rays, N_SEM, N_INST, dev, rank)
 
-            def step(reduce=True):
+            reducer = pnr_train.GradReducer(tnet, world)      # world 1: a no-op
+
+            def step(reduce="overlapped"):
                 opt.zero_grad(set_to_none=True)
                 _, loss, _, _ = wrap(tb)
                 loss.backward()
-                if reduce:
+                if reduce == "overlapped":      # the fine NeRF's bucket goes out from its last gradient hook, beside the coarse backward
+                    reducer.finish()
+                elif reduce == "flat":          # ONE bucket after the whole backward
                     pnr_train.allreduce_grads(tnet, world)
                 opt.step()
                 return loss
@@ -676,11 +680,19 @@ def main():
                 ll = step()
             sync()
             tdt = (time.perf_counter() - t0) / args.train_steps
-            ar_ms = None
+            ar_ms, tdt_flat = None, None
             if world > 1:
-                tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
+                # the same steps with the one-bucket form (hooks removed), so that the line says what the overlap is worth
+                reducer.remove()
+                step("flat")
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.train_steps):
+                    step("flat")
+                sync()
+                tt = torch.tensor([tdt, (time.perf_counter() - t0) / args.train_steps], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tdt = float(tt.item())
+                tdt, tdt_flat = float(tt[0].item()), float(tt[1].item())
                 # the collective alone: ONE flat bucket of every gradient, RCCL over xGMI
                 ar_ms = event_ms(lambda: pnr_train.allreduce_grads(tnet, world), 10, 3)
             graph_ms = None
@@ -709,7 +721,10 @@ def main():
             train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms, "rays_per_rank": args.train_rays,
                           "Msamples_per_s_fwd_bwd": round(S_step * world / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
-                          "grad_allreduce": "flat bucket of %d fp32, %s" % (n_par, "RCCL (nccl)" if world > 1 else "single rank: skipped"),
+                          "grad_allreduce": ("one bucket per NeRF (%d fp32 in all), the fine level's launched from its last gradient hook beside the coarse "
+                                             "backward, RCCL (nccl): train.GradReducer" % n_par) if world > 1
+                                            else "flat bucket of %d fp32, single rank: skipped" % n_par,
+                          "ms_per_step_flat_bucket": None if tdt_flat is None else round(tdt_flat * 1e3, 3),
                           "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
                           "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE",
                           # the three MLP kernels of the step alone (hipEvents, both levels summed; algorithmic bytes; HBM peak 8 TB/s)

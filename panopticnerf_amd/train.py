@@ -112,3 +112,91 @@ def allreduce_grads(module, world=None, group=None):
         n = p.grad.numel()
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
+
+
+class GradReducer:
+    """Gradient averaging overlapped with the backward ("overlap the all-reduce of one level's network with the
+    other level's backward").  The two levels of render_rays are independent autograd subgraphs (z of the fine level comes from
+    the detached sampler), and the engine runs the fine level's LevelFn.backward first: when the last gradient of the fine NeRF
+    has been accumulated its flat bucket goes out as an ASYNCHRONOUS all-reduce (RCCL's own stream under 'nccl'), beside the
+    ~2 ms of coarse-level k_mlp_bwd / k_wgrad; only the coarse bucket's collective is exposed.  Two latency-bound collectives of
+    ~2.5 MB instead of one of 5 MB.
+
+        reducer = GradReducer(net)           # once; world 1: a no-op
+        loss.backward(); reducer.finish(); optimizer.step()
+
+    Every rank launches the same buckets in the same order: a bucket whose parameters all received a gradient goes out from
+    the hook that completes it (fine, then coarse); anything left -- a module with an unused parameter, parameters outside the
+    NeRFs -- goes out in finish(), in module order.  For trainers that wrap the network in DistributedDataParallel none of this is needed (DDP's reducer
+    does the same job, tests/test_integration.py); allreduce_grads() is the one-bucket form without hooks."""
+
+    def __init__(self, net, world=None, group=None):
+        self.group = group
+        self.world = world or (dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1)
+        self.buckets, self.works, self.handles = [], [], []
+        if self.world == 1:
+            return
+        seen = set()
+        levels = [1, 0] if getattr(net, "N_importance", 0) > 0 else [0]
+        for lv in levels:                      # fine first: the order the backward completes them in
+            m = net.nerf(lv)
+            if id(m) in seen:              # cfg.share_coarse_fine: one NeRF, one bucket (autograd sums both levels' contributions
+                continue                   # before the parameter's AccumulateGrad -- and with it the hook -- runs once)
+            seen.add(id(m))
+            ps = [p for p in m.parameters() if p.requires_grad]
+            self.buckets.append({"params": ps, "hits": 0, "sent": False})
+        inside = {id(p) for b in self.buckets for p in b["params"]}
+        rest = [p for p in net.parameters() if p.requires_grad and id(p) not in inside]
+        if rest:
+            self.buckets.append({"params": rest, "hits": 0, "sent": False})
+        for b in self.buckets:
+            for p in b["params"]:
+                self.handles.append(p.register_post_accumulate_grad_hook(self._hook(b)))
+
+    def _hook(self, b):
+        def fn(_p):
+            b["hits"] += 1
+            if b["hits"] == len(b["params"]) and self._in_order(b):
+                self._send(b)
+        return fn
+
+    def _in_order(self, b):
+        # a bucket may go out from a hook only if every bucket in front of it has: the launch order is the same on every rank
+        for o in self.buckets:
+            if o is b:
+                return True
+            if not o["sent"]:
+                return False
+        return True
+
+    def _send(self, b):
+        ps = [p for p in b["params"] if p.grad is not None]
+        b["sent"] = True
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, ps))
+
+    def finish(self):
+        """After backward(): launch what no hook launched, wait for every collective, write the means back."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if not b["sent"]:
+                self._send(b)
+        for work, flat, ps in self.works:
+            work.wait()
+            flat.div_(self.world)
+            o = 0
+            for p in ps:
+                n = p.grad.numel()
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                o += n
+        self.works = []
+        for b in self.buckets:
+            b["hits"], b["sent"] = 0, False
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

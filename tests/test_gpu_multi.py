@@ -82,6 +82,19 @@ def _worker(rank, world, port, q):
         err = max(((p.grad - want[n]).norm() / want[n].norm().clamp(min=1e-12)).item() for n, p in net.named_parameters())
         ok["flat_bucket"] = err < (1e-6 if world == 1 else 2e-2)        # world > 1: bf16 kernels on different ray subsets
         ok["flat_bucket_err"] = err
+        flat = {n: p.grad.clone() for n, p in net.named_parameters()}
+        # ... the overlapped per-level buckets (train.GradReducer: the fine NeRF's all-reduce beside the coarse backward) give
+        # the same means as the flat bucket (same kernels on the same shard: only the collective's split differs)
+        red = train.GradReducer(net, world)
+        net.zero_grad(set_to_none=True)
+        wrap(_batch(full, box, ids, sel, dev))[1].backward()
+        if world > 1:
+            ok["reducer_fine_bucket_sent_in_backward"] = red.buckets[0]["sent"]
+        red.finish()
+        red.remove()
+        err = max(((p.grad - flat[n]).norm() / flat[n].norm().clamp(min=1e-12)).item() for n, p in net.named_parameters())
+        ok["reducer"] = err < 1e-6
+        ok["reducer_err"] = err
         # ... and an unchanged DDP wrap (the reference trainer's form)
         from torch.nn.parallel import DistributedDataParallel as DDP
         ddp = DDP(wrap, device_ids=[rank])

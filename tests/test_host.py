@@ -145,6 +145,64 @@ def _ar_worker(rank, world, port, q):
     q.put((rank, ok))
 
 
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticnerf_amd import train
+    ok = True
+    for share in (False, True):
+        torch.manual_seed(0)
+        net = make_network(NS(D=2, W=128, skips=[], num_classes=3, N_importance=8, share_coarse_fine=share))
+        red = train.GradReducer(net, world)
+        assert len(red.buckets) == (1 if share else 2)
+        sent_in_backward = []
+        for step in range(2):                                  # twice: the reducer re-arms itself in finish()
+            for p in net.parameters():
+                p.grad = None
+            unused = net.nerf_0.rgb_linear.bias                # never enters the loss: its bucket completes only in finish()
+            loss = 0.0
+            for lv in ((1, 0) if not share else (0, 0)):       # a shared NeRF is used by both levels
+                for i, p in enumerate(net.nerf(lv).parameters()):
+                    if p is not unused:
+                        loss = loss + (p * float((rank + 1) * (i + 1) * (lv + 1))).sum()
+            loss.backward()
+            sent_in_backward.append([b["sent"] for b in red.buckets])
+            red.finish()
+            for lv in ((1, 0) if not share else (0,)):
+                for i, p in enumerate(net.nerf(lv).parameters()):
+                    if p is unused:
+                        ok = ok and p.grad is None
+                        continue
+                    uses = 2 if share else 1
+                    want = 1.5 * (i + 1) * (lv + 1) * uses     # mean over ranks 1, 2 of (rank + 1) * ...
+                    ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+        # the fine bucket (complete: every parameter used) went out DURING backward; the coarse one (an unused parameter) in finish()
+        ok = ok and (sent_in_backward == ([[False]] * 2 if share else [[True, False]] * 2))
+        red.remove()
+    one = train.GradReducer(make_network(NS(D=2, W=128, skips=[])), 1)
+    one.finish()                                               # world 1: nothing registered, nothing to do
+    ok = ok and not one.handles
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_grad_reducer_overlapped_buckets_world2_gloo():
+    """train.GradReducer (the fine network's all-reduce beside the coarse level's backward): per-NeRF buckets launched
+    from post-accumulate hooks in a rank-independent order, the rest in finish(); means equal the flat-bucket form's."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def test_flat_bucket_grad_allreduce_world2_gloo():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
