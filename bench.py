@@ -84,6 +84,20 @@ def traffic(kernel, n_rays_launch, config):
         return None
 
 
+def rocprof_recorded(kernel, bytes_per_launch):
+    """The rocprofv3 kernel-trace average of a standalone compositing kernel from the last committed profile of this bench
+    command (profiles/latest_traffic.json, written by tools/update_traffic.py), quoted beside the run's own hipEvent timing;
+    {} when no profile recorded it."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            t = json.load(f)[kernel]
+        us = float(t["rocprof_avg_us"])
+        return {"rocprof_avg_us_recorded": us, "rocprof_frac_recorded": round(bytes_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "rocprof_source": t.get("rocprof_source")}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def make_train_batch(cfg, rays, box, ids, n_rays, C, K, dev, seed):
     """A training batch whose targets are LEARNABLE: a teacher network (same architecture, different seed) renders the
     batch's rays; its fine-level colour / depth are the rgb / stereo-depth targets and the argmax of its composited
@@ -636,6 +650,8 @@ def main():
                        "traffic": traffic("k_composite", Rc, args.config) if N == 192 else None,
                        "ms_per_launch": round(cms, 4), "bytes_per_ray": bytes_ray, "timing": "hipEvents around 20 back-to-back launches",
                        "note": "training / two-kernel path only: the fused inference step does not launch it"}
+                if args.config == 5 and Rc == 65536:      # what the profile's bench run launched
+                    out.update(rocprof_recorded("k_composite" if N == 192 else "k_composite_coarse", Rc * bytes_ray))
                 # the pure-read probe walks the image 4 samples per lane; it is a ceiling only where that mapping is the kernel's
                 if read_gbs > gbs:
                     out.update(pure_read_same_pattern_gbs=round(read_gbs, 1), frac_of_pure_read=round(gbs / read_gbs, 4))

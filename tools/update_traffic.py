@@ -1,7 +1,9 @@
 """profiles/latest_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (rocpd sqlite): HBM bytes of the
 fine-level launch (the largest dispatch) of the fused MLP and of the compositing kernel.  FETCH_SIZE is doubled per
 MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported.
-usage: python tools/update_traffic.py <fetch.db> <write.db> <summary file name for the note>"""
+With a kernel-trace database as 4th argument the same record also takes the rocprofv3 average launch durations of the two standalone
+compositing kernels (bench.py quotes them beside its own hipEvent timing: round-3 verdict item 5).
+usage: python tools/update_traffic.py <fetch.db> <write.db> <summary file name for the note> [<kernel-trace.db>]"""
 import json
 import os
 import sqlite3
@@ -17,6 +19,7 @@ def biggest(db, counter, pat):
 
 
 fetch_db, write_db, note = sys.argv[1:4]
+trace_db = sys.argv[4] if len(sys.argv) > 4 else None
 sys.path.insert(0, ROOT)
 from panopticnerf_amd.renderer import chunk_plan      # the largest dispatch of a full frame is the renderer's first chunk
 LAUNCH_RAYS = {"k_mlp_pp_fused": chunk_plan(1408 * 376, 65536)[0][1], "k_composite": 65536}
@@ -31,5 +34,11 @@ for key, pat in (("k_mlp_pp_fused", "%k_mlp_pp%"), ("k_composite", "%k_composite
     out[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024), "rays_per_launch": LAUNCH_RAYS[key],
                 "note": "fine-level launch (%d rays x 192: the largest dispatch); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128 B requests "
                         "as 64 B on wide coalesced reads); WRITE_SIZE as reported (uncalibrated); profiles/" % LAUNCH_RAYS[key] + note}
+if trace_db:
+    cur = sqlite3.connect(trace_db).cursor()
+    for key, pat in (("k_composite", "%k_composite<true, 64%"), ("k_composite_coarse", "%k_composite2<8, 2%")):
+        r = cur.execute("select count(*), avg(end-start) from kernels where name like ?", (pat,)).fetchone()
+        if r and r[0]:
+            out.setdefault(key, {}).update(rocprof_launches=int(r[0]), rocprof_avg_us=round(float(r[1]) / 1e3, 2), rocprof_source="profiles/" + note)
 json.dump(out, open(os.path.join(ROOT, "profiles", "latest_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
