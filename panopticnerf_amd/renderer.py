@@ -142,6 +142,20 @@ class Renderer:
             level(1, z_fine)
         return ret
 
+    def _empty_outputs(self, lead, has_box, dev):
+        """render() of zero rays: every output key of a non-empty call, with zero rows and no launch (the edge case a caller
+        hits with an empty shard: n_rays < world, or a mask that selects nothing)."""
+        n0 = self.net.nerf(0)
+        C, K = n0.n_sem, n0.n_inst
+        ret = {}
+        for lv, N in ((0, self.N_samples),) + (((1, self.N_samples + self.N_importance),) if self.N_importance > 0 else ()):
+            need_w = self.keep_weights or (lv == 0 and self.N_importance > 0)
+            m = ops._maps(None, 0, N, C, K, True if has_box else None, True if has_box else None, need_w, dev)
+            m["z_vals"] = torch.empty((0, N), device=dev, dtype=torch.float32)
+            for k, v in m.items():
+                ret[f"{k}_{lv}"] = v.reshape(*lead, *v.shape[1:])
+        return ret
+
     # --- the plugin entry point (row a1)
     def render(self, batch):
         rays = batch["rays"]
@@ -165,6 +179,8 @@ class Renderer:
             u = u.reshape(R, -1).float().contiguous()
         train = self.net.training
         self._overflow = None
+        if R == 0:
+            return self._empty_outputs(lead, box is not None, rays.device)
         outs = []
         frame = None        # inference frames of several chunks: frame-sized maps, every later chunk writes its own rows
         for s, e in chunk_plan(R, self.chunk_size):

@@ -31,7 +31,12 @@ def gather_maps(local, n_rays, rank, world, group=None):
     keys = list(local)
     cols, parts = [], []
     for k in keys:
-        flat = _to_carrier(local[k].reshape(local[k].shape[0], -1).contiguous(), k)
+        v = local[k]
+        width = 1
+        for d in v.shape[1:]:
+            width *= int(d)
+        # explicit width: reshape(n, -1) is ambiguous for an EMPTY shard (a frame with fewer rays than ranks)
+        flat = _to_carrier(v.reshape(v.shape[0], width).contiguous(), k)
         cols.append(flat.shape[1])
         parts.append(flat)
     first = local[keys[0]]
@@ -47,7 +52,9 @@ def gather_maps(local, n_rays, rank, world, group=None):
     out, c0 = {}, 0
     for k, c in zip(keys, cols):
         v = local[k]
-        out[k] = _from_carrier(full[:, c0:c0 + c].contiguous(), v.dtype).reshape((n_rays,) + tuple(v.shape[1:]))
+        # clone(), not contiguous(): a one-row slice counts as contiguous where it lies, and its odd storage offset cannot be
+        # viewed as an 8-byte type
+        out[k] = _from_carrier(full[:, c0:c0 + c].clone(memory_format=torch.contiguous_format), v.dtype).reshape((n_rays,) + tuple(v.shape[1:]))
         c0 += c
     return out
 

@@ -291,3 +291,31 @@ def test_a_ranks_share_of_the_frame_is_one_chunk(dev):
         two = make_renderer(cfg, net).render(b)
     for k in one:
         assert torch.equal(one[k], two[k]), k
+
+
+@pytest.mark.parametrize("with_box", [False, True])
+def test_render_of_zero_rays_returns_every_key_with_zero_rows(dev, with_box):
+    # empty input (a mask that selects nothing, a shard of a frame with fewer rays than ranks): same keys, dtypes and trailing
+    # shapes as a non-empty render, zero rows, no kernel launched -- and a one-ray render works (ragged: far below one tile)
+    C, K = 5, 3
+    cfg, net, oc, params = _setup(dev, C, K, "bf16", chunk_size=4096)
+    rays = synthetic.camera_rays()[::53][:7].contiguous().to(dev)
+    b = {"rays": rays[None]}
+    if with_box:
+        box, ids = synthetic.random_boxes(16, C, K)
+        b.update(bbox=box.to(dev), bbox_ids=ids.to(dev))
+    rend = make_renderer(cfg, net)
+    with torch.no_grad():
+        some = rend.render(b)
+        none = rend.render(dict(b, rays=rays[None, :0]))
+        one = rend.render(dict(b, rays=rays[None, :1]))
+    assert set(none) == set(some) == set(one)
+    for k, v in some.items():
+        assert none[k].shape == (1, 0) + tuple(v.shape[2:]) and none[k].dtype == v.dtype and none[k].device == v.device, k
+        assert one[k].shape == (1, 1) + tuple(v.shape[2:]), k
+        assert torch.equal(one[k][0, 0], v[0, 0]), k                 # rays are independent: ray 0 alone == ray 0 in a batch
+    with torch.enable_grad():
+        net.train()
+        empty = make_renderer(cfg, net).render(dict(b, rays=rays[None, :0]))
+        net.eval()
+    assert all(v.shape[1] == 0 for v in empty.values())

@@ -246,6 +246,8 @@ def _worker(rank, world, port, n_rays, q):
     rays = synthetic.camera_rays()[:: (1408 * 376) // n_rays][:n_rays].contiguous()
 
     def render(r):
+        if r.shape[0] == 0:      # an empty shard (fewer rays than ranks): what Renderer._empty_outputs returns on the GPU
+            return {"rgb_1": torch.empty(0, 3), "depth_1": torch.empty(0), "semantic_1": torch.empty(0, 3), "z_vals_1": torch.empty(0, 32)}
         o = to.render_rays(params, cfg, r, 16, 16)
         return {k: o[k] for k in ("rgb_1", "depth_1", "semantic_1", "z_vals_1")}
 
@@ -293,7 +295,7 @@ def _worker(rank, world, port, n_rays, q):
     q.put((rank, ok))
 
 
-@pytest.mark.parametrize("n_rays", [10, 7])      # even and ragged split over 2 ranks
+@pytest.mark.parametrize("n_rays", [10, 7, 1])      # even and ragged split over 2 ranks; one ray: rank 1's shard is empty
 def test_sharded_render_world2_gloo(n_rays):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
