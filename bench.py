@@ -128,7 +128,8 @@ def make_train_batch(cfg, rays, box, ids, n_rays, C, K, dev, seed):
 
 def graph_step_child(args):
     """Child process of the training-step measurement: the same step (NetworkWrapper render + fused losses, backward through
-    the HIP kernels, Adam(capturable), in-place repack of both weight images) captured into ONE HIP graph; prints
+    the HIP kernels, Adam(capturable, fused), in-place repack of both weight images) as panopticnerf_amd.train.GraphedStep runs
+    it -- captured into ONE HIP graph, replayed per step after copying the batch into its static buffers; prints
     {"graph_ms": ms per replayed step}.  Separate process: see the call site."""
     from panopticnerf_amd import NetworkWrapper, make_network, synthetic
     dev = torch.device("cuda", 0)
@@ -139,35 +140,20 @@ def graph_step_child(args):
     tnet = make_network(cfg).to(dev).train()
     synthetic.trained_like_(tnet)
     wrap = NetworkWrapper(tnet, cfg)
-    opt = torch.optim.Adam(tnet.parameters(), lr=5e-4, capturable=True)
+    opt = torch.optim.Adam(tnet.parameters(), lr=5e-4, capturable=True, fused=True)
     rays = synthetic.camera_rays().to(dev)
     box = ids = None
     if c["bbox"]:
         box, ids = (t.to(dev) for t in synthetic.random_boxes(64, c["num_classes"], max(c["num_instances"], 1)))
     tb = make_train_batch(cfg, rays, box, ids, args.train_rays, c["num_classes"], c["num_instances"], dev, 0)
 
-    def step():
-        opt.zero_grad(set_to_none=False)
-        _, loss, _, _ = wrap(tb)
-        loss.backward()
-        opt.step()
-        return loss
-
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
-    graph.replay()
+    from panopticnerf_amd import train as pnr_train
+    step = pnr_train.GraphedStep(wrap, opt, tb)          # warm-up on a side stream, undone in place; then the capture
+    step(tb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
-        graph.replay()
+        step(tb)                                         # copies the batch into the static buffers, replays the graph
     torch.cuda.synchronize()
     print(json.dumps({"graph_ms": round((time.perf_counter() - t0) / args.train_steps * 1e3, 3)}), flush=True)
 
@@ -673,7 +659,8 @@ def main():
             tnet = make_network(cfg).to(dev).train()
             synthetic.trained_like_(tnet)
             wrap = NetworkWrapper(tnet, cfg)       # the trainer's loss wrapper: render + fused losses
-            opt = torch.optim.Adam(tnet.parameters(), lr=5e-4)
+            # fused=True: torch's single-kernel Adam (the foreach default is ~10 small kernels = 0.15 ms of this 8 ms step)
+            opt = torch.optim.Adam(tnet.parameters(), lr=5e-4, fused=True)
             tb = make_train_batch(cfg, rays, box, ids, args.train_rays, N_SEM, N_INST, dev, rank)
 
             reducer = pnr_train.GradReducer(tnet, world)      # world 1: a no-op
@@ -734,7 +721,9 @@ def main():
                 ktable = {"error": "%s: %s" % (type(e).__name__, e)}
             bps = train_bytes_per_sample(c)
             tbs = bps * S_step / tdt / 1e12
-            train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms, "rays_per_rank": args.train_rays,
+            train_info = {"ms_per_step": round(tdt * 1e3, 3), "ms_per_step_as_one_hip_graph": graph_ms,
+                          "forms": "ms_per_step: the eager loop (wrapper(batch); loss.backward(); optimizer.step()); ms_per_step_as_one_hip_graph: "
+                                   "the same step through panopticnerf_amd.train.GraphedStep (bit-identical, tests/test_gpu_backward.py)", "rays_per_rank": args.train_rays,
                           "Msamples_per_s_fwd_bwd": round(S_step * world / tdt / 1e6, 2),
                           "loss_first": round(l0, 5), "loss_last": round(ll.item(), 5),
                           "grad_allreduce": ("one bucket per NeRF (%d fp32 in all), the fine level's launched from its last gradient hook beside the coarse "
@@ -743,6 +732,7 @@ def main():
                           "ms_per_step_flat_bucket": None if tdt_flat is None else round(tdt_flat * 1e3, 3),
                           "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
                           "losses": "NetworkWrapper: rgb, depth, semantic/instance 2D CE on learned + fixed fields, 3D CE",
+                          "optimizer": "torch.optim.Adam(lr=5e-4, fused=True)",
                           # the three MLP kernels of the step alone (hipEvents, both levels summed; algorithmic bytes; HBM peak 8 TB/s)
                           "kernels": ktable,
                           # forward + data-gradient + weight-gradient GEMMs = 3x the forward's algorithmic FLOPs; the step is

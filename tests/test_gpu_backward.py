@@ -291,6 +291,63 @@ def test_training_step_is_graph_capturable(dev):
         assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_step_replays_equal_eager_steps_on_changing_batches(dev, split):
+    """train.GraphedStep: the whole step as one HIP graph (or, with a `reduce` callable, forward + backward | eager collective |
+    optimiser).  Constructing it trains nothing (the warm-up steps are undone in place); replays on CHANGING batches equal eager
+    steps bit for bit -- losses and every parameter; a batch of another shape is refused."""
+    from types import SimpleNamespace as NS
+    import copy
+    from panopticnerf_amd import NetworkWrapper, make_network, synthetic, train as pnr_train
+    C, K = 6, 4
+    cfg = NS(N_samples=32, N_importance=32, num_classes=C, num_instances=K, precision="bf16", D=4, W=128, skips=[1])
+    torch.manual_seed(6)
+    net_e = make_network(cfg).to(dev).train()
+    net_g = copy.deepcopy(net_e)
+    R = 256
+    box, ids = synthetic.random_boxes(16, C, K, seed=2)
+    g = torch.Generator().manual_seed(2)
+
+    def batch(i):
+        rays = synthetic.camera_rays()[i::2003][:R].contiguous()
+        return {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
+                "rgb": torch.rand(1, R, 3, generator=g).to(dev), "depth": (torch.rand(1, R, generator=g) * 20 - 2).to(dev),
+                "pseudo_label": torch.randint(-1, C, (1, R), generator=g).to(dev), "instance_label": torch.randint(-1, K, (1, R), generator=g).to(dev)}
+
+    batches = [batch(i) for i in range(4)]
+    wrap_e, wrap_g = NetworkWrapper(net_e, cfg), NetworkWrapper(net_g, cfg)
+    opt_e = torch.optim.Adam(net_e.parameters(), lr=1e-3, capturable=True, fused=True)
+    opt_g = torch.optim.Adam(net_g.parameters(), lr=1e-3, capturable=True, fused=True)
+    calls = []
+    step = pnr_train.GraphedStep(wrap_g, opt_g, batches[3], reduce=(lambda: calls.append(1)) if split else None)
+    n_warm = len(calls)
+    for a, b in zip(net_e.parameters(), net_g.parameters()):
+        assert torch.equal(a, b)                                   # construction trained nothing
+    for st in opt_g.state.values():
+        assert all(float(v.abs().sum()) == 0.0 for v in st.values() if torch.is_tensor(v))
+    losses_g, losses_e = [], []
+    for b in batches[:3]:
+        _, loss, stats = step(b)
+        losses_g.append(loss.item())
+        assert stats["loss"].item() == losses_g[-1]
+    for b in batches[:3]:
+        opt_e.zero_grad(set_to_none=False)
+        _, loss, _, _ = wrap_e(b)
+        loss.backward()
+        opt_e.step()
+        losses_e.append(loss.item())
+    assert losses_g == losses_e, (losses_g, losses_e)
+    assert losses_g[0] != losses_g[1]                              # the batches do differ
+    for (n, a), b in zip(net_e.named_parameters(), net_g.parameters()):
+        assert torch.equal(a, b), n
+    if split:
+        assert len(calls) == n_warm + 3                            # the collective's slot ran eagerly once per step
+    with pytest.raises(ValueError, match="captured step takes"):
+        step(dict(batches[0], rays=batches[0]["rays"][:, :100]))
+    with pytest.raises(ValueError, match="capturable"):
+        pnr_train.GraphedStep(wrap_g, torch.optim.Adam(net_g.parameters(), lr=1e-3), batches[0])
+
+
 @pytest.mark.parametrize("S_rays", [(37, 24), (16, 64)])      # 888 samples (ragged: S_pad = 1024) and 1024 (S = S_pad)
 def test_saved_tensors_layout_gates_and_padding(dev, S_rays):
     """The training buffers as include/pnr.h documents them: read back through the saved-tensor layout (tests/_wgrad_ref.

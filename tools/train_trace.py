@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 cfg = NS(N_samples=64, N_importance=128, num_classes=45, num_instances=32, precision="bf16")
 net = make_network(cfg).to(dev).train(); synthetic.trained_like_(net)
 wrap = NetworkWrapper(net, cfg)
-opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)       # as bench.py's training step
 g = torch.Generator(device=dev).manual_seed(0)
 rays = synthetic.camera_rays().to(dev); box, ids = synthetic.random_boxes(64, 45, 32)
 R = 4096
