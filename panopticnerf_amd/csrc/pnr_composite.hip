@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a)
                     const f4 v = load4<CH_MAJOR>(a.raw, a.stride_s, a.stride_c, s0, ch0 + c, active);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float m2 = fmaxf(mx.v[k], v.v[k]);
-                        den.v[k] = den.v[k] * expf(mx.v[k] - m2) + expf(v.v[k] - m2);
-                        mx.v[k] = m2;
+                        const float d = v.v[k] - mx.v[k], e = expf(-fabsf(d));      // one expf per value (the other factor is expf(0))
+                        den.v[k] = d <= 0.0f ? den.v[k] + e : den.v[k] * e + 1.0f;
+                        mx.v[k] = fmaxf(mx.v[k], v.v[k]);
                     }
                 }
             };
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(256) void k_composite2(CompositeArgs a)
                     row(a.raw + (int64_t)(ch0 + c) * sc, v);
 #pragma unroll
                     for (int k = 0; k < M; ++k) {
-                        const float m2 = fmaxf(mx[k], v[k]);
-                        den[k] = den[k] * expf(mx[k] - m2) + expf(v[k] - m2);
-                        mx[k] = m2;
+                        const float d = v[k] - mx[k], e = expf(-fabsf(d));          // one expf per value (the other factor is expf(0))
+                        den[k] = d <= 0.0f ? den[k] + e : den[k] * e + 1.0f;
+                        mx[k] = fmaxf(mx[k], v[k]);
                     }
                 }
             };

@@ -29,6 +29,32 @@ struct CompositeBwdArgs {
 };
 
 struct f4 { float v[4]; };
+// one row's arithmetic at a time: without the fence hipcc interleaves the expf chains of a whole batch of rows (8 rows x 4 samples)
+// for instruction-level parallelism and needs ~175 registers for it -- at the 128 the launch bound grants it spilled ~45 of them
+#ifndef BWD_FENCE
+#define BWD_FENCE 1
+#endif
+#if BWD_FENCE
+#define BWD_ROW_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define BWD_ROW_FENCE ((void)0)
+#endif
+// Per ray-group width (SUB lanes per ray): waves per SIMD the launch bound asks for, logit rows per pipelined batch (two batches
+// resident), rows in flight in the log-sum-exp / dot passes.  One ray per wave (N > 64: SUB >= 32) means R waves in all -- 4096 at the
+// training batch, 16 per CU -- so the kernel is capped at 128 VGPRs (4 waves per SIMD: the launch is resident at once; at its
+// natural 149 registers it ran in two rounds) and keeps little in flight; several rays per wave (N <= 64) means few waves and
+// nothing to gain from the cap, so those instances keep 3 waves per SIMD and deeper batches.  Same box, 4096 rays, 45 + 32 fields,
+// tools/composite_bwd_time.py (d_raw bit-identical throughout): N = 192  229 us before -> 168 (cap 4, 2 + 4 rows) / 176-179 (cap 4,
+// 4 + 4 / 4 + 8 rows) / 192 (no cap, pipelined only);  N = 64  95 -> 77 (no cap, 4 + 8) / 84-86 (capped).
+#ifndef BWD_WAVES
+#define BWD_WAVES(SUB) ((SUB) >= 32 ? 4 : 3)
+#endif
+#ifndef BWD_PB_OF
+#define BWD_PB_OF(SUB) ((SUB) >= 32 ? 2 : 4)
+#endif
+#ifndef BWD_CB_OF
+#define BWD_CB_OF(SUB) ((SUB) >= 32 ? 4 : 8)
+#endif
 
 __device__ __forceinline__ f4 ld4(const float* p, bool active)
 {
@@ -38,16 +64,31 @@ __device__ __forceinline__ f4 ld4(const float* p, bool active)
     o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
     return o;
 }
+// Row access as (wave-uniform row pointer) + (32-bit per-lane byte offset): hipcc then selects the scalar-base form of
+// global_load / global_store (SGPR pair + one shared VGPR offset) instead of materialising a 64-bit VGPR address per row in
+// flight -- two registers per row, which is what pushed this kernel past 128 VGPRs (3 waves per SIMD instead of 4).
+__device__ __forceinline__ f4 ld4o(const float* row, uint32_t ob, bool active)
+{
+    return ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ob), active);
+}
+__device__ __forceinline__ void st4(float* p, const f4& v, bool active);
+__device__ __forceinline__ void st4o(float* row, uint32_t ob, const f4& v, bool active)
+{
+    st4(reinterpret_cast<float*>(reinterpret_cast<char*>(row) + ob), v, active);
+}
 __device__ __forceinline__ void st4(float* p, const f4& v, bool active)
 {
     if (active) *reinterpret_cast<float4*>(p) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
 }
 
-template <int SUB>
-__global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
+// SM: softmax compositing (sem_mode 1) -- a template parameter so that the default (logit compositing) instance carries neither
+// the dot products nor their branches in its register budget
+template <int SUB, bool SM>
+__global__ __launch_bounds__(256, BWD_WAVES(SUB)) void k_composite_bwd(CompositeBwdArgs a)
 {
     constexpr int RPW = 64 / SUB;
-    constexpr int CB = 8;                   // channel rows in flight per lane
+    constexpr int CB = BWD_CB_OF(SUB);      // channel rows in flight per lane (log-sum-exp / dot passes)
+    constexpr int BWD_PB = BWD_PB_OF(SUB);  // logit rows per pipelined batch of the main pass
     const int lane = threadIdx.x & 63;
     const int N = a.N, nq4 = N >> 2;
     const int q = lane & (SUB - 1), g = lane / SUB;
@@ -62,9 +103,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
         const int64_t s0 = rayc * N + (active ? 4 * q : 0);
 
         // ---- recompute alpha, T, w (as the forward kernel does)
-        const f4 zz = ld4(a.z + s0, active);
-        f4 sg = ld4(a.raw + 3 * a.sc + s0, active);
-        if (a.noise) { const f4 nz = ld4(a.noise + s0, active); for (int k = 0; k < 4; ++k) sg.v[k] += nz.v[k]; }
+        const uint32_t ob = (uint32_t)s0 * 4u;          // byte offset of the lane's first sample in a row (R * N < 2^30: the launcher checks)
+        const f4 zz = ld4o(a.z, ob, active);
+        f4 sg = ld4o(a.raw + 3 * a.sc, ob, active);
+        if (a.noise) { const f4 nz = ld4o(a.noise, ob, active); for (int k = 0; k < 4; ++k) sg.v[k] += nz.v[k]; }
         const float dx = a.rays[rayc * 8 + 3], dy = a.rays[rayc * 8 + 4], dz = a.rays[rayc * 8 + 5];
         const float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float znext = __shfl_down(zz.v[0], 1, 64);
@@ -98,7 +140,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
         f4 G;
         {
             const float gd = a.g_depth ? a.g_depth[rayc] : 0.0f, ga = a.g_acc ? a.g_acc[rayc] : 0.0f;
-            const f4 gw = a.g_w ? ld4(a.g_w + s0, active) : f4{{0, 0, 0, 0}};
+            const f4 gw = a.g_w ? ld4o(a.g_w, ob, active) : f4{{0, 0, 0, 0}};
 #pragma unroll
             for (int k = 0; k < 4; ++k) G.v[k] = fmaf(gd, zz.v[k], ga) + gw.v[k];
         }
@@ -121,21 +163,31 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             for (int c0 = 0; c0 < nch; c0 += CB) {
                 f4 v[CB];
 #pragma unroll
-                for (int j = 0; j < CB; ++j) v[j] = ld4(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc + s0, active);
+                for (int j = 0; j < CB; ++j) v[j] = ld4o(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc, ob, active);
 #pragma unroll
                 for (int j = 0; j < CB; ++j) {
                     if (c0 + j >= nch) break;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float m2 = fmaxf(mx.v[k], v[j].v[k]);
-                        den.v[k] = den.v[k] * expf(mx.v[k] - m2) + expf(v[j].v[k] - m2);
-                        mx.v[k] = m2;
+                        // online log-sum-exp with ONE expf per value: of the two factors expf(mx - m2), expf(v - m2) one is always
+                        // expf(0) = 1 (same bits as the two-expf form)
+                        const float d = v[j].v[k] - mx.v[k], e = expf(-fabsf(d));
+                        den.v[k] = d <= 0.0f ? den.v[k] + e : den.v[k] * e + 1.0f;
+                        mx.v[k] = fmaxf(mx.v[k], v[j].v[k]);
                     }
+                    BWD_ROW_FENCE;
                 }
             }
         };
-        if (ces != 0.0f || (a.sem_mode && a.g_sem)) lse(a.C, 4, mx_s, den_s);
-        if (cei != 0.0f || (a.sem_mode && a.g_inst)) lse(a.K, 4 + a.C, mx_i, den_i);
+        // The 3D term touches labelled samples only, and most rays cross no box at all: a wave none of whose samples carries a
+        // label skips the pass (wave-uniform; mx / den are then never read -- the `lab < 0` guard below).  The pass is a read of
+        // every logit row plus two expf per value: at 4096 rays (16 waves per CU, one ray group each) it was half the kernel.
+        bool lab_s = false, lab_i = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lab_s |= ls[k] >= 0 && ls[k] < a.C; lab_i |= li[k] >= 0 && li[k] < a.K; }
+        const bool wave_s = __builtin_amdgcn_ballot_w64(lab_s) != 0, wave_i = __builtin_amdgcn_ballot_w64(lab_i) != 0;
+        if ((ces != 0.0f && wave_s) || (SM && a.g_sem)) lse(a.C, 4, mx_s, den_s);
+        if ((cei != 0.0f && wave_i) || (SM && a.g_inst)) lse(a.K, 4 + a.C, mx_i, den_i);
         // softmax compositing: map_c = sum_i w_i s_{i,c}, s = softmax(x_i).  Needs dot_i = sum_c g_c s_{i,c}:
         //   dL/dw_i += dot_i,   d x_{i,c} = w_i s_{i,c} (g_c - dot_i)
         f4 dot_s = {{0, 0, 0, 0}}, dot_i = {{0, 0, 0, 0}};
@@ -143,7 +195,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             for (int c0 = 0; c0 < nch; c0 += CB) {
                 f4 v[CB];
 #pragma unroll
-                for (int j = 0; j < CB; ++j) v[j] = ld4(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc + s0, active);
+                for (int j = 0; j < CB; ++j) v[j] = ld4o(a.raw + (int64_t)(ch0 + (c0 + j < nch ? c0 + j : nch - 1)) * a.sc, ob, active);
 #pragma unroll
                 for (int j = 0; j < CB; ++j) {
                     if (c0 + j >= nch) break;
@@ -153,12 +205,12 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
                 }
             }
         };
-        if (a.sem_mode && a.g_sem) gdot(a.C, 4, a.g_sem, mx_s, den_s, dot_s);
-        if (a.sem_mode && a.g_inst) gdot(a.K, 4 + a.C, a.g_inst, mx_i, den_i, dot_i);
+        if (SM && a.g_sem) gdot(a.C, 4, a.g_sem, mx_s, den_s, dot_s);
+        if (SM && a.g_inst) gdot(a.K, 4 + a.C, a.g_inst, mx_i, den_i, dot_i);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float gc = a.g_rgb ? a.g_rgb[rayc * 3 + c] : 0.0f;
-            const f4 r = ld4(a.raw + (int64_t)c * a.sc + s0, active);
+            const f4 r = ld4o(a.raw + (int64_t)c * a.sc, ob, active);
             f4 dr;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -166,22 +218,27 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
                 G.v[k] = fmaf(gc, v, G.v[k]);
                 dr.v[k] = w.v[k] * gc * v * (1.0f - v);
             }
-            st4(a.d_raw + (int64_t)c * a.sc + s0, dr, active);
+            st4o(a.d_raw + (int64_t)c * a.sc, ob, dr, active);
         }
         const int CK = a.C + a.K;
-        for (int c0 = 0; c0 < CK; c0 += CB) {
-            f4 rb[CB];
-            float gcb[CB];
+        // The logit rows, BWD_PB rows per batch, software-pipelined: the next batch's loads are issued BEFORE this batch's
+        // stores.  vmcnt is one in-order counter for loads and stores on this part, so a load issued behind a store is not seen
+        // as landed until the store is acknowledged -- with the loads in front, the wait the compiler emits is a counted one
+        // that leaves the stores in flight.  (One ray group per wave and 16 waves per CU at 4096 rays: the kernel is a chain of
+        // memory round trips, not a bandwidth problem.)
+        auto fetch_rows = [&](int c0, f4 (&rb)[BWD_PB], float (&gcb)[BWD_PB]) {
 #pragma unroll
-            for (int j = 0; j < CB; ++j) {
+            for (int j = 0; j < BWD_PB; ++j) {
                 const int c = c0 + j < CK ? c0 + j : CK - 1;
                 const bool is_s = c < a.C;
                 const float* gp = is_s ? a.g_sem : a.g_inst;
                 gcb[j] = gp ? gp[rayc * (is_s ? a.C : a.K) + (is_s ? c : c - a.C)] : 0.0f;
-                rb[j] = ld4(a.raw + (int64_t)(4 + c) * a.sc + s0, active);
+                rb[j] = ld4o(a.raw + (int64_t)(4 + c) * a.sc, ob, active);
             }
+        };
+        auto do_rows = [&](int c0, const f4 (&rb)[BWD_PB], const float (&gcb)[BWD_PB]) {
 #pragma unroll
-            for (int j = 0; j < CB; ++j) {
+            for (int j = 0; j < BWD_PB; ++j) {
                 const int c = c0 + j;
                 if (c >= CK) break;
                 const bool is_s = c < a.C;
@@ -191,7 +248,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
                 f4 dr;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (a.sem_mode && gp) {
+                    if (SM && gp) {
                         const float sc = expf(r.v[k] - (is_s ? mx_s.v[k] : mx_i.v[k])) / (is_s ? den_s.v[k] : den_i.v[k]);
                         dr.v[k] = w.v[k] * sc * (gc - (is_s ? dot_s.v[k] : dot_i.v[k]));
                     } else {
@@ -210,11 +267,24 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
                         dr.v[k] += ce * (pc - (lab == cc ? 1.0f : 0.0f));
                     }
                 }
-                st4(a.d_raw + (int64_t)(4 + c) * a.sc + s0, dr, active);
+                st4o(a.d_raw + (int64_t)(4 + c) * a.sc, ob, dr, active);
+                BWD_ROW_FENCE;
+            }
+        };
+        {
+            f4 rbA[BWD_PB], rbB[BWD_PB];
+            float gA[BWD_PB], gB[BWD_PB];
+            if (CK > 0) fetch_rows(0, rbA, gA);
+            for (int c0 = 0; c0 < CK; c0 += 2 * BWD_PB) {
+                if (c0 + BWD_PB < CK) fetch_rows(c0 + BWD_PB, rbB, gB);
+                do_rows(c0, rbA, gA);
+                if (c0 + BWD_PB >= CK) break;
+                if (c0 + 2 * BWD_PB < CK) fetch_rows(c0 + 2 * BWD_PB, rbA, gA);
+                do_rows(c0 + BWD_PB, rbB, gB);
             }
         }
 
-        if (a.sem_mode) {
+        if (SM) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) G.v[k] += dot_s.v[k] + dot_i.v[k];
         }
@@ -243,7 +313,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdArgs a)
             const float dalpha = G.v[k] * T.v[k] - S.v[k] / (om + 1e-10f);
             ds.v[k] = (sg.v[k] > 0.0f) ? dist.v[k] * om * dalpha : 0.0f;
         }
-        st4(a.d_raw + 3 * a.sc + s0, ds, active);
+        st4o(a.d_raw + 3 * a.sc, ob, ds, active);
     }
 }
 
@@ -322,13 +392,13 @@ static int composite_backward_impl(const float* raw, int64_t raw_stride_c, const
     const int grid = pnr_grid_cap((n_groups + 3) / 4, 8);
     hipStream_t st = (hipStream_t)stream;
     switch (sub) {
-    case 1: hipLaunchKernelGGL(k_composite_bwd<1>, dim3(grid), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_composite_bwd<2>, dim3(grid), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_composite_bwd<4>, dim3(grid), dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_composite_bwd<8>, dim3(grid), dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(k_composite_bwd<16>, dim3(grid), dim3(256), 0, st, a); break;
-    case 32: hipLaunchKernelGGL(k_composite_bwd<32>, dim3(grid), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_composite_bwd<64>, dim3(grid), dim3(256), 0, st, a); break;
+    case 1: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<1, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<1, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case 2: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<2, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<2, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case 4: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<4, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<4, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case 8: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<8, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<8, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case 16: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<16, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<16, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case 32: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<32, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<32, false>), dim3(grid), dim3(256), 0, st, a); break;
+    default: if (a.sem_mode) hipLaunchKernelGGL((k_composite_bwd<64, true>), dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL((k_composite_bwd<64, false>), dim3(grid), dim3(256), 0, st, a); break;
     }
     PNR_CHECK_LAUNCH("pnr_composite_backward");
     return PNR_OK;

@@ -209,9 +209,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_ce3d(Ce3dArgs a)
             float mx = -INFINITY, den = 0.0f, at = 0.0f;
             for (int c = 0; c < a.n_cls; ++c) {          // online log-sum-exp: one pass over the channel rows
                 const float v = p[(int64_t)c * a.sc];
-                const float m2 = fmaxf(mx, v);
-                den = den * expf(mx - m2) + expf(v - m2);
-                mx = m2;
+                const float d = v - mx, e = expf(-fabsf(d));      // one expf per value: the other factor of the online form is expf(0)
+                den = d <= 0.0f ? den + e : den * e + 1.0f;
+                mx = fmaxf(mx, v);
                 if (c == lab) at = v;
             }
             ce = (mx + logf(den)) - at;
