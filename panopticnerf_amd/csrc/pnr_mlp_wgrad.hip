@@ -377,8 +377,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgRedArgs a)
     const int ldp = it.nb + WG_BIAS_COLS;
     const float* p = a.partial + it.p_off + (int64_t)srow * ldp + scol;
     const int64_t stride = (int64_t)it.ma * ldp;
+    // the slabs' partial sums in slab order; eight loads requested before the first is added (same order, same bits: with one load
+    // in flight per thread the kernel waited out ~100 dependent round trips)
     float s = 0.0f;
-    for (int k = 0; k < a.n_slabs; ++k) s += p[k * stride];
+    int k = 0;
+    for (; k + 8 <= a.n_slabs; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(k + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < a.n_slabs; ++k) s += p[k * stride];
     if (bias) it.out_b[o] = s;
     else it.out[(int64_t)o * it.ld + it.col_off + i] = s;
 }
