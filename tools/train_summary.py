@@ -11,7 +11,7 @@ rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), max(e
 tot = sum(r[2] for r in rows)
 print("== training step (tools/train_trace.py: 4096 rays x (64+192) samples, 8x256 + 45/32 heads, NetworkWrapper losses, Adam), rocprofv3, MI355X")
 print(f"total kernel time per step: {tot / nt / 1e6:.3f} ms   (the first step of the trace includes first-launch effects)")
-for r in rows[:16]:
+for r in rows[:32]:
     print(f"{r[0][:70]:70s} calls/step {r[1] / nt:5.1f}  ms/step {r[2] / nt / 1e6:7.3f}  avg_us {r[3] / 1e3:8.1f} max_us {r[4] / 1e3:8.1f}")
 if fetch is None:
     sys.exit(0)
