@@ -78,7 +78,11 @@ __device__ __forceinline__ void store_slots(uint16_t* base, int width, int s, in
     u32x4 a, b;
     a[0] = r8[0]; a[1] = r8[1]; a[2] = r8[2]; a[3] = r8[3];
     b[0] = r8[4]; b[1] = r8[5]; b[2] = r8[6]; b[3] = r8[7];
-#if PNR_ABL_STORE == 1          /* ablation: no activation / gradient stores (results invalid) */
+#if PNR_ABL_STORE == 4 || PNR_ABL_STORE == 5   /* ablation (results invalid): 4 = waves 0-3 (the piece issuers of the training forward) do not
+                                                  store, 5 = waves 4-7 do not: is it the ISSUERS' stores that the piece waits hang on? */
+    if (((int)(threadIdx.x >> 6) < 4) == (PNR_ABL_STORE == 4)) { asm volatile("" :: "v"(a), "v"(b), "v"(p)); return; }
+    p[0] = a; p[8] = b;
+#elif PNR_ABL_STORE == 1          /* ablation: no activation / gradient stores (results invalid) */
     asm volatile("" :: "v"(a), "v"(b), "v"(p));
 #elif PNR_ABL_STORE == 2        /* nontemporal: 1.8 -> 3.0 ms (sc0 / sc1 / sc0 sc1 scopes: +-0 / +-0 / +8 %) */
     __builtin_nontemporal_store(a, p); __builtin_nontemporal_store(b, p + 8);
