@@ -126,6 +126,9 @@ class GradReducer:
         reducer = GradReducer(net)           # once; world 1: a no-op
         loss.backward(); reducer.finish(); optimizer.step()
 
+    Several backward() calls before one finish() (gradient accumulation) are reduced correctly but without overlap: a bucket
+    that left after the first backward is dropped and everything is reduced in finish().
+
     Every rank launches the same buckets in the same order: a bucket whose parameters all received a gradient goes out from
     the hook that completes it (fine, then coarse); anything left -- a module with an unused parameter, parameters outside the
     NeRFs -- goes out in finish(), in module order.  For trainers that wrap the network in DistributedDataParallel none of this is needed (DDP's reducer
@@ -157,7 +160,9 @@ class GradReducer:
     def _hook(self, b):
         def fn(_p):
             b["hits"] += 1
-            if b["hits"] == len(b["params"]) and self._in_order(b):
+            if b["sent"]:
+                b["stale"] = True          # a second backward() before finish() (gradient accumulation): what went out is not the sum
+            elif b["hits"] == len(b["params"]) and self._in_order(b):
                 self._send(b)
         return fn
 
@@ -182,6 +187,14 @@ class GradReducer:
         """After backward(): launch what no hook launched, wait for every collective, write the means back."""
         if self.world == 1:
             return
+        if any(b.get("stale") for b in self.buckets):
+            # gradients kept accumulating after a bucket had left: drop what is in flight and reduce everything now, in bucket
+            # order (every rank takes this branch together: the hooks fire the same way everywhere)
+            for work, _flat, _ps in self.works:
+                work.wait()
+            self.works = []
+            for b in self.buckets:
+                b["sent"], b["stale"] = False, False
         for b in self.buckets:
             if not b["sent"]:
                 self._send(b)
@@ -195,7 +208,7 @@ class GradReducer:
                 o += n
         self.works = []
         for b in self.buckets:
-            b["hits"], b["sent"] = 0, False
+            b["hits"], b["sent"], b["stale"] = 0, False, False
 
     def remove(self):
         for h in self.handles:

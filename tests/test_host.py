@@ -176,6 +176,21 @@ def _reducer_worker(rank, world, port, q):
                     uses = 2 if share else 1
                     want = 1.5 * (i + 1) * (lv + 1) * uses     # mean over ranks 1, 2 of (rank + 1) * ...
                     ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+        # gradient accumulation: two backward() calls before one finish() -- the early bucket is stale and everything is reduced again
+        for p in net.parameters():
+            p.grad = None
+        for _rep in range(2):
+            loss = 0.0
+            for lv in ((1, 0) if not share else (0, 0)):
+                for i, p in enumerate(net.nerf(lv).parameters()):
+                    if p is not net.nerf_0.rgb_linear.bias:
+                        loss = loss + (p * float((rank + 1) * (i + 1) * (lv + 1))).sum()
+            loss.backward()
+        red.finish()
+        for lv in ((1, 0) if not share else (0,)):
+            for i, p in enumerate(net.nerf(lv).parameters()):
+                if p is not net.nerf_0.rgb_linear.bias:
+                    ok = ok and torch.allclose(p.grad, torch.full_like(p, 2 * 1.5 * (i + 1) * (lv + 1) * (2 if share else 1)))
         # the fine bucket (complete: every parameter used) went out DURING backward; the coarse one (an unused parameter) in finish()
         ok = ok and (sent_in_backward == ([[False]] * 2 if share else [[True, False]] * 2))
         red.remove()
