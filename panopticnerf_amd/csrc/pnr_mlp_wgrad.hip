@@ -398,6 +398,8 @@ static int wg_slab(int64_t S)
 {
     // samples per slab: enough slabs to fill the GPU a few times over, few enough to keep the partials small
     // (measured at 786 K samples: 2048 / 4096 / 8192 / 16384 / 32768 samples per slab -> 3.28 / 2.97 / 2.79 / 2.96 / 3.18 ms)
+    // (round 4, slab sizes chosen for whole rounds of the 256 CUs: 7680 / 8192 / 8768 / 9216 / 10240 -> 1.90 / 1.84 / 1.81 / 1.81 / 1.82 ms at
+    //  786 K samples and 0.69 / 0.63 / 0.64 / 0.68 / 0.70 ms at 262 K: a wash over the two levels, 8192 stays)
     int slab = WG_SLAB;
     while (slab > 1024 && S / slab < 24) slab >>= 1;
     return slab;
