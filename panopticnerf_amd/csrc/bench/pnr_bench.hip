@@ -24,6 +24,14 @@ static void set_error(const char* fmt, ...)
     va_end(ap);
 }
 PNRB_EXPORT const char* pnrb_last_error(void) { return g_err; }
+// for the other translation units of the library (bench/pnr_proto_two_tile.hip)
+void pnrb_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
 #define PNR_EXPORT PNRB_EXPORT
 #define PNR_REQUIRE(cond, ...) do { if (!(cond)) { set_error(__VA_ARGS__); return PNR_EINVAL; } } while (0)
 #define PNR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e__)); return PNR_EHIP; } } while (0)

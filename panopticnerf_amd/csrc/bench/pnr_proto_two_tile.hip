@@ -1,0 +1,379 @@
+// TIMING-ONLY prototype (libpnr_bench.so; results are not a network's outputs): the steady hidden-layer loop of the fused MLP in
+// the one structural form the 8-wave ping-pong kernel (pnr_mlp_pp.h) cannot take -- ONE wave per SIMD with 512 registers and
+// TWO 32-sample tiles per wave, so that every 1 KiB weight fragment read from the LDS feeds two MFMAs (tile A, tile B) instead
+// of one.  Round-4 verdict, item 1: "halve the LDS fragment reads per FLOP; hand-place tile A's pack / ReLU and the refill
+// pieces in tile B's MFMA gaps (<= 5 fillers per gap, MI355X_MICROARCH.md: one wave per SIMD)".
+//
+// What it keeps of the real kernel (k_mlp_pp<256, .., FUSE, plan 1>), so that cycles per MFMA and the clock are comparable:
+//   * v_mfma_f32_32x32x16_bf16, transposed evaluation (weights = A operand from the LDS, activations = B operand in registers),
+//     256-wide layers: a layer = 4 chunks of 2 output blocks x 16 k-steps; per chunk and wave 64 MFMAs on 4 accumulator chains
+//     (2 blocks x 2 tiles, round-robin: no two consecutive MFMAs share an accumulator);
+//   * the weight stream: a 33-fragment chunk (32 weight fragments + 1 bias fragment) per 2 output blocks, L2 -> LDS by the same
+//     scalar-base LDS-DMA pieces (pnr_dma_piece, `nt`), every 256 samples stream the whole image once (40 chunks = 1.35 MB here,
+//     1.41 MB in the real network);
+//   * fragments through a ring of 4 register quads with counted lgkmcnt waits (inline asm pinned by sched_barrier), bias quads
+//     read straight into the accumulators, pack (v_cvt_pk_bf16_f32) + ReLU (v_pk_max_i16) of every output register;
+//   * pseudo-random weights and activations (He-scaled), because the clock the chip grants depends on the operands' toggle rate.
+// What it leaves out (all of it would cost the real kernel extra): the encoders, the skip layer's extra k-steps, layer 0, the
+// narrow views / head layers, the fused compositing epilogue, input loads and record stores, ragged groups.
+//
+// Time structure.  4 LDS slots; during chunk c every wave issues its 8-9 pieces of chunk c+3 one per 7 MFMA gaps; at the end of
+// chunk c it waits for its own pieces of chunk c+2 (`vmcnt(8)`: issued a whole chunk ago) and the workgroup meets at ONE
+// s_barrier -- so everything of chunk c+2 is visible during chunk c+1, whose tail requests chunk c+2's bias quads and first
+// fragments: the fragment ring never drains at a chunk boundary.  The pack / ReLU of chunk c-1's four accumulators runs in the
+// first 43 gaps of chunk c (three output registers per four gaps), chunk c+1's 16 bias quads are read into the vacated
+// accumulators in gaps 44..59.  Two layers per loop trip (in -> out, out -> in): no hand-over copies.
+//
+// FLAGS (ablations): 1 = LDS-DMA pieces, 2 = fragment reads, 4 = pack / ReLU epilogue.  7 = the prototype.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "pnr_common.h"
+#include "pnr_bench.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 p2_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 p2_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float p2_f32x2;
+typedef __attribute__((ext_vector_type(2))) short p2_i16x2;
+typedef __attribute__((ext_vector_type(16))) float p2_f32x16;
+typedef __attribute__((ext_vector_type(4))) float p2_f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t p2_u32x4;
+typedef __attribute__((address_space(3))) void p2_lds_void;
+
+template <int... I, class F>
+__device__ __forceinline__ void p2_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void p2_for(F&& f) { p2_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+namespace p2 {
+constexpr int P = 4;                      // fragment ring (quads)
+constexpr int NFRAG = 32;                 // weight fragments per chunk: 2 blocks x 16 k-steps
+constexpr int CHUNK_FRAGS = NFRAG + 1;    // + the bias fragment
+constexpr int SLOT = CHUNK_FRAGS * 1024;
+constexpr int NSLOT = 4;
+constexpr int NCHUNK = 40;                // 10 layers x 4 chunks per 256-sample group (the real plan: 1336 MFMAs per tile = 41.75 such chunks)
+constexpr int BIAS0 = 44, BIAS1 = 60;     // gaps that carry one bias-quad read each
+constexpr int TOPWAIT = (64 - BIAS1) / 2; // fragment reads (odd gaps) younger than the last bias read when a chunk ends
+constexpr int EPI_GAPS = 43;              // the previous chunk's 32 output registers are packed in gaps 0 .. 42 (3 per 4 gaps)
+constexpr int epi_reg(int g) { return (g & 3) == 3 ? -1 : (g >> 2) * 3 + (g & 3); }
+constexpr int frag_off(int f) { return ((f & 1) * 16 + (f >> 1)) * 1024; }        // fragment f = ks * 2 + b  ->  block-major image
+// LGKM operations issued after the read of fragment f (gap 2 f - 5 of this chunk, counted from the previous chunk's end for
+// f < 3) and before the wait in front of MFMA 2 f: the reads of f + 1, f + 2 and the bias reads of the gaps in between
+constexpr int younger(int f)
+{
+    int n = 2;
+    for (int g = 2 * f - 5; g <= 2 * f - 1; ++g) n += (g >= BIAS0 && g < BIAS1) ? 1 : 0;
+    return n;
+}
+}   // namespace p2
+
+struct P2Args {
+    const uint8_t* image;       // NCHUNK x 33 KiB: 32 bf16 weight fragments + one fp32 bias fragment per chunk
+    int n_groups;
+    float* sink;
+    unsigned long long* clk;    // {shader cycles, 100 MHz ticks} of workgroup 0's first wave
+};
+
+template <int OFF>
+__device__ __forceinline__ void p2_read(p2_u32x4& dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// bias quads: into ACCUMULATOR registers ("a": hipcc keeps the MFMA accumulators of a 512-register kernel in AGPRs; a quad that
+// lands in VGPRs costs 4 v_accvgpr_write in front of the chunk's first MFMAs)
+template <int OFF>
+__device__ __forceinline__ void p2_read(p2_f32x4& dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void p2_wait(p2_u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+
+__device__ __forceinline__ uint32_t p2_pack_relu(float lo, float hi)
+{
+    const p2_f32x2 f = {lo, hi};
+    const uint32_t v = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, p2_bf16x2));
+    const p2_i16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(p2_i16x2, v), z));
+}
+
+struct P2State {
+    const uint8_t* image;
+    char* smem;
+    uint32_t lds_frag, lds_bias;     // smem + lane * 16, smem + hi * 16
+    int lane, wave;
+    int cg;                          // chunk of the group whose MFMAs come next (0 .. NCHUNK-1); its slot is cg & 3
+};
+
+// One chunk.  CB: chunk of the layer (= its LDS slot).  cur: accumulators of this chunk (bias already in them), prv: the previous
+// chunk's results, packed into dst[t][PB*8 ..] (PB, PB+1 = its two output blocks) in the first 32 gaps, then re-armed with the
+// NEXT chunk's bias quads.
+template <int FLAGS, int CB, int PB>
+__device__ __forceinline__ void p2_chunk(P2State& s, p2_u32x4 (&A)[p2::P], const uint32_t (&in)[2][64], uint32_t (&dst)[2][64],
+                                         p2_f32x16 (&cur)[2][2], p2_f32x16 (&prv)[2][2], p2_f32x4 (&bq)[16])
+{
+    using namespace p2;
+    constexpr bool DMA = FLAGS & 1, READS = FLAGS & 2, EPI = FLAGS & 4;
+    constexpr int SL = CB, SLN = (CB + 1) % NSLOT;
+    const uint32_t fa = s.lds_frag + SL * SLOT, fan = s.lds_frag + SLN * SLOT, ban = s.lds_bias + SLN * SLOT;
+    // refill: this wave's fragments wave, wave + 4, ... of chunk cg + 3 into the slot chunk cg - 1 left (everybody passed the
+    // barrier that ended it)
+    int c3 = s.cg + 3;
+    c3 = c3 >= NCHUNK ? c3 - NCHUNK : c3;
+    const uint8_t* rsrc = s.image + (size_t)c3 * SLOT;
+    char* rdst = s.smem + ((CB + 3) % NSLOT) * SLOT;
+    // the bias quads requested in the previous chunk's tail -> accumulators (the wait covers them: TOPWAIT fragment reads are younger)
+    if constexpr (READS) {       // (written out: clang does not capture a variable a generic lambda names only in asm operands)
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(TOPWAIT) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // accumulator <- its four bias quads, as ONE concatenation of register values (element-wise copies are re-vectorised into a
+    // 64-byte load of the quad array, which then stays in scratch memory)
+    p2_for<4>([&](auto J) {
+        constexpr int j = J, b = j >> 1, t = j & 1;
+        typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+        const f32x8_t lo = __builtin_shufflevector(bq[4 * j], bq[4 * j + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const f32x8_t hi8 = __builtin_shufflevector(bq[4 * j + 2], bq[4 * j + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+        cur[b][t] = __builtin_shufflevector(lo, hi8, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    p2_for<64>([&](auto I) {
+        constexpr int i = I;
+        constexpr int ks = i >> 2, b = (i >> 1) & 1, t = i & 1, f = ks * 2 + b;
+        if constexpr (t == 0 && READS) p2_wait<younger(f)>(A[f % P]);
+        {
+            p2_u32x4 bv;
+            bv[0] = in[t][4 * ks]; bv[1] = in[t][4 * ks + 1]; bv[2] = in[t][4 * ks + 2]; bv[3] = in[t][4 * ks + 3];
+            cur[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(p2_bf16x8, A[f % P]), __builtin_bit_cast(p2_bf16x8, bv),
+                                                                cur[b][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- fillers of gap i
+        if constexpr (t == 1 && READS) {                 // fragment f + 3 into the quad fragment f - 1 used; past 31: the next chunk's
+            constexpr int fn = f + P - 1;
+            if constexpr (fn < NFRAG) p2_read<frag_off(fn)>(A[fn % P], fa);
+            else p2_read<frag_off(fn - NFRAG)>(A[fn % P], fan);
+        }
+        if constexpr (i >= BIAS0 && i < BIAS1 && READS) {  // next chunk's bias quads: block b', tile t', quad m
+            constexpr int j = i - BIAS0, bb = j >> 3, m = j & 3;
+            p2_read<NFRAG * 1024 + bb * 128 + m * 32>(bq[j], ban);
+        }
+        if constexpr (i < EPI_GAPS && epi_reg(i) >= 0 && epi_reg(i) < 32 && EPI) {      // an output register of the previous chunk
+            constexpr int q = epi_reg(i), bb = q >> 4, tt = (q >> 3) & 1, p = q & 7;
+            uint32_t v = p2_pack_relu(prv[bb][tt][2 * p], prv[bb][tt][2 * p + 1]);
+            asm volatile("" : "+v"(v));
+            dst[tt][(PB + bb) * 8 + p] = v;
+        }
+        if constexpr (i % 7 == 2 && DMA) {               // pieces j = 0 .. 8: fragments wave + 4 j < 33
+            constexpr int j = i / 7;
+            const int fr = s.wave + 4 * j;
+            if (j < 8 || fr < CHUNK_FRAGS) pnr_dma_piece<2>(rsrc + (size_t)fr * 1024, rdst + fr * 1024, s.lane * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // chunk hand-over: own pieces of chunk cg + 2 (issued during the previous chunk) have landed -- the 8 youngest operations are
+    // this chunk's pieces of cg + 3 -- and every wave is done reading this chunk's slot
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    s.cg = s.cg + 1 == NCHUNK ? 0 : s.cg + 1;
+}
+
+// One 256-wide layer: 4 chunks; accumulator sets alternate X, Y, X, Y.  The results of the previous layer's last chunk (in Y)
+// are packed into `in` blocks 6, 7 during chunk 0 (its k-steps 12..15 = MFMAs 48..63 are the first to read them).
+template <int FLAGS>
+__device__ __forceinline__ void p2_layer(P2State& s, p2_u32x4 (&A)[p2::P], uint32_t (&in)[2][64], uint32_t (&out)[2][64],
+                                         p2_f32x16 (&X)[2][2], p2_f32x16 (&Y)[2][2], p2_f32x4 (&bq)[16])
+{
+    p2_chunk<FLAGS, 0, 6>(s, A, in, in, X, Y, bq);
+    p2_chunk<FLAGS, 1, 0>(s, A, in, out, Y, X, bq);
+    p2_chunk<FLAGS, 2, 2>(s, A, in, out, X, Y, bq);
+    p2_chunk<FLAGS, 3, 4>(s, A, in, out, Y, X, bq);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void k_proto_two_tile(const P2Args a)
+{
+    using namespace p2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), hi = lane >> 5;
+    P2State s{a.image, smem, (uint32_t)(uintptr_t)(p2_lds_void*)smem + lane * 16, (uint32_t)(uintptr_t)(p2_lds_void*)smem + hi * 16, lane, wave, 0};
+    // chunks 0, 1, 2 into slots 0, 1, 2
+    for (int c = 0; c < 3; ++c)
+        for (int f = wave; f < CHUNK_FRAGS; f += 4) pnr_dma_piece<2>(a.image + (size_t)c * SLOT + (size_t)f * 1024, smem + c * SLOT + f * 1024, lane * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long c0 = 0, r0 = 0;
+    if (a.clk) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    p2_u32x4 A[P];
+    p2_f32x4 bq[16];
+    p2_f32x16 X[2][2], Y[2][2];
+    uint32_t cur[2][64], nxt[2][64];
+    // the ring's first three fragments and chunk 0's bias quads
+    p2_for<P - 1>([&](auto I) { constexpr int i = I; p2_read<frag_off(i)>(A[i], s.lds_frag); });
+    A[P - 1] = p2_u32x4{0, 0, 0, 0};
+    p2_for<16>([&](auto J) {
+        constexpr int j = J;
+        bq[j] = *reinterpret_cast<const p2_f32x4*>(smem + NFRAG * 1024 + (j >> 3) * 128 + (j & 3) * 32 + hi * 16);
+    });
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { X[b][t][r] = 0.0f; Y[b][t][r] = 0.25f * (float)((lane + r) & 3); }
+    // the ring's three fragments must be the youngest LGKM operations when chunk 0 starts: drain, then read them again
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    p2_for<P - 1>([&](auto I) { constexpr int i = I; p2_read<frag_off(i)>(A[i], s.lds_frag); });
+    uint32_t h = (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    float total = 0.0f;
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        // this group's "inputs": post-ReLU-like bf16 pairs in [0.5, 1)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                h = h * 1664525u + 1013904223u;
+                cur[t][i] = ((h >> 8) & 0x007f007fu) | 0x3f003f00u;
+                if (!(FLAGS & 4)) nxt[t][i] = ((h >> 9) & 0x007f007fu) | 0x3f003f00u;
+            }
+#pragma unroll 1
+        for (int l = 0; l < NCHUNK / 8; ++l) {
+            p2_layer<FLAGS>(s, A, cur, nxt, X, Y, bq);
+            p2_layer<FLAGS>(s, A, nxt, cur, X, Y, bq);
+        }
+        // "outputs" of the group
+#pragma unroll
+        for (int i = 0; i < 64; i += 8) total += __uint_as_float(cur[0][i] << 16) + __uint_as_float(cur[1][i] & 0xffff0000u);
+        total += Y[0][0][0] + Y[1][1][5];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        a.clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    if (total == 12345.678f) a.sink[threadIdx.x] = total;
+}
+
+#define P2_EXPORT extern "C" __attribute__((visibility("default")))
+void pnrb_set_error(const char* fmt, ...);
+
+template <int FLAGS>
+static hipError_t p2_launch(const P2Args& a, int grid, hipStream_t st)
+{
+    auto kern = k_proto_two_tile<FLAGS>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p2::NSLOT * p2::SLOT, st, a);
+    return hipGetLastError();
+}
+
+// image: pnrb_proto_two_tile_image_bytes() device bytes (random bf16 weight fragments, fp32 bias fragments); n_samples: rounded
+// up to whole 256-sample groups.  flags: 7 = the prototype; ablations see the header.  Outputs (host): mean ms per launch, mean
+// shader MHz of the last launch, MFMAs per wave per launch / cycles of workgroup 0's first wave = cycles per MFMA.
+P2_EXPORT int64_t pnrb_proto_two_tile_image_bytes(void) { return (int64_t)p2::NCHUNK * p2::SLOT; }
+P2_EXPORT int pnrb_proto_two_tile(const void* image, int64_t n_samples, int flags, int iters, void* scratch, float* ms_out_host,
+                                  float* mhz_out_host, float* cyc_per_mfma_out_host, void* stream)
+{
+    if (!image || !scratch || !ms_out_host || !mhz_out_host || !cyc_per_mfma_out_host || iters < 1 || n_samples < 256) {
+        pnrb_set_error("pnrb_proto_two_tile: bad arguments");
+        return PNR_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    P2Args a;
+    a.image = (const uint8_t*)image;
+    a.n_groups = (int)((n_samples + 255) / 256);
+    a.clk = (unsigned long long*)scratch;
+    a.sink = (float*)((char*)scratch + 64);
+    const int grid = a.n_groups < cus ? a.n_groups : cus;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { pnrb_set_error("hipEventCreate failed"); return PNR_EHIP; }
+    hipError_t he = hipSuccess;
+    for (int rep = 0; rep < 2 && he == hipSuccess; ++rep) {          // rep 0: warm-up
+        he = hipEventRecord(e0, st);
+        for (int i = 0; i < (rep ? iters : 1) && he == hipSuccess; ++i) {
+            switch (flags) {
+            case 7: he = p2_launch<7>(a, grid, st); break;
+            case 6: he = p2_launch<6>(a, grid, st); break;
+            case 3: he = p2_launch<3>(a, grid, st); break;
+            case 2: he = p2_launch<2>(a, grid, st); break;
+            case 0: he = p2_launch<0>(a, grid, st); break;
+            default: pnrb_set_error("pnrb_proto_two_tile: flags %d not built (7, 6, 3, 2, 0)", flags); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PNR_EINVAL;
+            }
+        }
+        if (he == hipSuccess) he = hipEventRecord(e1, st);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+    }
+    float ms = 0.0f;
+    unsigned long long hclk[2] = {0, 1};
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (he == hipSuccess) he = hipMemcpy(hclk, scratch, sizeof(hclk), hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (he != hipSuccess) { pnrb_set_error("pnrb_proto_two_tile: %s", hipGetErrorString(he)); return PNR_EHIP; }
+    *ms_out_host = ms / (float)iters;
+    *mhz_out_host = hclk[1] ? (float)(100.0 * (double)hclk[0] / (double)hclk[1]) : 0.0f;
+    const int groups_wg0 = (a.n_groups + grid - 1) / grid;
+    *cyc_per_mfma_out_host = (float)((double)hclk[0] / ((double)groups_wg0 * p2::NCHUNK * 64.0));
+    return PNR_OK;
+}
+
+// The HAND-PLACED form of the same loop: gfx950 assembly generated by tools/probe/gen_two_tile_asm.py (every register and issue
+// slot chosen by hand; see its header), assembled into `co_path` by `make` (panopticnerf_amd/pnr_two_tile_proto.co).  Same image.
+P2_EXPORT int pnrb_proto_two_tile_asm(const char* co_path, const void* image, int64_t n_samples, int flags, int iters, void* scratch,
+                                      float* ms_out_host, float* mhz_out_host, float* cyc_per_mfma_out_host, void* stream)
+{
+    if (!co_path || !image || !scratch || !ms_out_host || !mhz_out_host || !cyc_per_mfma_out_host || iters < 1 || n_samples < 256) {
+        pnrb_set_error("pnrb_proto_two_tile_asm: bad arguments");
+        return PNR_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    char name[64];
+    snprintf(name, sizeof(name), "k_two_tile_asm_f%d", flags);
+    hipError_t he = hipModuleLoad(&mod, co_path);
+    if (he != hipSuccess) { pnrb_set_error("pnrb_proto_two_tile_asm: hipModuleLoad(%s): %s", co_path, hipGetErrorString(he)); return PNR_EHIP; }
+    he = hipModuleGetFunction(&fn, mod, name);
+    if (he != hipSuccess) { pnrb_set_error("pnrb_proto_two_tile_asm: no kernel %s: %s", name, hipGetErrorString(he)); (void)hipModuleUnload(mod); return PNR_EHIP; }
+    struct { const void* image; int n_groups, n_wg; void* sink; void* clk; } ka;
+    ka.image = image;
+    ka.n_groups = (int)((n_samples + 255) / 256);
+    ka.n_wg = ka.n_groups < cus ? ka.n_groups : cus;
+    ka.clk = scratch;
+    ka.sink = (char*)scratch + 64;
+    size_t ka_size = sizeof(ka);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size, HIP_LAUNCH_PARAM_END};
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { pnrb_set_error("hipEventCreate failed"); (void)hipModuleUnload(mod); return PNR_EHIP; }
+    for (int rep = 0; rep < 2 && he == hipSuccess; ++rep) {          // rep 0: warm-up
+        he = hipEventRecord(e0, st);
+        for (int i = 0; i < (rep ? iters : 1) && he == hipSuccess; ++i)
+            he = hipModuleLaunchKernel(fn, (unsigned)ka.n_wg, 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+        if (he == hipSuccess) he = hipEventRecord(e1, st);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+    }
+    float ms = 0.0f;
+    unsigned long long hclk[2] = {0, 1};
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (he == hipSuccess) he = hipMemcpy(hclk, scratch, sizeof(hclk), hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipModuleUnload(mod);
+    if (he != hipSuccess) { pnrb_set_error("pnrb_proto_two_tile_asm: %s", hipGetErrorString(he)); return PNR_EHIP; }
+    *ms_out_host = ms / (float)iters;
+    *mhz_out_host = hclk[1] ? (float)(100.0 * (double)hclk[0] / (double)hclk[1]) : 0.0f;
+    const int groups_wg0 = (ka.n_groups + ka.n_wg - 1) / ka.n_wg;
+    *cyc_per_mfma_out_host = (float)((double)hclk[0] / ((double)groups_wg0 * p2::NCHUNK * 64.0));
+    return PNR_OK;
+}
