@@ -371,6 +371,7 @@ P2_EXPORT int pnrb_proto_two_tile_asm(const char* co_path, const void* image, in
     (void)hipEventDestroy(e1);
     (void)hipModuleUnload(mod);
     if (he != hipSuccess) { pnrb_set_error("pnrb_proto_two_tile_asm: %s", hipGetErrorString(he)); return PNR_EHIP; }
+    if (flags > 100) fprintf(stderr, "pnrb_proto_two_tile_asm debug: image %p  scratch words %016llx %016llx\n", image, hclk[0], hclk[1]);
     *ms_out_host = ms / (float)iters;
     *mhz_out_host = hclk[1] ? (float)(100.0 * (double)hclk[0] / (double)hclk[1]) : 0.0f;
     const int groups_wg0 = (ka.n_groups + ka.n_wg - 1) / ka.n_wg;

@@ -373,6 +373,8 @@ static int composite_backward_impl(const float* raw, int64_t raw_stride_c, const
     PNR_REQUIRE(n_samples >= 4 && n_samples <= 256 && (n_samples % 4) == 0,
                 "pnr_composite_backward: n_samples=%d must be a multiple of 4 in [4,256]", n_samples);
     if (n_rays <= 0) return PNR_OK;
+    PNR_REQUIRE(n_rays * (int64_t)n_samples < ((int64_t)1 << 30), "pnr_composite_backward: R*N=%lld must stay below 2^30 (32-bit byte "
+                "offsets inside a channel row): split the batch", (long long)(n_rays * (int64_t)n_samples));
     PNR_REQUIRE(raw && z && rays && d_raw, "pnr_composite_backward: null pointer");
     PNR_REQUIRE((raw_stride_c % 4) == 0 && (((uintptr_t)raw | (uintptr_t)d_raw | (uintptr_t)z | (uintptr_t)noise |
                                             (uintptr_t)g_weights | (uintptr_t)label_sem | (uintptr_t)label_inst) & 15) == 0,

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_f32_gemm(const Gemm g)
     __shared__ float As[BK][BM + 4];
     __shared__ float Bs[BK][BN + 4];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;      // M (= R*N samples in the forward / data-gradient launches) on grid.x: its limit is 2^31 - 1, grid.y's 65535
     int k_lo = 0, k_hi = g.K;
     float* C = g.C;
     if (g.kslab > 0) {
@@ -192,7 +192,7 @@ Layout make_layout(const pnr_mlp_desc& d, int64_t S)
 int launch(Gemm g, hipStream_t st, const char* what)
 {
     if (g.M <= 0 || g.N <= 0) return PNR_OK;
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.kslab > 0 ? (g.K + g.kslab - 1) / g.kslab : 1);
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, g.kslab > 0 ? (g.K + g.kslab - 1) / g.kslab : 1);
     hipLaunchKernelGGL(k_f32_gemm, grid, dim3(256), 0, st, g);
     PNR_CHECK_LAUNCH(what);
     return PNR_OK;

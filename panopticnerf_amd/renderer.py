@@ -31,19 +31,25 @@ CHUNK_QUANTUM = 1024     # rays: at 64 and at 192 samples per ray a multiple of 
                          # MLP kernels' persistent grid (256 workgroups x 256 samples)
 
 
+CHUNK_TAIL = 8           # a tail of at most chunk_size / CHUNK_TAIL rays joins the other chunks instead of becoming a chunk
+
+
 def chunk_plan(n_rays, chunk_size):
     """[(start, end)] of the ray chunks of one render() call: BALANCED chunks instead of `chunk_size` pieces plus a tail.
-    cfg.chunk_size bounds the working set, it is not a hard limit: a tail smaller than half a chunk joins the other chunks
-    (n = round(R / chunk_size)), and every chunk but the last is rounded up to CHUNK_QUANTUM rays so that its MLP launches
-    are whole rounds of the persistent grid.  A rank's 66,176-ray share of a 1408 x 376 frame over 8 ranks is then ONE chunk
-    (not 65,536 + a 640-ray chunk with its own ~14 launches), the full frame 7 x 66,560 + 63,488 rays (every launch whole
-    rounds) instead of 8 x 65,536 + 5,120."""
+    cfg.chunk_size bounds the working set (raw, acts, weights and the frame maps scale with it): n = ceil(R / chunk_size)
+    chunks, except that a tail of at most chunk_size / 8 rays joins the others -- so a chunk never holds more than
+    chunk_size * (1 + 1/8) rays plus one rounding quantum -- and every chunk but the last is rounded up to CHUNK_QUANTUM rays
+    so that its MLP launches are whole rounds of the persistent grid.  A rank's 66,176-ray share of a 1408 x 376 frame over 8
+    ranks is then ONE chunk (not 65,536 + a 640-ray chunk with its own ~14 launches), the full frame 7 x 66,560 + 63,488
+    rays (every launch whole rounds) instead of 8 x 65,536 + 5,120."""
     n_rays, chunk_size = int(n_rays), max(1, int(chunk_size))
     if n_rays <= 0:
         return []
-    n = max(1, int(n_rays / chunk_size + 0.5))
+    n = -(-n_rays // chunk_size)
+    if n > 1 and n_rays - (n - 1) * chunk_size <= chunk_size // CHUNK_TAIL:
+        n -= 1
     size = -(-n_rays // n)
-    if n > 1 and chunk_size >= CHUNK_QUANTUM:
+    if n > 1 and chunk_size >= CHUNK_QUANTUM * CHUNK_TAIL:
         size = -(-size // CHUNK_QUANTUM) * CHUNK_QUANTUM
     out, s = [], 0
     while s < n_rays:

@@ -132,13 +132,20 @@ class GradReducer:
     Every rank launches the same buckets in the same order: a bucket whose parameters all received a gradient goes out from
     the hook that completes it (fine, then coarse); anything left -- a module with an unused parameter, parameters outside the
     NeRFs -- goes out in finish(), in module order.  For trainers that wrap the network in DistributedDataParallel none of this is needed (DDP's reducer
-    does the same job, tests/test_integration.py); allreduce_grads() is the one-bucket form without hooks."""
+    does the same job, tests/test_integration.py); allreduce_grads() is the one-bucket form without hooks.
 
-    def __init__(self, net, world=None, group=None):
+    With GraphedStep (`reduce=reducer.finish`): the hooks also fire while the step is being CAPTURED into a HIP graph, and a
+    collective inside the captured region would tie the graph to one communicator state and be replayed beside the eager one --
+    so a hook that runs under stream capture only counts (`_capturing`), nothing is launched, and `finish()` -- which GraphedStep
+    calls eagerly between its two graphs, where no hook has run -- sends every bucket.  Replayed steps therefore get the
+    two-bucket form without the overlap.  `always=True` keeps the hooks and collectives at world size 1 (tests)."""
+
+    def __init__(self, net, world=None, group=None, always=False):
         self.group = group
         self.world = world or (dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1)
         self.buckets, self.works, self.handles = [], [], []
-        if self.world == 1:
+        self.active = self.world > 1 or bool(always)
+        if not self.active:
             return
         seen = set()
         levels = [1, 0] if getattr(net, "N_importance", 0) > 0 else [0]
@@ -157,13 +164,18 @@ class GradReducer:
             for p in b["params"]:
                 self.handles.append(p.register_post_accumulate_grad_hook(self._hook(b)))
 
+    @staticmethod
+    def _capturing():
+        """True while the current stream is being captured into a HIP graph (GraphedStep's capture of forward + backward)."""
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
     def _hook(self, b):
         def fn(_p):
             b["hits"] += 1
             if b["sent"]:
                 b["stale"] = True          # a second backward() before finish() (gradient accumulation): what went out is not the sum
-            elif b["hits"] == len(b["params"]) and self._in_order(b):
-                self._send(b)
+            elif b["hits"] == len(b["params"]) and self._in_order(b) and not self._capturing():
+                self._send(b)              # (under capture: nothing may be launched from here -- finish() sends, eagerly)
         return fn
 
     def _in_order(self, b):
@@ -185,8 +197,11 @@ class GradReducer:
 
     def finish(self):
         """After backward(): launch what no hook launched, wait for every collective, write the means back."""
-        if self.world == 1:
+        if not self.active:
             return
+        if self._capturing():
+            raise RuntimeError("GradReducer.finish() inside a HIP-graph capture: pass it to GraphedStep as `reduce` (it then runs "
+                               "eagerly between the two graphs), do not call it in the captured region")
         if any(b.get("stale") for b in self.buckets):
             # gradients kept accumulating after a bucket had left: drop what is in flight and reduce everything now, in bucket
             # order (every rank takes this branch together: the hooks fire the same way everywhere)
@@ -232,8 +247,9 @@ class GraphedStep:
     constructor warms up with two real steps on a side stream (first-call allocations, optimiser state) and then restores the
     parameters and the optimiser state IN PLACE (the captured addresses must survive), so constructing a GraphedStep trains
     nothing.  `reduce`: None on one GPU; with several ranks a callable (e.g. `lambda: allreduce_grads(net)` or a
-    GradReducer's finish) that runs EAGERLY between two graphs -- forward + backward | collective | optimiser -- since a
-    collective inside a captured region ties the graph to one communicator state.  After training through replays call
+    GradReducer's finish: its hooks launch nothing while a stream is being captured, so every bucket leaves from finish()) that
+    runs EAGERLY between two graphs -- forward + backward | collective | optimiser -- since a collective inside a captured
+    region ties the graph to one communicator state.  After training through replays call
     `net.eval()` (or `net.invalidate_packed()`) before rendering: tensor versions do not see what a replay did to the weights."""
 
     def __init__(self, wrapper, optimizer, example_batch, reduce=None, warmup=2):

@@ -64,8 +64,9 @@ def reorder(sc, order_seed):
     return [torch.randint(0, sc.pool.shape[0], (sc.batch,), generator=g) for _ in range(sc.steps)]
 
 
-def oracle_student(sc, mode="fp32", W=UNIT, w3d=0.1, lr=5e-4, batches=None, init_jitter=0.0, log=None):
-    """Train one CPU student; returns dict(losses, rgb (fine-level colour term per step), psnr, eval maps, params)."""
+def oracle_student(sc, mode="fp32", W=UNIT, w3d=0.1, lr=5e-4, batches=None, init_jitter=0.0, log=None, snap=()):
+    """Train one CPU student; returns dict(losses, rgb (fine-level colour term per step), psnr, eval maps, params, snaps =
+    {k: parameters after k Adam steps, for k in `snap`})."""
     emu = {"fp32": False, "bf16_fwd": True, "bf16_bwd": "bwd", "bf16_hilo": "bwd_hilo"}[mode]
     batches = sc.batches if batches is None else batches
     prm = {lv: {k: v.clone() for k, v in sc.init[lv].items()} for lv in ("coarse", "fine")}
@@ -78,7 +79,7 @@ def oracle_student(sc, mode="fp32", W=UNIT, w3d=0.1, lr=5e-4, batches=None, init
         for v in d.values():
             v.requires_grad_(True)
     opt = torch.optim.Adam([p for d in prm.values() for p in d.values()], lr=lr)
-    losses, rgb = [], []
+    losses, rgb, snaps = [], [], {}
     for it, idx in enumerate(batches):
         out = to.render_rays(prm, sc.oc, sc.pool[idx], sc.Nc, sc.Nf, box=sc.box, box_ids=sc.ids, keep_raw=True, emulate_bf16=emu)
         hits = to.bbox_hits(sc.pool[idx], sc.box, 8)
@@ -97,17 +98,21 @@ def oracle_student(sc, mode="fp32", W=UNIT, w3d=0.1, lr=5e-4, batches=None, init
         loss.backward()
         opt.step()
         losses.append(loss.item())
+        if it + 1 in snap:
+            snaps[it + 1] = {f"{lv}.{k}": v.detach().clone() for lv, d in prm.items() for k, v in d.items()}
         if log and (it % 25 == 0 or it == len(batches) - 1):
             log(f"[{mode}] step {it}: loss {losses[-1]:.4f} rgb {rgb[-1]:.5f}")
     sd = {lv: {k: v.detach() for k, v in d.items()} for lv, d in prm.items()}
     with torch.no_grad():
         ev = to.render_rays(sd, sc.oc, sc.held, sc.Nc, sc.Nf, box=sc.box, box_ids=sc.ids)
-    return {"mode": mode, "losses": losses, "rgb": rgb, "psnr": psnr(ev["rgb_1"], sc.t_held["rgb_1"]), "eval": ev, "params": sd}
+    return {"mode": mode, "losses": losses, "rgb": rgb, "psnr": psnr(ev["rgb_1"], sc.t_held["rgb_1"]), "eval": ev, "params": sd,
+            "snaps": snaps}
 
 
-def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=None):
+def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=None, snap=(), evaluate=True, graphed=False):
     """The HIP student through the trainer's wrapper (NetworkWrapper), same init / batches / terms.  precision "bf16": the
-    training path; "fp32": its parity mode (pnr_mlp_forward_train_fp32 / pnr_mlp_backward_fp32)."""
+    training path; "fp32": its parity mode (pnr_mlp_forward_train_fp32 / pnr_mlp_backward_fp32).  snap: step counts after which
+    the parameters are copied out (`snaps`); graphed: the steps run through train.GraphedStep (one HIP graph per step)."""
     from panopticnerf_amd import NetworkWrapper, make_network, make_renderer
     batches = sc.batches if batches is None else batches
     cfg = NS(N_samples=sc.Nc, N_importance=sc.Nf, num_classes=sc.Cc, num_instances=sc.Kk, precision=precision, chunk_size=4096,
@@ -118,26 +123,39 @@ def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=Non
     net.nerf_1.load_state_dict(sc.init["fine"])
     net = net.to(dev).train()
     wrap = NetworkWrapper(net, cfg)
-    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, **({"capturable": True, "fused": True} if graphed else {}))
     bx, bi = sc.box.to(dev), sc.ids.to(dev)
-    losses, rgb = [], []
-    for idx in batches:
-        b = {"rays": sc.pool[idx][None].to(dev), "bbox": bx, "bbox_ids": bi, "rgb": sc.tgt["rgb"][idx][None].to(dev),
-             "depth": sc.tgt["depth"][idx][None].to(dev), "pseudo_label": sc.tgt["semantic"][idx][None].to(dev),
-             "instance_label": sc.tgt["instance"][idx][None].to(dev)}
-        _, loss, st, _ = wrap(b)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+    losses, rgb, snaps, step = [], [], {}, None
+
+    def mk(idx):
+        return {"rays": sc.pool[idx][None].to(dev), "bbox": bx, "bbox_ids": bi, "rgb": sc.tgt["rgb"][idx][None].to(dev),
+                "depth": sc.tgt["depth"][idx][None].to(dev), "pseudo_label": sc.tgt["semantic"][idx][None].to(dev),
+                "instance_label": sc.tgt["instance"][idx][None].to(dev)}
+    if graphed:
+        from panopticnerf_amd import train as pnr_train
+        step = pnr_train.GraphedStep(wrap, opt, mk(batches[0]))
+    for it, idx in enumerate(batches):
+        if step is not None:
+            _, loss, st = step(mk(idx))
+        else:
+            _, loss, st, _ = wrap(mk(idx))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
         losses.append(loss.item())
         rgb.append(float(st["rgb_loss_1"]))
+        if it + 1 in snap:
+            snaps[it + 1] = {f"{lv}.{k}": v.detach().cpu().clone() for lv, n in (("coarse", net.nerf_0), ("fine", net.nerf_1))
+                             for k, v in n.state_dict().items()}
+    sd = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
+          "fine": {k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}}
+    if not evaluate:
+        return {"mode": "hip:" + precision, "losses": losses, "rgb": rgb, "params": sd, "snaps": snaps}
     with torch.no_grad():
         ev = make_renderer(cfg, net.eval()).render({"rays": sc.held[None].to(dev), "bbox": bx, "bbox_ids": bi})
     ev = {k: v[0].cpu() for k, v in ev.items()}
-    sd = {"coarse": {k: v.detach().cpu() for k, v in net.nerf_0.state_dict().items()},
-          "fine": {k: v.detach().cpu() for k, v in net.nerf_1.state_dict().items()}}
     return {"mode": "hip:" + precision, "losses": losses, "rgb": rgb, "psnr": psnr(ev["rgb_1"], sc.t_held["rgb_1"]),
-            "eval": ev, "params": sd}
+            "eval": ev, "params": sd, "snaps": snaps}
 
 
 def _loss_of(sc, out, hits, idx, W, w3d):

@@ -348,6 +348,68 @@ def test_graphed_step_replays_equal_eager_steps_on_changing_batches(dev, split):
         pnr_train.GraphedStep(wrap_g, torch.optim.Adam(net_g.parameters(), lr=1e-3), batches[0])
 
 
+def test_graphed_step_with_grad_reducer_finish_as_reduce(dev):
+    """`GraphedStep(..., reduce=GradReducer(net).finish)` -- the reducer's post-accumulate hooks fire during the warm-up
+    AND during the capture of forward + backward; under capture they must launch no collective (it would be baked into the graph
+    and replayed beside the eager one).  A one-rank nccl group with `always=True` keeps hooks and collectives alive: the capture
+    succeeds, no Work object survives it, every replay reduces both buckets eagerly in finish(), and three replays equal three
+    eager steps bit for bit (mean over one rank = identity)."""
+    from types import SimpleNamespace as NS
+    import copy
+    import socket
+    import torch.distributed as dist
+    from panopticnerf_amd import NetworkWrapper, make_network, synthetic, train as pnr_train
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        C, K = 6, 4
+        cfg = NS(N_samples=32, N_importance=32, num_classes=C, num_instances=K, precision="bf16", D=4, W=128, skips=[1])
+        torch.manual_seed(6)
+        net_e = make_network(cfg).to(dev).train()
+        net_g = copy.deepcopy(net_e)
+        R = 256
+        box, ids = synthetic.random_boxes(16, C, K, seed=2)
+        g = torch.Generator().manual_seed(2)
+
+        def batch(i):
+            rays = synthetic.camera_rays()[i::2003][:R].contiguous()
+            return {"rays": rays[None].to(dev), "bbox": box.to(dev), "bbox_ids": ids.to(dev),
+                    "rgb": torch.rand(1, R, 3, generator=g).to(dev), "depth": (torch.rand(1, R, generator=g) * 20 - 2).to(dev),
+                    "pseudo_label": torch.randint(-1, C, (1, R), generator=g).to(dev), "instance_label": torch.randint(-1, K, (1, R), generator=g).to(dev)}
+
+        batches = [batch(i) for i in range(4)]
+        wrap_e, wrap_g = NetworkWrapper(net_e, cfg), NetworkWrapper(net_g, cfg)
+        opt_e = torch.optim.Adam(net_e.parameters(), lr=1e-3, capturable=True, fused=True)
+        opt_g = torch.optim.Adam(net_g.parameters(), lr=1e-3, capturable=True, fused=True)
+        red = pnr_train.GradReducer(net_g, always=True)
+        assert red.active and len(red.buckets) == 2 and red.handles
+        sends = []
+        orig_send = red._send
+        red._send = lambda b: (sends.append(torch.cuda.is_current_stream_capturing()), orig_send(b))[1]
+        step = pnr_train.GraphedStep(wrap_g, opt_g, batches[3], reduce=red.finish)
+        assert not red.works and sends and not any(sends)          # nothing was launched inside the captured region
+        n0 = len(sends)
+        for b in batches[:3]:
+            step(b)
+        assert len(sends) == n0 + 3 * 2 and not any(sends)         # per replay: both buckets, from finish(), eagerly
+        for b in batches[:3]:
+            opt_e.zero_grad(set_to_none=False)
+            _, loss, _, _ = wrap_e(b)
+            loss.backward()
+            opt_e.step()
+        for (n, a), b in zip(net_e.named_parameters(), net_g.parameters()):
+            assert torch.equal(a, b), n
+        red.remove()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("S_rays", [(37, 24), (16, 64)])      # 888 samples (ragged: S_pad = 1024) and 1024 (S = S_pad)
 def test_saved_tensors_layout_gates_and_padding(dev, S_rays):
     """The training buffers as include/pnr.h documents them: read back through the saved-tensor layout (tests/_wgrad_ref.

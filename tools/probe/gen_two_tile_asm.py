@@ -62,8 +62,8 @@ def ar(lo, n):
 
 
 class Gen:
-    def __init__(self, flags, name):
-        self.flags, self.name, self.o, self.nlabel = flags, name, [], 0
+    def __init__(self, flags, name, stop=0):
+        self.flags, self.name, self.o, self.nlabel, self.stop = flags, name, [], 0, stop       # stop: debug builds end after stage `stop`
 
     def e(self, s):
         self.o.append("\t" + s)
@@ -146,8 +146,12 @@ class Gen:
         e("s_load_dwordx2 s[%d:%d], s[0:1], 0x8" % (S_NGRP, S_NGRP + 1))
         e("s_load_dwordx2 s[%d:%d], s[0:1], 0x10" % (S_SINK, S_SINK + 1))
         e("s_load_dwordx2 s[%d:%d], s[0:1], 0x18" % (S_CLK, S_CLK + 1))
-        e("v_lshrrev_b32 v3, 6, v0")
-        e("v_readfirstlane_b32 s%d, v3" % S_WAVE)
+        # wave id from v0 itself: v0 is never written.  (Measured: `v_lshrrev v3, 6, v0; v_readfirstlane s12, v3` with v3 re-used ten
+        # instructions later returned the LATER value of v3 in two of four waves -- the read of a v_readfirstlane's source is not
+        # ordered against younger VALU writes of it while scalar-load data is returning.)
+        e("v_readfirstlane_b32 s%d, v0" % S_WAVE)
+        e("s_nop 4")
+        e("s_lshr_b32 s%d, s%d, 6" % (S_WAVE, S_WAVE))
         e("s_lshl_b32 s%d, s%d, 10" % (S_W1K, S_WAVE))
         e("v_and_b32 v1, 63, v0")
         e("v_lshlrev_b32 v%d, 4, v1" % V_LANE16)
@@ -161,6 +165,24 @@ class Gen:
         for k, c in enumerate((1664525, 1013904223, 0x007f007f, 0x3f003f00, 2654435761, 40503)):
             e("s_mov_b32 s%d, 0x%x" % (S_K + k, c))
         e("s_waitcnt lgkmcnt(0)")
+        lend = self.label()
+        if self.stop == 1:
+            e("s_branch %s" % lend)
+        if self.stop == 8:            # debug: dump s4, s5 (image), s12 (wave), s14 to the clock buffer
+            ldump = self.label()
+            e("s_cmp_lg_u32 s2, 0")
+            e("s_cbranch_scc1 %s" % ldump)
+            e("v_mov_b32 v20, s4")
+            e("v_mov_b32 v21, s5")
+            e("v_mov_b32 v22, s12")
+            e("v_mov_b32 v23, v0")
+            e("v_mov_b32 v13, 0")
+            e("v_cmp_eq_u32 vcc, 0, v1")
+            e("s_and_saveexec_b64 s[38:39], vcc")
+            e("global_store_dwordx4 v13, v[20:23], s[10:11]")
+            e("s_waitcnt vmcnt(0)")
+            self.o.append(ldump + ":")
+            e("s_endpgm")
         # chunks 0, 1, 2 -> slots 0, 1, 2
         for c in range(3):
             e("s_add_u32 s%d, s%d, 0x%x" % (S_SRC, S_IMG, c * SLOT))
@@ -168,10 +190,23 @@ class Gen:
             e("s_add_u32 s%d, s%d, s%d" % (S_SRCW, S_SRC, S_W1K))
             e("s_addc_u32 s%d, s%d, 0" % (S_SRCW + 1, S_SRC + 1))
             for j in range(9):
+                if self.stop == 7 and c == 0 and j == 0:       # debug: the same first piece as a plain register load (no LDS)
+                    e("s_add_u32 s%d, s%d, 0" % (S_PIECE, S_SRCW))
+                    e("s_addc_u32 s%d, s%d, 0" % (S_PIECE + 1, S_SRCW + 1))
+                    e("global_load_dwordx4 v[20:23], v%d, s[%d:%d]" % (V_LANE16, S_PIECE, S_PIECE + 1))
+                    break
                 self.piece(S_SRCW, S_SRCW + 1, c * SLOT, j, guard_wave0=(j == 8))
+                if self.stop == 5 and c == 0 and j == 0:
+                    break
+            if self.stop in (5, 6, 7) and c == 0:
+                break
         e("s_waitcnt vmcnt(0)")
         e("s_barrier")
+        if self.stop in (5, 6, 7):
+            e("s_branch %s" % lend)
         e("s_mov_b32 s%d, 3" % S_C3)
+        if self.stop == 2:
+            e("s_branch %s" % lend)
         # activations: post-ReLU-like bf16 pairs in [0.5, 1) from a per-lane LCG
         e("v_mul_lo_u32 v%d, v0, s%d" % (V_HASH, S_K + 4))
         e("s_mul_i32 s%d, s2, s%d" % (S_PIECE, S_K + 5))
@@ -189,6 +224,8 @@ class Gen:
         for r in range(64):                      # Y = 0 (its "previous results" are packed during the first chunk)
             e("v_mov_b32 v%d, 0" % (acc(1, 0, 0) + r))
         e("v_mov_b32 v%d, 0" % V_ZERO)
+        if self.stop == 3:
+            e("s_branch %s" % lend)
         e("s_memtime s[30:31]")
         e("s_memrealtime s[32:33]")
         e("s_waitcnt lgkmcnt(0)")
@@ -200,8 +237,10 @@ class Gen:
             e("ds_read_b128 %s, v%d offset:%d" % (vr(V_RING + 4 * f, 4), V_FRAG, frag_off(f)))
         if not (self.flags & 2):
             e("s_waitcnt lgkmcnt(0)")
+        if self.stop == 4:
+            e("s_branch %s" % lend)
         e("s_mov_b32 s%d, s2" % S_GRP)
-        lgrp, lend, llayer, lfin = self.label(), self.label(), self.label(), self.label()
+        lgrp, llayer, lfin = self.label(), self.label(), self.label()
         self.o.append(lgrp + ":")
         e("s_cmp_ge_i32 s%d, s%d" % (S_GRP, S_NGRP))
         e("s_cbranch_scc1 %s" % lend)
@@ -234,6 +273,7 @@ class Gen:
         e("s_subb_u32 s37, s37, s33")
         for k in range(4):
             e("v_mov_b32 v%d, s%d" % (20 + k, 34 + k))
+        e("v_mov_b32 v%d, 0" % V_ZERO)
         e("global_store_dwordx4 v%d, v[20:23], s[%d:%d]" % (V_ZERO, S_CLK, S_CLK + 1))
         e("s_waitcnt vmcnt(0)")
         self.o.append(lfin + ":")
@@ -272,6 +312,10 @@ def main():
         n = "k_two_tile_asm_f%d" % fl
         names.append(n)
         parts.append(Gen(fl, n).kernel())
+    for stop in (1, 2, 3, 4, 5, 6, 7, 8):          # debug: the full kernel cut short after stage `stop` (pnrb_proto_two_tile_asm flags 100 + stop)
+        n = "k_two_tile_asm_f%d" % (100 + stop)
+        names.append(n)
+        parts.append(Gen(7, n, stop).kernel())
     parts.append(metadata(names))
     with open(out, "w") as f:
         f.write("\n".join(parts))

@@ -25,7 +25,22 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-head", action="store_true")
+    ap.add_argument("--debug-asm", action="store_true", help="run the staged debug builds of the assembly kernel (flags 101..104)")
+    ap.add_argument("--one", default=None, help="(internal) run ONE prototype variant in this process: asm:7, hipcc:6, ...")
     a = ap.parse_args()
+    if a.one:
+        kind, fl = a.one.split(":")
+        image = benchlib.proto_two_tile_image(torch.device("cuda:0"))
+        benchlib.proto_two_tile(image, 65536 * 192, int(fl), 1, kind == "asm")
+        best = min((benchlib.proto_two_tile(image, 65536 * 192, int(fl), a.iters, kind == "asm") for _ in range(3)), key=lambda t: t[0])
+        print("RESULT " + json.dumps(best), flush=True)
+        return
+    if a.debug_asm:
+        import subprocess
+        for fl in (108, 107, 102, 104, 0, 7):
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", "asm:%d" % fl, "--iters", "1"], capture_output=True, text=True, timeout=120)
+            print("asm debug stage %d: rc %d %s" % (fl, p.returncode, (p.stdout + p.stderr)[-400:].replace("\n", " | ")), flush=True)
+        return
     dev = torch.device("cuda:0")
     R, N = 65536, 192
     S = R * N
@@ -47,22 +62,27 @@ def main():
         tf, pm = benchlib.probe_mfma_peak(True)
         rows.append({"variant": "register-only random-operand MFMA loop (8 waves per CU)", "tflops": tf, "mhz": pm,
                      "cycles_per_mfma_per_simd": 32.0 * (2.0 * 32 * 32 * 16 * 1024 * pm * 1e6 / 32.0) / (tf * 1e12)})
-    image = benchlib.proto_two_tile_image(dev)
+    for r in rows:
+        print("%-84s %s" % (r["variant"], "  ".join("%s=%.3f" % (k, v) for k, v in r.items() if isinstance(v, float))), flush=True)
     names = {7: "two-tile prototype (fragment reads + pack/ReLU + LDS-DMA pieces)", 6: "  without the LDS-DMA pieces",
              3: "  without the pack/ReLU epilogue", 2: "  fragment reads only", 0: "  bare MFMA stream (no reads, no epilogue, no pieces)"}
-    for asm in (True, False):
-        for fl in (7, 6, 3, 2, 0):
+    import subprocess
+    for kind in ("asm", "hipcc"):
+        for fl in (7, 6, 3, 2, 0):          # one process per variant: a faulting prototype must not take the others with it
+            row = {"variant": kind + " " + names[fl]}
             try:
-                benchlib.proto_two_tile(image, S, fl, 1, asm)
-                best = min((benchlib.proto_two_tile(image, S, fl, a.iters, asm) for _ in range(3)), key=lambda t: t[0])
-            except RuntimeError as e:
-                rows.append({"variant": ("asm " if asm else "hipcc ") + names[fl], "error": str(e)})
-                continue
-            ms, mhz, cyc = best
-            rows.append({"variant": ("asm " if asm else "hipcc ") + names[fl], "ms": ms, "mhz": mhz, "cycles_per_mfma_per_simd": cyc,
-                         "ms_at_real_work": ms * 1336.0 / 1280.0})
-    for r in rows:
-        print("%-84s %s" % (r["variant"], "  ".join("%s=%.3f" % (k, v) for k, v in r.items() if isinstance(v, float)) or r.get("error", "")), flush=True)
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", "%s:%d" % (kind, fl), "--iters", str(a.iters)],
+                                   capture_output=True, text=True, timeout=120)
+                res = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+                if res:
+                    ms, mhz, cyc = json.loads(res[-1][7:])
+                    row.update({"ms": ms, "mhz": mhz, "cycles_per_mfma_per_simd": cyc, "ms_at_real_work": ms * 1336.0 / 1280.0})
+                else:
+                    row["error"] = "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:].replace("\n", " | "))
+            except subprocess.TimeoutExpired:
+                row["error"] = "timeout (hang?)"
+            rows.append(row)
+            print("%-84s %s" % (row["variant"], "  ".join("%s=%.3f" % (k, v) for k, v in row.items() if isinstance(v, float)) or row.get("error", "")), flush=True)
     if a.json:
         with open(a.json, "w") as f:
             json.dump({"device": torch.cuda.get_device_name(0), "samples_per_launch": S, "rows": rows}, f, indent=1)
