@@ -79,7 +79,11 @@ typedef struct pnr_mlp_desc {
     int32_t schedule;  /* time structure of the bf16 weight stream (tests and A/B tools; the arithmetic, the packed image and the
                           results are identical bit for bit): 0 = default (ping-pong k_mlp_pp for inference launches, lock-step
                           k_mlp_fused for the training forward), 1 = lock-step everywhere, 2 = ping-pong everywhere */
-    int32_t reserved[3];
+    int32_t clk_probe[2]; /* diagnostics (libpnr_bench.so, tools/): low / high 32 bits of a DEVICE address of 16 bytes; when non-zero
+                             the forward MLP kernels launched with this descriptor write {shader cycles, 100 MHz ticks} of
+                             workgroup 0's first wave there (their ratio = the mean shader clock during the launch).  0 = off.
+                             A descriptor field, not a setter: the library keeps no mutable state (round 5) */
+    int32_t reserved[1];
 } pnr_mlp_desc;
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
@@ -336,11 +340,8 @@ int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float
                       const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream);
 
 /* ---- diagnostics.  Measurement helpers (hipEvent timing, MFMA / HBM ceilings of the device) live in libpnr_bench.so
- * (include/pnr_bench.h), not here: every export of this library is stream-ordered and never synchronises.
- * pnr_mlp_set_clock_probe: the fused MLP kernels launched by THIS thread afterwards write {shader cycles, 100 MHz ticks} of
- * workgroup 0's first wave to two_u64_dev (16 device bytes; their ratio = the mean shader clock during the launch); NULL
- * switches it off.  A thread-local setter: no device work, no synchronisation. */
-int pnr_mlp_set_clock_probe(void* two_u64_dev);
+ * (include/pnr_bench.h), not here: every export of this library is stream-ordered, never synchronises and keeps no mutable
+ * state -- the one diagnostic hook of the MLP kernels is a descriptor field (pnr_mlp_desc.clk_probe). */
 
 #ifdef __cplusplus
 }

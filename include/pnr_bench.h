@@ -15,8 +15,8 @@ extern "C" {
 #endif
 
 const char* pnrb_last_error(void);
-/* Addresses of pnr_mlp_forward, pnr_mlp_forward_tiles and pnr_mlp_set_clock_probe of the loaded libpnr.so. */
-int pnrb_bind(void* mlp_forward, void* mlp_forward_tiles, void* mlp_set_clock_probe);
+/* Addresses of pnr_mlp_forward and pnr_mlp_forward_tiles of the loaded libpnr.so. */
+int pnrb_bind(void* mlp_forward, void* mlp_forward_tiles);
 
 /* Mean milliseconds per launch of `iters` launches of pnr_mlp_forward (hipEvents recorded on `stream`, the stream the
  * launches go to) and the mean SHADER CLOCK during the last one (s_memtime / s_memrealtime of workgroup 0's first wave).

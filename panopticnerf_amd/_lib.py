@@ -27,7 +27,7 @@ class MlpDesc(ctypes.Structure):
                 ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
                 ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
                 ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("head_tap", ctypes.c_int32),
-                ("head_depth", ctypes.c_int32), ("schedule", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("head_depth", ctypes.c_int32), ("schedule", ctypes.c_int32), ("clk_probe", ctypes.c_int32 * 2), ("reserved", ctypes.c_int32 * 1)]
 
 
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -94,7 +94,6 @@ SIGNATURES = {
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_restrict_rays": (c_int, [c_f, c_i64, c_f, c_f, c_int, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
-    "pnr_mlp_set_clock_probe": (c_int, [c_f]),
     "pnr_mlp_forward_tiles": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f]),
     "pnr_composite_combine": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
                                       c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

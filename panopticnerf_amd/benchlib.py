@@ -14,7 +14,7 @@ c_f, c_i64, c_int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 _fp = ctypes.POINTER(ctypes.c_float)
 SIGNATURES = {
     "pnrb_last_error": (ctypes.c_char_p, []),
-    "pnrb_bind": (c_int, [c_f, c_f, c_f]),
+    "pnrb_bind": (c_int, [c_f, c_f]),
     "pnrb_time_mlp_forward": (c_int, [ctypes.POINTER(_lib.MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_time_mlp_forward_tiles": (c_int, [ctypes.POINTER(_lib.MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_mfma_peak": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
@@ -40,7 +40,7 @@ def load():
         fn.restype, fn.argtypes = res, args
     prod = _lib.load()
     addr = lambda f: ctypes.cast(f, ctypes.c_void_p)
-    rc = lib.pnrb_bind(addr(prod.pnr_mlp_forward), addr(prod.pnr_mlp_forward_tiles), addr(prod.pnr_mlp_set_clock_probe))
+    rc = lib.pnrb_bind(addr(prod.pnr_mlp_forward), addr(prod.pnr_mlp_forward_tiles))
     if rc != 0:
         raise RuntimeError("pnrb_bind failed: " + lib.pnrb_last_error().decode())
     _blib = lib

@@ -52,22 +52,27 @@ static inline int pnr_grid_cap(int64_t wanted, int per_cu = 8)
 // ---- the product entry points under test (addresses from the caller)
 typedef int (*fn_mlp_forward)(const pnr_mlp_desc*, const void*, const float*, const float*, int64_t, int, float*, int64_t, int64_t, void*);
 typedef int (*fn_mlp_forward_tiles)(const pnr_mlp_desc*, const void*, const float*, const float*, int64_t, int, void*, void*);
-typedef int (*fn_set_clock_probe)(void*);
 static fn_mlp_forward g_fwd = nullptr;
 static fn_mlp_forward_tiles g_tiles = nullptr;
-static fn_set_clock_probe g_clk = nullptr;
 
-PNRB_EXPORT int pnrb_bind(void* mlp_forward, void* mlp_forward_tiles, void* mlp_set_clock_probe)
+PNRB_EXPORT int pnrb_bind(void* mlp_forward, void* mlp_forward_tiles)
 {
-    PNR_REQUIRE(mlp_forward && mlp_forward_tiles && mlp_set_clock_probe, "pnrb_bind: null entry point");
+    PNR_REQUIRE(mlp_forward && mlp_forward_tiles, "pnrb_bind: null entry point");
     g_fwd = (fn_mlp_forward)mlp_forward;
     g_tiles = (fn_mlp_forward_tiles)mlp_forward_tiles;
-    g_clk = (fn_set_clock_probe)mlp_set_clock_probe;
     return PNR_OK;
+}
+// the caller's descriptor with the clock probe armed (pnr_mlp_desc.clk_probe: {shader cycles, 100 MHz ticks} -> scratch)
+static pnr_mlp_desc with_probe(const pnr_mlp_desc* desc, void* scratch)
+{
+    pnr_mlp_desc d = *desc;
+    d.clk_probe[0] = (int32_t)(uint32_t)((uintptr_t)scratch & 0xffffffffu);
+    d.clk_probe[1] = (int32_t)(uint32_t)((uint64_t)(uintptr_t)scratch >> 32);
+    return d;
 }
 
 // iters launches of `launch` between two events on `st`; the clock probe (s_memtime / s_memrealtime of workgroup 0's first wave,
-// written by the kernel to `scratch`: >= 16 device bytes) is armed for the whole series, read after the last launch
+// written by the kernel to `scratch`, >= 16 device bytes: armed by the caller through with_probe) is read after the last launch
 template <class F>
 static int time_launches(F&& launch, int iters, void* scratch, float* ms_out, float* mhz_out, hipStream_t st)
 {
@@ -77,10 +82,8 @@ static int time_launches(F&& launch, int iters, void* scratch, float* ms_out, fl
     PNR_HIP(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return PNR_EHIP; }
     int rc = PNR_OK;
-    g_clk(scratch);
     hipError_t he = hipEventRecord(e0, st);
     for (int i = 0; i < iters && rc == PNR_OK && he == hipSuccess; ++i) rc = launch();
-    g_clk(nullptr);
     float ms = 0.0f;
     unsigned long long h[2] = {0, 1};
     if (rc == PNR_OK && he == hipSuccess) he = hipEventRecord(e1, st);
@@ -100,7 +103,9 @@ PNRB_EXPORT int pnrb_time_mlp_forward(const pnr_mlp_desc* desc, const void* pack
                                       int n_samples, float* raw, int64_t raw_stride_s, int64_t raw_stride_c, int iters, void* scratch,
                                       float* ms_out_host, float* mhz_out_host, void* stream)
 {
-    return time_launches([&]() { return g_fwd(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, stream); },
+    PNR_REQUIRE(desc && scratch, "pnrb_time_mlp_forward: null desc / scratch");
+    const pnr_mlp_desc d = with_probe(desc, scratch);
+    return time_launches([&]() { return g_fwd(&d, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, stream); },
                          iters, scratch, ms_out_host, mhz_out_host, (hipStream_t)stream);
 }
 
@@ -108,7 +113,9 @@ PNRB_EXPORT int pnrb_time_mlp_forward_tiles(const pnr_mlp_desc* desc, const void
                                             int64_t n_rays, int n_samples, void* workspace, int iters, void* scratch,
                                             float* ms_out_host, float* mhz_out_host, void* stream)
 {
-    return time_launches([&]() { return g_tiles(desc, packed, rays, z, n_rays, n_samples, workspace, stream); },
+    PNR_REQUIRE(desc && scratch, "pnrb_time_mlp_forward_tiles: null desc / scratch");
+    const pnr_mlp_desc d = with_probe(desc, scratch);
+    return time_launches([&]() { return g_tiles(&d, packed, rays, z, n_rays, n_samples, workspace, stream); },
                          iters, scratch, ms_out_host, mhz_out_host, (hipStream_t)stream);
 }
 

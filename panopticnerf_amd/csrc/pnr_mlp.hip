@@ -858,14 +858,12 @@ static int launch_mlp(const MlpArgs& a0, hipStream_t stream)
 // pnr_mlp_desc::schedule (tests and A/B tools): 0 = ping-pong for inference / lock-step for the training forward, 1 = lock-step
 // everywhere, 2 = ping-pong everywhere.  A descriptor field: the library keeps no mutable process-global (include/pnr.h).
 
-// diagnostics: where the MLP kernels of this thread's next launches leave {shader cycles, 100 MHz ticks} of workgroup 0's first
-// wave (their ratio = the mean shader clock during the launch); null = off.  A setter, no synchronisation: libpnr_bench.so arms it
-// around the launches it times.
-static thread_local unsigned long long* g_clk_buf = nullptr;
-PNR_EXPORT int pnr_mlp_set_clock_probe(void* two_u64_dev)
+// diagnostics: pnr_mlp_desc.clk_probe = where the kernels of THIS launch leave {shader cycles, 100 MHz ticks} of workgroup 0's first
+// wave (their ratio = the mean shader clock during the launch); 0 = off.  A descriptor field: libpnr_bench.so sets it on its own copy
+// of the descriptor around the launches it times -- the library keeps no mutable state.
+static inline unsigned long long* clk_probe_of(const pnr_mlp_desc* d)
 {
-    g_clk_buf = (unsigned long long*)two_u64_dev;
-    return PNR_OK;
+    return (unsigned long long*)(uintptr_t)(((uint64_t)(uint32_t)d->clk_probe[1] << 32) | (uint64_t)(uint32_t)d->clk_probe[0]);
 }
 
 static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,
@@ -900,7 +898,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
-    a.clk = g_clk_buf;
+    a.clk = clk_probe_of(desc);
     if (acts) pnr_train_layout(*desc, a.S, a.acts_off, a.dys_off, a.gate_off);
     hipStream_t st = (hipStream_t)stream;
     // bf16: 8 waves x 1 tile, registers capped at 256 (2 waves per SIMD, one workgroup per CU);
@@ -969,7 +967,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     a.rec = (float*)workspace;
     const int64_t tiles = ((int64_t)a.S + 255) / 256 * 8;
     a.ps = (float4*)(a.rec + tiles * a.rec_floats);           // rec_floats % 4 == 0: 16-byte aligned
-    a.clk = g_clk_buf;
+    a.clk = clk_probe_of(desc);
 #if PNR_TRACE
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif

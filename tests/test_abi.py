@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.MlpDesc) == 64          # 9 ints + reserved[7]
+    assert ctypes.sizeof(_lib.MlpDesc) == 64          # 13 named ints + clk_probe[2] + reserved[1]
     assert ctypes.sizeof(_lib.MlpParamsHost) == 18 * ctypes.sizeof(ctypes.c_void_p)
     # pnr_loss_cfg: the binding's fields are, in order and type, the header's (a silent mismatch would scramble the weights)
     import re

@@ -8,12 +8,15 @@ from types import SimpleNamespace as NS
 dev = torch.device("cuda:0")
 clk = torch.zeros(2, dtype=torch.int64, device=dev)
 from panopticnerf_amd import _lib, make_network, ops, synthetic
-_lib.load().pnr_mlp_set_clock_probe(clk.data_ptr())      # the forward kernels of this thread stamp their clock here
 net = make_network(NS(N_samples=64, N_importance=128, num_classes=45, num_instances=32, precision="bf16")).to(dev).train()
 R, N = 4096, 192
 rays = synthetic.camera_rays()[::129][:R].contiguous().to(dev)
 z = ops.stratified(rays, N)
 desc, img = net.packed(1, dev)
+desc = _lib.MlpDesc.from_buffer_copy(bytes(desc))           # pnr_mlp_desc.clk_probe: the forward kernels launched with THIS copy
+desc.clk_probe[0] = clk.data_ptr() & 0xffffffff            # of the descriptor stamp their clock here (int32 fields: wrap)
+desc.clk_probe[1] = clk.data_ptr() >> 32
+
 _, img_b = net.packed_bwd(1, dev)
 def run(tag, fn, n=8):
     for _ in range(3): fn()
