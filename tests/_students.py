@@ -109,10 +109,11 @@ def oracle_student(sc, mode="fp32", W=UNIT, w3d=0.1, lr=5e-4, batches=None, init
             "snaps": snaps}
 
 
-def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=None, snap=(), evaluate=True, graphed=False):
+def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=None, snap=(), evaluate=True, graphed=False, fused_adam=False):
     """The HIP student through the trainer's wrapper (NetworkWrapper), same init / batches / terms.  precision "bf16": the
     training path; "fp32": its parity mode (pnr_mlp_forward_train_fp32 / pnr_mlp_backward_fp32).  snap: step counts after which
-    the parameters are copied out (`snaps`); graphed: the steps run through train.GraphedStep (one HIP graph per step)."""
+    the parameters are copied out (`snaps`); graphed: the steps run through train.GraphedStep (one HIP graph per step; implies
+    fused_adam); fused_adam: torch's fused capturable Adam (one kernel; its arithmetic differs from the default Adam's in the last bits)."""
     from panopticnerf_amd import NetworkWrapper, make_network, make_renderer
     batches = sc.batches if batches is None else batches
     cfg = NS(N_samples=sc.Nc, N_importance=sc.Nf, num_classes=sc.Cc, num_instances=sc.Kk, precision=precision, chunk_size=4096,
@@ -123,7 +124,7 @@ def hip_student(sc, dev, W=UNIT, w3d=0.1, lr=5e-4, precision="bf16", batches=Non
     net.nerf_1.load_state_dict(sc.init["fine"])
     net = net.to(dev).train()
     wrap = NetworkWrapper(net, cfg)
-    opt = torch.optim.Adam(net.parameters(), lr=lr, **({"capturable": True, "fused": True} if graphed else {}))
+    opt = torch.optim.Adam(net.parameters(), lr=lr, **({"capturable": True, "fused": True} if (graphed or fused_adam) else {}))
     bx, bi = sc.box.to(dev), sc.ids.to(dev)
     losses, rgb, snaps, step = [], [], {}, None
 

@@ -219,7 +219,7 @@ def test_training_trajectory_at_the_benched_geometry(dev):
     tests/golden/trajectory_cpu.npz made by tests/golden/make_trajectory.py on the CPU) of
         the HIP bf16 student        vs  "bf16_bwd" (the training kernels' arithmetic restated on the CPU)
         the HIP fp32-mode student   vs  "fp32"     (torch autograd through the oracle)
-        the HIP bf16 student run through train.GraphedStep  ==  the eager HIP bf16 student, bit for bit.
+        the HIP bf16 student run through train.GraphedStep  ==  the eager HIP bf16 student (same fused Adam), bit for bit.
     Bounds: relative to what two CPU students of the SAME arithmetic differ by when the initialisation is jittered by 1e-6
     ("fp32" vs "fp32_jitter", "bf16_bwd" vs "bf16_bwd_jitter" at the same k) -- the trajectory's own sensitivity -- times a
     margin, with a floor; and always far below the distance a WRONG step produces: Adam's step counter off by one changes every
@@ -242,10 +242,11 @@ def test_training_trajectory_at_the_benched_geometry(dev):
 
     h = S.hip_student(sc, dev, W, w3d, snap=KS, evaluate=False)
     h32 = S.hip_student(sc, dev, W, w3d, precision="fp32", snap=KS, evaluate=False)
+    hf = S.hip_student(sc, dev, W, w3d, snap=KS, evaluate=False, fused_adam=True)      # eager, the optimiser GraphedStep needs
     hg = S.hip_student(sc, dev, W, w3d, snap=KS, evaluate=False, graphed=True)
     for k in KS:
         for pn in names:
-            assert torch.equal(h["snaps"][k][pn], hg["snaps"][k][pn]), ("GraphedStep != eager", k, pn)
+            assert torch.equal(hf["snaps"][k][pn], hg["snaps"][k][pn]), ("GraphedStep != eager", k, pn)
     for k in KS:
         _, jit32_w, jit32 = _traj_distance(g, "fp32", "fp32_jitter", k, names)
         _, jit16_w, jit16 = _traj_distance(g, "bf16_bwd", "bf16_bwd_jitter", k, names)
