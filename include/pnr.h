@@ -71,8 +71,8 @@ typedef struct pnr_mlp_desc {
     int32_t xyz_L, dir_L;
     int32_t n_sem, n_inst, head_W;
     int32_t precision; /* PNR_PREC_* */
-    int32_t plan;      /* chunk order of the packed image: 0 = classic (every kernel); 1 = fused-inference order, see
-                          pnr_mlp_fused_plan (only pnr_mlp_forward_composite accepts it) */
+    int32_t plan;      /* chunk order of the packed image: 0 = classic (every kernel); 1 = fused-inference order, 2 = two-tile order,
+                          see pnr_mlp_fused_plan (only pnr_mlp_forward_composite accepts them) */
     int32_t head_tap;  /* what the semantic / instance heads read: 0 = the trunk output h (default), 1 = the feature_linear
                           output (the reference's tap point cannot be checked here, so it is a switch) */
     int32_t head_depth;/* 0 or 2 = W -> head_W -> n (ReLU between; default), 1 = one Linear W -> n */
@@ -139,11 +139,15 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  * multiple of 32 in [32, 256], n_sem + n_inst <= 128.  Results equal the two-kernel path to fp32 rounding (the sums are
  * associated per tile).  Outputs as pnr_composite's (any may be null; fix_* need their labels); weights (R,N) optional.
  * workspace: pnr_mlp_forward_composite_workspace_bytes(desc, n_rays, n_samples, weights != null) device bytes. */
-/* Chunk order for images that only pnr_mlp_forward_composite will consume.  Returns 1 when `desc`'s geometry has the
- * fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then BOTH
- * head hidden layers, then the two logit layers as ONE chunk -- three 8-MFMA chunks whose memory phase nothing covered become
- * one 24-MFMA chunk.  Set desc.plan to the returned value before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it for the
- * forward call; 0 = the classic order, which every entry point accepts.  Same arithmetic per layer: results are bit-identical. */
+/* Chunk order for images that only pnr_mlp_forward_composite will consume: the BEST plan `desc`'s geometry has.
+ *   1: the fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then
+ *      BOTH head hidden layers, then the two logit layers as ONE chunk (k_mlp_pp: 8 waves, one 32-sample tile per wave);
+ *   2: the two-tile plan (the benched geometry: D = 8, skip = 4, L = 10 / 4, both heads, head_tap 0): no chunk above 33
+ *      fragments, consumed by k_mlp_tt -- hand-placed gfx950 assembly, one wave per SIMD, two tiles per wave, every LDS weight
+ *      fragment feeds two MFMAs (csrc/asm/gen_mlp_tt.py);
+ *   0: the classic order, which every entry point accepts.
+ * Set desc.plan to the returned value (or to any smaller supported one) before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it
+ * for the forward call.  Same arithmetic per layer under every plan: records and maps are bit-identical. */
 int pnr_mlp_fused_plan(const pnr_mlp_desc* desc);
 int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights);
 int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

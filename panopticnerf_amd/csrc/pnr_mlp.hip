@@ -40,6 +40,7 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 #define PNR_FUSE_TRANSPOSED 1      /* fused epilogue: logit blocks computed transposed (operands swapped), see PPChunk::mma<SWAP> */
 #endif
 #include "pnr_mlp_fuse.h"
+#include "pnr_mlp_tt.h"
 #ifndef PNR_OPT_EAGER_EPI
 #define PNR_OPT_EAGER_EPI 1
 #endif
@@ -972,6 +973,13 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     hipStream_t st = (hipStream_t)stream;
+    if (desc->plan == 2) {      // the two-tile assembly kernel (csrc/asm/gen_mlp_tt.py): same records, bit for bit
+        PnrTTArgs t;
+        memset(&t, 0, sizeof(t));
+        t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
+        t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
+        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st);
+    }
     if (desc->plan == 1) {
         const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;
         switch (4 * nbs + nbi) {

@@ -29,7 +29,7 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
     PNR_REQUIRE(d->head_tap == 0 || d->head_tap == 1, "pnr_mlp: head_tap=%d must be 0 (trunk output) or 1 (feature)", d->head_tap);
     PNR_REQUIRE(d->head_depth >= 0 && d->head_depth <= 2, "pnr_mlp: head_depth=%d must be 1 or 2", d->head_depth);
     PNR_REQUIRE(d->schedule >= 0 && d->schedule <= 2, "pnr_mlp: schedule=%d must be 0 (default), 1 (lock-step) or 2 (ping-pong)", d->schedule);
-    PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)),
+    PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)) || (d->plan == 2 && pnr_plan2_supported(*d)),
                 "pnr_mlp: plan=%d is not available for this geometry (ask pnr_mlp_fused_plan)", d->plan);
     return PNR_OK;
 }
@@ -40,7 +40,7 @@ PNR_EXPORT int pnr_mlp_fused_plan(const pnr_mlp_desc* desc)
     pnr_mlp_desc d = *desc;
     d.plan = 0;
     if (pnr_mlp_validate(&d) != PNR_OK) return 0;
-    return pnr_plan1_supported(d) ? 1 : 0;
+    return pnr_plan2_supported(d) ? 2 : pnr_plan1_supported(d) ? 1 : 0;
 }
 
 static int bwd_validate(const pnr_mlp_desc* d)

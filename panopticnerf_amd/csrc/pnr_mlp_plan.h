@@ -4,6 +4,11 @@
 //   plan 0 (classic):          trunk 0..D-1 | feature | views | rgb+sigma | [sem0, sem1] | [inst0, inst1]
 //   plan 1 (fused inference):  trunk 0..D-1 | feature | views | rgb+sigma | [sem0] | [inst0] | logits = {sem1, inst1} in ONE chunk;
 //                              layer 0 is one chunk of all W/32 blocks (32 MFMAs) instead of two of 16
+//   plan 2 (two-tile kernel, csrc/asm/gen_mlp_tt.py): plan 0's order (sem0 | sem1 | inst0 | inst1: sem1's reduction hides under
+//                              inst0's MFMAs) with layer 0, sem1 and inst1 as ONE chunk EACH (all blocks of the layer), and no
+//                              chunk above 33 fragments -- a layer whose 2-block chunk would be larger (the layer behind
+//                              the skip: 2 x 20 + 1, views: 2 x 18 + 1) is cut into 1-block chunks -- so that FOUR weight slots fit
+//                              the LDS; the number of chunks is then a multiple of 4 (slot = chunk % 4 is static)
 #pragma once
 #include <stddef.h>
 
@@ -19,6 +24,12 @@ static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
 {
     const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
     return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1 && pnr_head_depth(d) == 2;
+}
+// plan 2 (the two-tile kernel's image): the geometry its generated kernels exist for -- the benched network
+#define PNR_PLAN2_MAX_CHUNK_FRAGS 33
+static inline int pnr_plan2_supported(const pnr_mlp_desc& d)
+{
+    return pnr_plan1_supported(d) && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 && d.head_tap == 0 && d.n_inst > 0;
 }
 
 #ifndef PNR_PLAN1_TRUNK0_MERGE
@@ -51,7 +62,9 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         L.nks = pnr_seg_vl(k0, n0) / kpl + (k1 >= 0 ? pnr_seg_vl(k1, n1) / kpl : 0);
         L.fbc = pnr_layer_fbc(kind, d.precision);
         if (L.n_fb % L.fbc) L.fbc = 1;
-        if (PNR_PLAN1_TRUNK0_MERGE && d.plan == 1 && kind == PNR_L_TRUNK0) L.fbc = L.n_fb;      // plan 1: layer 0 is ONE chunk of W/32 blocks x 4 k-steps
+        if (PNR_PLAN1_TRUNK0_MERGE && d.plan >= 1 && kind == PNR_L_TRUNK0) L.fbc = L.n_fb;      // plan 1, 2: layer 0 is ONE chunk of W/32 blocks x 4 k-steps
+        if (d.plan == 2 && (kind == PNR_L_SEM1 || kind == PNR_L_INST1)) L.fbc = L.n_fb;         // plan 2: a logit layer is one chunk
+        if (d.plan == 2 && L.fbc * L.nks + 1 > PNR_PLAN2_MAX_CHUNK_FRAGS) L.fbc = 1;            // plan 2: four slots must fit the LDS
         plan.layers.push_back(L);
     };
     plan.layers.clear();

@@ -1,0 +1,61 @@
+// Launcher of k_mlp_tt, the two-tile assembly form of the fused inference MLP (csrc/asm/gen_mlp_tt.py): the code object is
+// assembled at build time, embedded in libpnr.so (build/obj/pnr_mlp_tt_co.inc) and loaded once per device with
+// hipModuleLoadData -- the "once-initialised module / kernel table" include/pnr.h allows next to the otherwise stateless library.
+// The first call on a device must therefore happen OUTSIDE a stream capture (module loading is not capturable); later calls are
+// plain kernel launches and capture like every other entry point.
+#include <mutex>
+
+#include "pnr_common.h"
+#include "pnr_mlp_tt.h"
+
+static const unsigned char k_co[] = {
+#include "pnr_mlp_tt_co.inc"
+};
+
+namespace {
+struct DevTable {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[3][2] = {};        // [nbs][nbi]
+    bool tried = false, ok = false;
+};
+DevTable g_tab[64];
+std::mutex g_mu;
+}   // namespace
+
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream)
+{
+    PNR_REQUIRE(nbs >= 1 && nbs <= 2 && nbi == 1, "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
+    PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
+                "render in chunks", a.S);
+    int dev = 0;
+    PNR_HIP(hipGetDevice(&dev));
+    PNR_REQUIRE(dev >= 0 && dev < 64, "pnr_mlp_tt: device index %d out of range", dev);
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        DevTable& t = g_tab[dev];
+        if (!t.tried) {
+            t.tried = true;
+            hipError_t e = hipModuleLoadData(&t.mod, k_co);
+            if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[1][1], t.mod, "k_mlp_tt_s1i1");
+            if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[2][1], t.mod, "k_mlp_tt_s2i1");
+            if (e != hipSuccess) {
+                pnr_set_error("pnr_mlp_tt: loading the two-tile code object failed: %s (the first call on a device must not be inside a "
+                              "stream capture)", hipGetErrorString(e));
+                t.tried = false;        // let the next call (outside a capture) try again
+                return PNR_EHIP;
+            }
+            t.ok = true;
+        }
+        PNR_REQUIRE(t.ok, "pnr_mlp_tt: the two-tile code object is not loaded");
+        fn = t.fn[nbs][nbi];
+    }
+    PnrTTArgs ka = a;
+    const int cus = pnr_cu_count();
+    ka.n_groups = (a.S + 255) / 256;
+    ka.n_wg = ka.n_groups < cus ? ka.n_groups : cus;
+    size_t size = sizeof(ka);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    PNR_HIP(hipModuleLaunchKernel(fn, (unsigned)ka.n_wg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+    return PNR_OK;
+}

@@ -1,0 +1,22 @@
+// Kernel arguments of k_mlp_tt (csrc/asm/gen_mlp_tt.py reads them with s_load at these byte offsets) and its launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PnrTTArgs {
+    const void* image;          //  0  fragment stream of the plan-2 image (packed + data_off)
+    const float* rays;          //  8
+    const float* z;             // 16
+    int32_t S, N;               // 24  samples, samples per ray
+    uint32_t n_magic;           // 32  x / N = (x * n_magic) >> n_shift (pnr_set_div_magic)
+    int32_t n_shift;            // 36
+    int32_t n_groups, n_wg;     // 40  256-sample groups, workgroups (filled by the launcher)
+    float* rec;                 // 48  per-tile records
+    int32_t rec_floats, pad0;   // 56
+    void* ps;                   // 64  per-sample (lw, r, g, b)
+    int32_t n_sem, n_inst;      // 72
+    unsigned long long* clk;    // 80  optional {shader cycles, 100 MHz ticks} of workgroup 0's first wave
+};
+static_assert(sizeof(PnrTTArgs) == 88, "k_mlp_tt reads its arguments at fixed offsets");
+
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream);

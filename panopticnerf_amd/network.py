@@ -110,8 +110,9 @@ class Network(nn.Module):
         net = self.nerf(level)                   # raises when a fine level is asked of a coarse-only network
         desc = net.desc(precision)
         if fused and not backward:
-            # image for pnr_mlp_forward_composite only: the fused-inference chunk order where the geometry has one
-            desc.plan = ops.fused_plan(desc)
+            # image for pnr_mlp_forward_composite only: the best fused-inference chunk order the geometry has (fused = 1 / 2: at most
+            # that plan -- tests compare the kernels)
+            desc.plan = ops.fused_plan(desc, None if fused is True else int(fused))
         key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision, int(desc.plan))
         ver = self._version(level)
         hit = self._packed.get(key)
@@ -136,7 +137,7 @@ class Network(nn.Module):
 
     def packed(self, level, device, precision=None, fused=False):
         """(desc, packed image).  fused=True: the image only ops.mlp_forward_composite consumes (desc.plan as
-        pnr_mlp_fused_plan says); every other op takes the classic image (fused=False)."""
+        pnr_mlp_fused_plan says; fused = 1 | 2 caps the plan); every other op takes the classic image (fused=False)."""
         return self._pack(level, device, precision or self.precision, False, fused)
 
     def packed_bwd(self, level, device):

@@ -5,6 +5,7 @@ PyTorch is used only for device memory and the current HIP stream: every op take
 All ops fail loudly off-GPU; nothing here computes on the CPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -138,10 +139,13 @@ def make_desc(D=8, W=256, skip=4, xyz_L=10, dir_L=4, n_sem=0, n_inst=0, head_W=N
     return d
 
 
-def fused_plan(desc):
-    """desc.plan to use for an image that only mlp_forward_composite will consume (pnr_mlp_fused_plan): 1 where the geometry
-    has the fused-inference chunk order, else 0."""
-    return int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc)))
+def fused_plan(desc, limit=None):
+    """desc.plan to use for an image that only mlp_forward_composite will consume (pnr_mlp_fused_plan): 2 where the geometry has
+    the two-tile assembly kernel, 1 where it has the fused-inference chunk order of the 8-wave kernel, else 0.  limit (or the
+    environment's PNR_FUSED_PLAN, for A/B runs) caps it."""
+    best = int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc)))
+    cap = limit if limit is not None else os.environ.get("PNR_FUSED_PLAN")
+    return best if cap is None else min(best, int(cap))
 
 
 def _param_struct(desc, params, device):
