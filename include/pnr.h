@@ -83,7 +83,8 @@ typedef struct pnr_mlp_desc {
                              the forward MLP kernels launched with this descriptor write {shader cycles, 100 MHz ticks} of
                              workgroup 0's first wave there (their ratio = the mean shader clock during the launch).  0 = off.
                              A descriptor field, not a setter: the library keeps no mutable state (round 5) */
-    int32_t reserved[1];
+    int32_t reserved[1];  /* 0.  (0x7A with plan 2 and clk_probe set: the trace build of k_mlp_tt -- 64 per-unit s_memtime stamps of
+                             workgroup 0's first wave instead of the clock pair; tools/tt_trace.py) */
 } pnr_mlp_desc;
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.

@@ -26,12 +26,19 @@ import struct
 import sys
 from contextlib import contextmanager
 
+import os
+STORE_NT = " nt" if os.environ.get("PNR_TT_STORE_NT", "0") == "1" else ""      # cache policy of the record / quadruple stores
+PIECE_FRAC = float(os.environ.get("PNR_TT_PIECE_FRAC", "1.0"))                 # the pieces of a chunk go out in this first fraction of its gaps
 NSLOT, SLOT = 4, 33 * 1024
 P = 4                                   # fragment ring (quads)
 D, SKIP = 8, 4
 
 # ---- VGPR map
-V_TID, V_LANE16, V_FRAG, V_BIAS, V_T0, V_T1, V_T2, V_T3, V_LB4, V_ZERO = 0, 1, 2, 6, 10, 11, 12, 13, 14, 15
+V_TID, V_LANE16, V_FRAG, V_BIAS, V_T0, V_DMA, V_LB4, V_TRACE = 0, 1, 2, 6, 10, 11, 14, 15
+# V_DMA + m: lane * 16 + wave * 4 KiB + m * 16 KiB: the LDS-DMA pieces' address offsets.  A wave copies the fragments
+# 16 m + 4 wave + i (i < 4: the instruction's immediate offset i KiB) of a chunk -- runs of four, round-robin over the waves.
+V_T1 = 1    # second pack temporary (lane * 16 is only needed to build the bases): one temporary for consecutive packs let the
+            # v_accvgpr_write of a pack see the NEXT pack's value (measured: records differed)
 V_RING, V_ACC = 16, 32                  # ring: v[16:31]; accumulators 0..7: v[32 + 16 i : +16]
 V_EX, V_ED = 160, 192                   # gamma(x) [2 tiles][16], gamma(d) [2][8]
 V_G = 208                               # g blocks 0, 1 of both tiles [2][16]  (views' first two blocks; the other two live in A0)
@@ -43,12 +50,13 @@ V_PTMP = 248                            # 8 more temporaries v[248:255]
 A0, A1 = 0, 128
 # ---- SGPR map
 S_IMG, S_RAYS, S_Z, S_S, S_N, S_MAGIC, S_SHIFT, S_NGRP, S_NWG, S_REC, S_RECF, S_PS, S_NSEM, S_NINST, S_CLK = 4, 6, 8, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 23, 24
-S_WAVE, S_W1K, S_GRP, S_PIECE, S_IMGW, S_T0, S_T1 = 26, 27, 28, 30, 32, 34, 35
+S_WAVE, S_W4K, S_GRP, S_PIECE, S_T0, S_T1 = 26, 27, 28, 30, 34, 35
 S_VALID, S_LAST = 36, 40                # [2 tiles] x 64-bit masks of the CURRENT group: s[36:39], s[40:43]
 S_NVALID, S_NLAST = 44, 48              # the same of the NEXT group (filled at fetch time): s[44:47], s[48:51]
 S_LO32, S_N0, S_HI0 = 52, 54, 56        # constants: lanes 0..31, lanes {0, 32}, lanes with hi == 0 (= lanes 0..31)
 S_SAVE, S_REC_T = 58, 60                # saved exec; the two tiles' record pointers s[60:61], s[62:63]
-S_W = 64                                # 32 local weights of a tile (v_readlane): s[64:95]
+S_MSK = 64                              # store masks of the (up to) three logit blocks: s[64:69] = lanes with hi == 0 and channel < n_out
+S_REC_I = 70                            # the two tiles' record pointers + 4 n_sem (the instance columns): s[70:73]
 S_CLK0 = 96                             # s[96:99] clocks at start
 S_K = 100                               # s100: literal constants that VOP3 cannot carry
 S_Q = 19                                # the tile's Q (v_readlane) between the scan and its store
@@ -110,16 +118,22 @@ class Sim:
 
 
 class Gen:
-    def __init__(self, nbs, nbi, name):
-        self.nbs, self.nbi, self.name = nbs, nbi, name
+    def __init__(self, nbs, nbi, name, trace=False, abl=0):
+        # abl (trace builds only; results invalid): 1 = no LDS-DMA pieces in the loop, 2 = no chunk hand-over (vmcnt + barrier),
+        # 4 = no pack / ReLU of the hidden layers
+        self.nbs, self.nbi, self.name, self.trace, self.abl = nbs, nbi, name, trace, abl
+        self.nstamp = 0
         self.o = []
         self.nlabel = 0
         self.lgkm = Sim("lgkm", 15)
         self.vm = Sim("vm", 63)
-        self.side, self.outbox, self.capture = [], [], None
+        self.side, self.side_lo, self.outbox, self.capture = [], [], [], None
         self.ring_tags = [None] * P
         self.piece_tag = {}
         self.pending_pack = None
+        self.g2_acc = self.park_acc = None
+        self.m0 = None
+        self.logit_units = []
         self.acc_free = list(range(8))
         self.build_plan()
         self.build_units()
@@ -147,10 +161,13 @@ class Gen:
         add("feature", 8, [("h", 16)], 2, "linear")
         add("views", 4, [("F", 16), ("ed", 2)], 2, "relu")
         add("rgbs", 1, [("g", 8), ("hh", 16)], 1, "rgbs")
+        # heads: sem0 | inst0 | sem1 | inst1 -- a logit layer never follows its own hidden layer directly (the hidden layer's last
+        # blocks would have to be packed inside the logit unit's first MFMA gaps), sem1's reduction runs beside inst1
         add("sem0", 4, [("hh", 16)], 2, "relu")
-        add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
         if self.nbi:
             add("inst0", 4, [("hh", 16)], 2, "relu")
+        add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
+        if self.nbi:
             add("inst1", 1, [("shi", 8)], 1, "logits")
         self.layers = L
         self.chunks = []
@@ -241,18 +258,19 @@ class Gen:
         """s_mov of a 32-bit literal (VOP3 instructions cannot carry one on gfx9)"""
         self.e("s_mov_b32 s%d, 0x%x" % (sreg, val & 0xffffffff))
 
-    def q(self, cost, fn):
-        self.side.append(fn)
+    def q(self, cost, fn, low=False):
+        """queue side work; low: work that holds no accumulator (the encoders) -- it waits for everything else"""
+        (self.side_lo if low else self.side).append(fn)
 
     def side_busy(self):
-        return bool(self.side or self.outbox)
+        return bool(self.side or self.side_lo or self.outbox)
 
     def drain_side(self, budget=None):
         """emit queued side work: all of it (budget None) or `budget` instructions"""
         spent = 0
         while self.side_busy() and (budget is None or spent < budget):
             if not self.outbox:
-                fn = self.side.pop(0)
+                fn = self.side.pop(0) if self.side else self.side_lo.pop(0)
                 self.capture = []
                 fn()
                 self.outbox, self.capture = self.capture, None
@@ -266,28 +284,47 @@ class Gen:
                 spent += 1
 
     # ------------------------------------------------------------------ LDS-DMA
-    def piece(self, chunk, j, guard_nfrag=None):
-        """fragment wave + 4 j of image chunk `chunk` -> its LDS slot"""
-        c = self.chunks[chunk]
+    def chunk_base(self, chunk):
+        """s[S_PIECE : S_PIECE + 1] = address of image chunk `chunk` (once per chunk, in front of its first piece)"""
+        self.e("s_add_u32 s%d, s%d, 0x%x" % (S_PIECE, S_IMG, self.chunks[chunk]["off"] * 1024))
+        self.e("s_addc_u32 s%d, s%d, 0" % (S_PIECE + 1, S_IMG + 1))
+
+    def piece_list(self, chunk):
+        """(m, i, waves) of the LDS-DMA pieces of a chunk: fragment 16 m + 4 wave + i, issued by waves 0 .. waves - 1"""
+        n = self.chunks[chunk]["nfrag"]
+        out = []
+        for m in range((n + 15) // 16):
+            for i in range(4):
+                nw = max(0, min(4, -(-(n - 16 * m - i) // 4)))
+                if nw:
+                    out.append((m, i, nw))
+        return out
+
+    def piece(self, chunk, j):
+        """piece j of image chunk `chunk` -> its LDS slot: M0 and the load (the address is the chunk's base + this lane's constant
+        offset register + an immediate; the first version's per-piece 64-bit SALU add cost a third of a piece)"""
+        m, i, nw = self.piece_list(chunk)[j]
         slot = chunk % NSLOT
         skip = None
-        certain = True
-        if c["nfrag"] - 4 * j < 4:              # only waves < nfrag - 4 j hold such a fragment
+        certain = nw >= 4
+        if not certain:
             skip = self.label()
-            certain = False
-            self.e("s_cmp_ge_u32 s%d, %d" % (S_WAVE, c["nfrag"] - 4 * j))
+            self.e("s_cmp_ge_u32 s%d, %d" % (S_WAVE, nw))
             self.e("s_cbranch_scc1 %s" % skip)
-        self.e("s_add_u32 m0, s%d, 0x%x" % (S_W1K, slot * SLOT + j * 4096))
-        self.e("s_add_u32 s%d, s%d, 0x%x" % (S_PIECE, S_IMGW, (c["off"] + 4 * j) * 1024))
-        self.e("s_addc_u32 s%d, s%d, 0" % (S_PIECE + 1, S_IMGW + 1))
-        tag = self.vm_op("global_load_lds_dwordx4 v%d, s[%d:%d] nt" % (V_LANE16, S_PIECE, S_PIECE + 1), certain)
+        # the instruction's immediate offset moves BOTH addresses (memory and LDS): M0 carries the run's base only -- and stays
+        # what it is for the four pieces of a run (nothing else in the loop writes M0; trace builds do)
+        m0 = slot * SLOT + 16 * m * 1024
+        if self.m0 != m0 or skip or self.trace:
+            self.e("s_add_u32 m0, s%d, 0x%x" % (S_W4K, m0))
+            self.e("s_nop 0")                   # SALU write of M0 -> LDS-DMA: one wait state
+        self.m0 = None if skip else m0          # (a guarded piece: the waves that skipped it did not write M0)
+        tag = self.vm_op("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d nt" % (V_DMA + m, S_PIECE, S_PIECE + 1, i * 1024), certain)
         if skip:
             self.o.append(skip + ":")
         return tag
 
     def pieces_of(self, chunk):
-        n = self.chunks[chunk]["nfrag"]
-        return (n + 3) // 4
+        return len(self.piece_list(chunk))
 
     # ------------------------------------------------------------------ operand locations of the layer inputs
     def loc_of(self, seg, layer_index, t, ks):
@@ -327,17 +364,17 @@ class Gen:
         if blk < 2:
             return Loc("v", V_G + 16 * t + 8 * blk + r)
         if blk == 2:
-            return Loc("v", V_EX + 16 * t + r)                                      # gamma(x) is dead after the skip layer
+            return Loc("v", self.acc_reg(self.g2_acc) + 8 * t + r)                  # an idle accumulator (views / rgbs units take two)
         return Loc("a", self.F_base() + 8 * t + r)                                  # F[0:15] (packed during the rgb / sigma unit)
 
     def shs_block(self, blk, t, r=0):
         return Loc("a", self.F_base() + 32 + 32 * t + 8 * blk + r)                  # F[32:95]
 
     def shi_block(self, blk, t, r=0):
-        # inst0 runs after sem1: sem0's outputs are dead, but the LAST inst0 unit is packed while inst1's MFMAs read the first
+        # the last inst0 unit is packed while sem1's MFMAs still read shs: its blocks go to h (dead once inst0's MFMAs are issued)
         if blk < 2:
             return Loc("a", self.F_base() + 96 + 16 * t + 8 * blk + r)              # F[96:127]
-        return Loc("a", self.F_base() + 32 + 16 * t + 8 * (blk - 2) + r)            # F[32:63] (shs is dead)
+        return Loc("a", self.trunk_out(D - 1) + 16 * t + 8 * (blk - 2) + r)         # h[0:31]
 
     def out_block(self, layer, blk, t):
         """Loc of the 8 packed registers of output block `blk` of `layer` for tile t"""
@@ -528,8 +565,9 @@ class Gen:
         return self.vm_op("global_load_dword v%d, v%d, s[%d:%d]" % (vi + 7, a64 + 1, S_Z, S_Z + 1))
 
     # ---- gamma(x), gamma(d), |d| of tile t from V_IN (results: V_EX / V_ED, and zz zn dn of the NEXT group parked in V_IN + {6, 7, 3})
-    def encode_tile(self, t, chunks):
-        """list of closures (side-queue pieces) that encode tile t"""
+    def encode_tile(self, t, part):
+        """closures (side-queue pieces) that encode tile t.  part "x": point, |d|, gamma(x), q = d / |d| (into V_IN + 3..5);
+        part "d": gamma(d) from q"""
         vi = V_IN + 8 * t
         T = list(range(V_TMP, V_TMP + 16))          # 16 temporaries
         s = T[0:3]
@@ -554,13 +592,15 @@ class Gen:
             e("v_add_f32 v%d, v%d, v%d" % (w[0], w[0], w[1]))
             e("v_mul_f32 v%d, v%d, v%d" % (w[1], vi + 5, vi + 5))
             e("v_add_f32 v%d, v%d, v%d" % (w[0], w[0], w[1]))
-        out.append((11, points))
+        if part == "x":
+            out.append((11, points))
 
         def norm():
             self.sqrt(w[5], w[0], [w[1], w[2], w[3]])
             # park |d| in the ray record's unused `ox` slot?  no: ox is still needed for nothing after points() -- q holds the point
             e("v_mov_b32 v%d, v%d" % (vi + 0, w[5]))        # V_IN + 0 := |d| of the next group
-        out.append((22, norm))
+        if part == "x":
+            out.append((22, norm))
 
         def xyz_reg():
             # reg 0 of gamma(x): pack(hi ? pz : px, hi ? 0 : py)
@@ -574,20 +614,30 @@ class Gen:
             hi_select(tt, tt, w[1])
             for a in range(3):
                 e("v_mul_f32 v%d, v%d, v%d" % (q[a], q[a], tt))         # p * base
-        out.append((12, xyz_reg))
-        for a in range(3):
-            out.append((30, (lambda a=a: self.sincos(s[a], c[a], q[a], w))))
-        for fp in range(5):
-            out.append((3, (lambda fp=fp: self.band_pack(ex + 1 + 3 * fp, s, c))))
-            if fp < 4:
-                out.append((15, (lambda: self.band_next(s, c, tt))))
+        if part == "x":
+            out.append((12, xyz_reg))
+            for a in range(3):
+                out.append((30, (lambda a=a: self.sincos(s[a], c[a], q[a], w))))
+            for fp in range(5):
+                out.append((3, (lambda fp=fp: self.band_pack(ex + 1 + 3 * fp, s, c))))
+                if fp < 4:
+                    out.append((15, (lambda: self.band_next(s, c, tt))))
 
-        # gamma(d): q = d / |d|
+        # q = d / |d|, kept in the d slots of V_IN
         def dirs():
             for a in range(3):
                 self.div(q[a], vi + 3 + a, vi + 0, [w[0], w[1], w[2], w[3], w[4]])
                 e("s_nop 0")
-        out.append((36, dirs))
+            for a in range(3):
+                e("v_mov_b32 v%d, v%d" % (vi + 3 + a, q[a]))
+        if part == "x":
+            out.append((39, dirs))
+            return out
+
+        def load_q():
+            for a in range(3):
+                e("v_mov_b32 v%d, v%d" % (q[a], vi + 3 + a))
+        out.append((3, load_q))
 
         def d_reg():
             hi_select(w[0], q[2], q[0])
@@ -683,6 +733,9 @@ class Gen:
             e("s_lshl_b64 s[%d:%d], s[%d:%d], 2" % (S_SAVE, S_SAVE + 1, S_SAVE, S_SAVE + 1))
             e("s_add_u32 s%d, s%d, s%d" % (S_REC_T + 2 * t, S_REC, S_SAVE))
             e("s_addc_u32 s%d, s%d, s%d" % (S_REC_T + 2 * t + 1, S_REC + 1, S_SAVE + 1))
+            e("s_lshl_b32 s%d, s%d, 2" % (S_SAVE, S_NSEM))                            # ... and of its instance columns
+            e("s_add_u32 s%d, s%d, s%d" % (S_REC_I + 2 * t, S_REC_T + 2 * t, S_SAVE))
+            e("s_addc_u32 s%d, s%d, 0" % (S_REC_I + 2 * t + 1, S_REC_T + 2 * t + 1))
             # ps[samp] = (lw, r, g, b): lanes hi == 0 and valid; byte offset (s0 * 16) fits 32 bits (S < 2^27 ... checked by the launcher)
             e("s_lshl_b32 s%d, s%d, 5" % (S_T0, S_T0))
             e("v_and_b32 v%d, 31, v%d" % (d, V_TID))
@@ -694,10 +747,11 @@ class Gen:
             e("v_mov_b32 v%d, v%d" % (T[7], acc + 2))
             e("s_and_b64 s[%d:%d], s[%d:%d], s[%d:%d]" % (S_SAVE, S_SAVE + 1, VAL, VAL + 1, S_HI0, S_HI0 + 1))
             e("s_mov_b64 exec, s[%d:%d]" % (S_SAVE, S_SAVE + 1))
-            self.vm_op("global_store_dwordx4 v%d, %s, s[%d:%d]" % (d, vr(T[4], 4), S_PS, S_PS + 1))
+            self.vm_op("global_store_dwordx4 v%d, %s, s[%d:%d]%s" % (d, vr(T[4], 4), S_PS, S_PS + 1, STORE_NT))
             e("s_mov_b64 exec, 1")                                                   # lane 0: rec[0] = q
             e("v_mov_b32 v%d, s%d" % (x, S_Q))
-            self.vm_op("global_store_dword v%d, v%d, s[%d:%d]" % (V_ZERO, x, S_REC_T + 2 * t, S_REC_T + 2 * t + 1))
+            e("v_mov_b32 v%d, 0" % d)
+            self.vm_op("global_store_dword v%d, v%d, s[%d:%d]%s" % (d, x, S_REC_T + 2 * t, S_REC_T + 2 * t + 1, STORE_NT))
             e("s_mov_b64 exec, -1")
         self.q(28, stores)
 
@@ -716,6 +770,7 @@ class Gen:
 
         def body():
             # lwr[r] (lwr_build): v[V_TMP + r] = hi ? lw[row(r, 1)] : lw[row(r, 0)]
+            self.wait_lgkm(self.lwr_tag)
             e("v_fma_f32 v%d, v%d, v%d, 0" % (s_, T[0], acc))
             for r in range(1, 16):
                 e("v_fmac_f32 v%d, v%d, v%d" % (s_, T[r], acc + r))
@@ -761,33 +816,43 @@ class Gen:
         self.acc_free = sorted(set(self.acc_free) | set(ids))
 
     # ------------------------------------------------------------------ arming: the bias of a unit into freshly taken accumulators
-    def arm_ops(self, u):
-        """list of closures, one LDS read each: bias of unit u -> its accumulators (u['accs'] is set here)"""
+    def arm_plan(self, u):
+        """per accumulator of unit u (block-major, tile-minor): a list of closures, one LDS read each, that put the bias into it;
+        the first closure of an accumulator TAKES it (u['accs'] fills as the closures run)"""
         c = self.chunks[u["chunk"]]
         l = self.layers[u["layer"]]
         slot = u["chunk"] % NSLOT
         bias_off = c["nfb"] * l["nks"] * 1024
-        nb = len(u["blocks"])
-        ids = self.acc_take(2 * nb)
-        u["accs"] = {(bi, t): ids[bi * 2 + t] for bi in range(nb) for t in range(2)}
-        u["arm_tags"] = []
-        ops = []
+        u["accs"], u["arm_tags"] = {}, []
+        plans = []
         for bi, blk in enumerate(u["blocks"]):
             b_in_chunk = blk - c["fb"]
             for t in range(2):
-                a = self.acc_reg(u["accs"][(bi, t)])
+                key = (bi, t)
+                ops = []
+
+                def take(key=key):
+                    while not self.acc_free and self.side_busy():       # a queued epilogue still holds accumulators: run it now
+                        self.drain_side(8)
+                    u["accs"][key] = self.acc_take(1)[0]
                 if l["mode"] == "logits":       # transposed product: every register = bias of channel lane & 31
-                    def mk_addr(slot=slot):
-                        self.e("v_add_u32 v%d, 0x%x, v%d" % (V_T2, slot * SLOT, V_LB4))
-                    ops.append(mk_addr)
-                    for r in range(16):
-                        ops.append(lambda a=a, r=r, off=bias_off + b_in_chunk * 128: u["arm_tags"].append(
-                            self.lds_read("ds_read_b32 v%d, v%d offset:%d" % (a + r, V_T2, off))))
+                    def first(key=key, slot=slot, take=take):           # the address lives in the accumulator's first register, read last
+                        take()
+                        self.e("v_add_u32 v%d, 0x%x, v%d" % (self.acc_reg(u["accs"][key]), slot * SLOT, V_LB4))
+                    ops.append(first)
+                    for r in list(range(1, 16)) + [0]:
+                        ops.append(lambda key=key, r=r, off=bias_off + b_in_chunk * 128: u["arm_tags"].append(
+                            self.lds_read("ds_read_b32 v%d, v%d offset:%d" % (self.acc_reg(u["accs"][key]) + r, self.acc_reg(u["accs"][key]), off))))
                 else:
                     for m in range(4):
-                        ops.append(lambda a=a, m=m, off=bias_off + b_in_chunk * 128 + m * 32: u["arm_tags"].append(
-                            self.lds_read("ds_read_b128 %s, v%d offset:%d" % (vr(a + 4 * m, 4), V_BIAS + slot, off))))
-        return ops
+                        def rd(key=key, m=m, off=bias_off + b_in_chunk * 128 + m * 32, take=take):
+                            if m == 0:
+                                take()
+                            a = self.acc_reg(u["accs"][key])
+                            u["arm_tags"].append(self.lds_read("ds_read_b128 %s, v%d offset:%d" % (vr(a + 4 * m, 4), V_BIAS + slot, off)))
+                        ops.append(rd)
+                plans.append(ops)
+        return plans
 
     # ------------------------------------------------------------------ pack / ReLU of a unit's accumulators -> list of (dst, closure)
     def pack_ops(self, u):
@@ -810,7 +875,7 @@ class Gen:
                             if relu:
                                 self.e("v_pk_max_i16 v%d, v%d, 0" % (tmp, tmp))
                             self.e("v_accvgpr_write_b32 a%d, v%d" % (dst.base + p, tmp))
-                    out.append(((dst.kind, dst.base + p), fn))
+                    out.append(((dst.kind, dst.base + p), fn, u["accs"][(bi, t)]))
         return out
 
     # ------------------------------------------------------------------ one unit of MFMAs with its fillers
@@ -830,6 +895,17 @@ class Gen:
         swap = l["mode"] == "logits"
         e = self.e
         e("; ==== unit %d: %s blocks %s (chunk %d, slot %d), %d MFMAs" % (ui, l["name"], u["blocks"], u["chunk"], u["chunk"] % NSLOT, nm))
+        self.stamp(ui)
+        if l["name"] == "L%d" % (SKIP + 2) and u["blocks"][0] == 0:
+            self.queue_inputs_early()
+        if l["name"] == "views" and u["blocks"] == [0]:
+            self.drain_side()                       # (nothing left normally) the early side work uses the g area
+        if l["name"] == "views" and u["blocks"] == [1]:
+            self.park()
+        if l["name"] == "sem0" and u["blocks"][0] == 0:
+            self.unpark()
+        if l["name"] == "views" and u["blocks"] == [2]:
+            self.g2_acc = self.acc_take(1)[0]       # home of g block 2 (packed during the next unit) until the rgb / sigma unit is issued
         # ---- what has to happen inside this unit
         # (1) the previous unit's pack / ReLU, each before the first MFMA of THIS unit that reads its destination
         prev = self.pending_pack
@@ -841,17 +917,43 @@ class Gen:
             loc = self.b_operand(u, frags[f][2], t)
             for r in range(4):
                 reads.setdefault((loc.kind, loc.base + r), i)
-        n = len(packs)
+        # ... and, pipelined with it, the NEXT unit's bias: as soon as an accumulator is packed it is released and re-armed.  One list
+        # of "musts" in program order, spread evenly over the unit's gaps (the first version packed in the first 60 % of the gaps
+        # and armed in the last 25 %: up to seven fillers per gap where five hide, and nothing to do in between)
+        nxt = U[ui + 1] if ui + 1 < len(U) else None
+        plans = self.arm_plan(nxt) if nxt is not None else []
+        musts, dls, pack_fns = [], [], set()
+        by_acc = {}
+        for dst, fn, a in packs:
+            by_acc.setdefault(a, []).append((dst, fn))
+        k = 0
+        for a, lst in by_acc.items():
+            for dst, fn in lst:
+                musts.append(fn if not self.abl & 4 else (lambda: None))
+                pack_fns.add(musts[-1])
+                dls.append(reads.get(dst))
+            musts.append(lambda a=a: self.acc_release([a]))
+            dls.append(None)
+            if k < len(plans):
+                for op in plans[k]:
+                    musts.append(op)
+                    dls.append(None)
+                k += 1
+        for kk in range(k, len(plans)):
+            for op in plans[kk]:
+                musts.append(op)
+                dls.append(None)
+        n = len(musts)
         pos = []
-        for j, (dst, _) in enumerate(packs):
-            spread = 1 + (j * max(1, int(0.62 * nm) - 1)) // max(1, n)
-            dl = reads.get(dst)
-            pos.append(spread if dl is None else min(spread, max(0, dl - 2)))
-        for j in range(n - 2, -1, -1):                  # program order: a pack never after a later pack's position
+        late = not packs and n > 0                      # nothing to pack (the previous unit's results go through the side queue and hold
+        for j in range(n):                              # their accumulators until then): arm in the unit's last third
+            spread = 1 + (j * max(1, nm - 6)) // max(1, n) if not late else (2 * nm) // 3 + (j * max(1, nm // 3 - 5)) // max(1, n)
+            pos.append(spread if dls[j] is None else min(spread, max(0, dls[j] - 2)))
+        for j in range(n - 2, -1, -1):                  # program order: a must never after a later must's position
             pos[j] = min(pos[j], pos[j + 1])
-        pack_at = {}
+        must_at = {}
         for j, g in enumerate(pos):
-            pack_at.setdefault(g, []).append(j)
+            must_at.setdefault(g, []).append(j)
         # (2) LDS-DMA pieces of chunk + 3, spread over the chunk's units
         piece_at = {}
         cu = [k for k, x in enumerate(U) if x["chunk"] == u["chunk"]]
@@ -859,14 +961,15 @@ class Gen:
         npieces = self.pieces_of(c3)
         k_in = cu.index(ui)
         mine = [j for j in range(npieces) if (j * len(cu)) // npieces == k_in]
+        cost = [3 * sum(1 for j in must_at.get(g, []) if j < n and dls[j] is not None or (j < n and musts[j] in pack_fns)) +
+                sum(1 for j in must_at.get(g, [])) for g in range(nm)]
         for idx, j in enumerate(mine):
-            g = 2 + (idx * (nm - 4)) // max(1, len(mine))
+            span = max(len(mine) + 1, int(PIECE_FRAC * (nm - 3)))
+            lo = 1 + (idx * span) // max(1, len(mine))
+            hi = max(lo + 1, 1 + ((idx + 1) * span) // max(1, len(mine)))
+            g = min(range(lo, min(hi, nm - 1)), key=lambda x: (cost[x], x))
+            cost[g] += 2
             piece_at.setdefault(g, []).append(j)
-        # (3) the next unit's bias: armed in this unit's tail, once its accumulators are free
-        nxt = U[ui + 1] if ui + 1 < len(U) else None
-        n_arm = 0 if nxt is None else 2 * len(nxt["blocks"]) * (17 if self.layers[nxt["layer"]]["mode"] == "logits" else 4)
-        arm_from = max(nm - 5 - n_arm, (max(pos) + 1) if pos else 0, 0)      # done ~4 gaps before the unit ends: the ring's reads stay the youngest
-        arm = None
         # ---- the MFMAs
         first_wait_done = False
         for i in range(nm):
@@ -892,34 +995,16 @@ class Gen:
                 if gn < len(self.stream):
                     sl, of = self.stream[gn]
                     self.ring_tags[gn % P] = self.lds_read("ds_read_b128 %s, v%d offset:%d" % (vr(V_RING + 4 * (gn % P), 4), V_FRAG + sl, of))
-            for j in pack_at.get(i, []):
-                packs[j][1]()
-            if prev and i == (max(pos) if pos else 0):
-                self.acc_release(prev["accs"])
-                prev = None
-            for j in piece_at.get(i, []):
+            for j in must_at.get(i, []):
+                musts[j]()
+            for j in ([] if self.abl & 1 else piece_at.get(i, [])):
+                if j == 0:
+                    self.chunk_base(c3)
                 tg = self.piece(c3, j)
                 self.piece_tag[c3] = tg
-            if nxt is not None and i >= arm_from:
-                if arm is None:
-                    # the accumulators must be there: if a queued epilogue still holds some, run it now
-                    need = 2 * len(nxt["blocks"])
-                    while len(self.acc_free) < need and self.side_busy():
-                        self.drain_side(8)
-                    arm = self.arm_ops(nxt)
-                per = -(-len(arm) // max(1, nm - 4 - i))
-                for _ in range(min(per, len(arm))):
-                    arm.pop(0)()
-            self.drain_side(side_budget)
-        if prev:
-            self.acc_release(prev["accs"])
-        if nxt is not None:
-            if arm is None:
-                while len(self.acc_free) < 2 * len(nxt["blocks"]) and self.side_busy():
-                    self.drain_side(8)
-                arm = self.arm_ops(nxt)
-            while arm:
-                arm.pop(0)()
+            self.drain_side(1 if l["name"].startswith("L") or l["name"] in ("feature", "views") else 3 if late else 2)
+        for g in sorted(must_at):                       # (positions beyond the last gap: none by construction)
+            assert g < nm, (g, nm)
         # ---- this unit's own results: packed during the next unit, or reduced by the side queue
         if l["mode"] in ("relu", "linear"):
             self.pending_pack = dict(ops=self.pack_ops(u), accs=list(u["accs"].values()))
@@ -928,35 +1013,100 @@ class Gen:
                 self.rgbs_epilogue(t, self.acc_reg(u["accs"][(0, t)]))
             ids = list(u["accs"].values())
             self.q(0, lambda: self.defer(lambda: self.acc_release(ids)))
-            self.queue_next_group_inputs()
+            self.queue_inputs_late()
+            self.acc_release([self.g2_acc])         # g is dead: every MFMA of the rgb / sigma unit has been issued
+            self.g2_acc = None
         else:
-            inst = l["name"] == "inst1"
-            ids = list(u["accs"].values())
-            for t in range(2):
-                self.q(66, (lambda t=t: self.lwr_build(t)))
-                for bi, blk in enumerate(u["blocks"]):
-                    self.q(32, self.logits_epilogue(t, self.acc_reg(u["accs"][(bi, t)]), blk, inst))
-            self.q(0, lambda: self.defer(lambda: self.acc_release(ids)))
+            # logit blocks keep their accumulators until the group's tail (tail_logits): all blocks of a tile are reduced TOGETHER there,
+            # three independent FMA chains beside each other -- one block at a time is a chain of 16 dependent FMAs and two LDS
+            # round trips with nothing to overlap them (the first version's tail: 2650 cycles)
+            self.logit_units.append(u)
         # ---- chunk hand-over
         if u["last_of_chunk"]:
             c2 = (u["chunk"] + 2) % self.NC
-            self.wait_vm(self.piece_tag.get(c2))
-            e("s_barrier")
+            if not self.abl & 2:
+                self.wait_vm(self.piece_tag.get(c2))
+                e("s_barrier")
+
+    def logit_blocks(self):
+        return [(b, False) for b in range(self.nbs)] + [(0, True)] * self.nbi
+
+    def tail_logits(self):
+        """the group's logit blocks -> record columns (fuse_logits_t).  Both tiles pipelined: lwr of tile 0 and tile 1 (the fragment
+        ring is idle at a group's end: its registers hold tile 1's), tile 0's FMAs -- every block's chain side by side --, its
+        exchanges between the half-waves, tile 1's FMAs beside them, then the stores.  Masks and the instance columns' pointers are
+        precomputed (S_MSK, S_REC_I)."""
+        e = self.e
+        blocks = []
+        for u in self.logit_units:
+            inst = self.layers[u["layer"]]["name"] == "inst1"
+            for bi, blk in enumerate(u["blocks"]):
+                blocks.append((u, bi, blk, inst))
+        nb = len(blocks)
+        lwr = (V_TMP, V_RING)
+        sums = ([V_PTMP + k for k in range(nb)], [V_IN + 1 + k for k in range(nb)])
+        oth = ([V_PTMP + 3 + k for k in range(nb)], [V_IN + 4, V_IN + 5, V_IN + 9][:nb])
+        adr = V_PTMP + 7
+        S_LW = S_REC_I + 4                              # 16 SGPRs: the local weights of eight sample-row pairs
+        for t in range(2):
+            # lwr[r] = lw[row(r, 0) + 4 hi], row(r, 0) = (r & 3) + 8 (r >> 2): in two halves of eight registers (16 v_readlane each:
+            # VALU only -- 32 ds_bpermute_b32 measured ~35 cycles each here, where nothing overlaps them)
+            for half in range(2):
+                rows = [(r & 3) + 8 * (r >> 2) for r in range(8 * half, 8 * half + 8)]
+                for i, row in enumerate(rows):
+                    e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i, V_LW + t, row))
+                    e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i + 1, V_LW + t, row + 4))
+                for i in range(8):
+                    e("v_mov_b32 v%d, s%d" % (lwr[t] + 8 * half + i, S_LW + 2 * i + 1))
+                e("s_mov_b64 exec, s[%d:%d]" % (S_HI0, S_HI0 + 1))
+                for i in range(8):
+                    e("v_mov_b32 v%d, s%d" % (lwr[t] + 8 * half + i, S_LW + 2 * i))
+                e("s_mov_b64 exec, -1")
+        tag_lwr = [None, None]
+        e("v_xor_b32 v%d, 32, v%d" % (adr, V_TID))
+        e("v_and_b32 v%d, 63, v%d" % (adr, adr))
+        e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
+        tags = [None, None]
+
+        def fmas(t):
+            self.wait_lgkm(tag_lwr[t])
+            for r in range(16):
+                for k, (u, bi, blk, inst) in enumerate(blocks):
+                    a = self.acc_reg(u["accs"][(bi, t)])
+                    if r == 0:
+                        e("v_fma_f32 v%d, v%d, v%d, 0" % (sums[t][k], lwr[t], a))
+                    else:
+                        e("v_fmac_f32 v%d, v%d, v%d" % (sums[t][k], lwr[t] + r, a + r))
+            tags[t] = [self.lds_read("ds_bpermute_b32 v%d, v%d, v%d" % (oth[t][k], adr, sums[t][k])) for k in range(nb)]
+
+        def stores(t):
+            for k in range(nb):                     # the sums under the FULL exec mask, then the masked stores
+                self.wait_lgkm(tags[t][k])
+                e("v_add_f32 v%d, v%d, v%d" % (oth[t][k], sums[t][k], oth[t][k]))
+            for k, (u, bi, blk, inst) in enumerate(blocks):
+                e("s_mov_b64 exec, s[%d:%d]" % (S_MSK + 2 * k, S_MSK + 2 * k + 1))
+                base = (S_REC_I if inst else S_REC_T) + 2 * t
+                self.vm_op("global_store_dword v%d, v%d, s[%d:%d] offset:%d%s" % (V_LB4, oth[t][k], base, base + 1, 4 + 128 * blk, STORE_NT))
+            e("s_mov_b64 exec, -1")
+        fmas(0)
+        self.stamp(len(self.units) + 4)
+        fmas(1)
+        self.stamp(len(self.units) + 5)
+        stores(0)
+        stores(1)
+        for u in self.logit_units:
+            self.acc_release(list(u["accs"].values()))
+        self.logit_units = []
 
     def lwr_build(self, t):
-        """lwr[r] of tile t -> v[V_TMP + r]: 32 readlanes, then two moves per register (full exec: the hi = 1 value; lanes 0..31: hi = 0)"""
-        e = self.e
-        self.lwr_load(t)
+        """lwr[r] of tile t -> v[V_TMP + r] = lw[row(r, 0) + 4 hi]: sixteen ds_bpermute_b32 (address = hi * 16 + 4 row(r, 0)); the 32
+        v_readlane + 32 v_mov of the first version were a fifth of the heads' side work"""
         for r in range(16):
-            e("v_mov_b32 v%d, s%d" % (V_TMP + r, S_W + (r & 3) + 8 * (r >> 2) + 4))
-        with self.atomic():
-            e("s_mov_b64 exec, s[%d:%d]" % (S_HI0, S_HI0 + 1))
-            for r in range(16):
-                e("v_mov_b32 v%d, s%d" % (V_TMP + r, S_W + (r & 3) + 8 * (r >> 2)))
-            e("s_mov_b64 exec, -1")
+            self.lwr_tag = self.lds_read("ds_bpermute_b32 v%d, v%d, v%d offset:%d" % (V_TMP + r, V_BIAS, V_LW + t, 4 * ((r & 3) + 8 * (r >> 2))))
 
-    def queue_next_group_inputs(self):
-        """side work: the next group's inputs, encodings, |d| (V_IN, V_EX, V_ED)"""
+    def queue_inputs_early(self):
+        """side work from the first unit behind the skip layer on (gamma(x) of this group is dead): the next group's inputs, its
+        point, |d|, gamma(x) and q = d / |d|.  Temporaries and inputs live in the g area (free until views' first pack)."""
         def which():
             # g2 = grp + n_wg < n_groups ? grp + n_wg : grp
             with self.atomic():
@@ -969,16 +1119,64 @@ class Gen:
             self.q(34, (lambda t=t: tags.__setitem__(t, self.fetch_tile(t, S_GRP2))))
         for t in range(2):
             self.q(1, (lambda t=t: self.wait_vm(tags[t])))      # (deferred: the holder is filled when the load is emitted)
-            for cost, fn in self.encode_tile(t, None):
+            for cost, fn in self.encode_tile(t, "x"):
                 self.q(cost, fn)
+
+    PARK = (3, 4, 5, 6, 7, 0)       # what of V_IN outlives gamma(x): q (3), z, z_next, |d|
+
+    def park(self):
+        """views' packs of tile 1 land on V_IN: its six live values per tile wait in an idle accumulator until the rgb / sigma unit"""
+        self.park_acc = self.acc_take(1)[0]
+        for t in range(2):
+            for i, k in enumerate(Gen.PARK):
+                self.e("v_mov_b32 v%d, v%d" % (self.acc_reg(self.park_acc) + 6 * t + i, V_IN + 8 * t + k))
+
+    def unpark(self):
+        for t in range(2):
+            for i, k in enumerate(Gen.PARK):
+                self.e("v_mov_b32 v%d, v%d" % (V_IN + 8 * t + k, self.acc_reg(self.park_acc) + 6 * t + i))
+        self.acc_release([self.park_acc])
+        self.park_acc = None
+
+    def queue_inputs_late(self):
+        """behind the rgb / sigma unit (gamma(d) of this group is dead): gamma(d) of the next group"""
+        for t in range(2):
+            for cost, fn in self.encode_tile(t, "d"):
+                self.q(cost, fn, low=True)
+
+    # ------------------------------------------------------------------ trace builds (k_mlp_tt_*_trace): s_memtime per unit
+    def stamp(self, idx):
+        """lane idx of v13 := low word of s_memtime here (written one stamp later: the scalar load has returned by then); the
+        clock output of a trace build is the 64 stamps of workgroup 0's first wave in its LAST group"""
+        if not self.trace:
+            return
+        pair = S_CLK0 + 2 * (self.nstamp & 1)
+        prev = S_CLK0 + 2 * ((self.nstamp + 1) & 1)
+        if self.last_stamp is not None:
+            self.o.append("\tv_writelane_b32 v%d, s%d, %d" % (V_TRACE, prev, self.last_stamp))
+        self.o.append("\ts_memtime s[%d:%d]" % (pair, pair + 1))
+        self.last_stamp = idx
+        self.nstamp += 1
+        if idx == len(self.units) + 3:
+            # the group's end also goes to lane 56 + (group counter & 7): the durations of the last eight groups
+            skip = self.label()
+            self.o += ["\ts_waitcnt lgkmcnt(0)", "\ts_and_b32 s%d, s101, 7" % S_T0, "\ts_add_u32 s%d, s%d, 56" % (S_T0, S_T0),
+                       "\ts_mov_b32 m0, s%d" % S_T0, "\ts_nop 1",
+                       "\tv_writelane_b32 v%d, s%d, m0" % (V_TRACE, pair),
+                       # every 32nd group's end (groups 0, 32, .., 160) to lanes 48..53: the average group time per window
+                       "\ts_and_b32 s%d, s101, 31" % S_T0, "\ts_cmp_eq_u32 s%d, 0" % S_T0, "\ts_cbranch_scc0 %s" % skip,
+                       "\ts_lshr_b32 s%d, s101, 5" % S_T0, "\ts_add_u32 s%d, s%d, 48" % (S_T0, S_T0), "\ts_mov_b32 m0, s%d" % S_T0,
+                       "\ts_nop 1", "\tv_writelane_b32 v%d, s%d, m0" % (V_TRACE, pair), skip + ":",
+                       "\ts_add_u32 s101, s101, 1"]
 
     # ------------------------------------------------------------------ group boundary
     def prefetch_first_unit(self):
         """bias of unit 0 into fresh accumulators + the ring's first three fragments (the only LGKM operations in flight at a
         group's start)"""
         u0 = self.units[0]
-        for op in self.arm_ops(u0):
-            op()
+        for plan in self.arm_plan(u0):
+            for op in plan:
+                op()
         for g in range(P - 1):
             sl, of = self.stream[g]
             self.ring_tags[g % P] = self.lds_read("ds_read_b128 %s, v%d offset:%d" % (vr(V_RING + 4 * (g % P), 4), V_FRAG + sl, of))
@@ -995,14 +1193,23 @@ class Gen:
             e("s_mov_b64 s[%d:%d], s[%d:%d]" % (S_LAST + 2 * t, S_LAST + 2 * t + 1, S_NLAST + 2 * t, S_NLAST + 2 * t + 1))
 
     def group_body(self):
+        self.m0 = None
         assert self.acc_free == [i for i in range(8) if i not in self.units[0]["accs"].values()], self.acc_free
+        self.last_stamp = None
         for ui in range(len(self.units)):
             self.emit_unit(ui)
-        self.drain_side()                               # whatever the last units could not cover (the last logit block's reduction)
+        self.stamp(len(self.units))
+        self.drain_side()                               # whatever the last units could not cover
+        self.tail_logits()
+        self.stamp(len(self.units) + 1)
         assert self.acc_free == list(range(8)), self.acc_free
         self.e("s_waitcnt lgkmcnt(0)")
         self.lgkm.drain()
         self.advance_group_state()
+        self.stamp(len(self.units) + 2)
+        if self.trace:
+            self.o.append("\ts_waitcnt lgkmcnt(0)")
+            self.stamp(len(self.units) + 3)
 
     # ------------------------------------------------------------------ the kernel
     def kernel(self):
@@ -1016,19 +1223,22 @@ class Gen:
         e("v_readfirstlane_b32 s%d, v0" % S_WAVE)
         e("s_nop 4")
         e("s_lshr_b32 s%d, s%d, 6" % (S_WAVE, S_WAVE))
-        e("s_lshl_b32 s%d, s%d, 10" % (S_W1K, S_WAVE))
+        e("s_lshl_b32 s%d, s%d, 12" % (S_W4K, S_WAVE))                    # wave * 4 KiB
         e("v_and_b32 v%d, 63, v0" % V_T0)
         e("v_lshlrev_b32 v%d, 4, v%d" % (V_LANE16, V_T0))
-        e("v_lshrrev_b32 v%d, 5, v0" % V_T1)
-        e("v_and_b32 v%d, 1, v%d" % (V_T1, V_T1))
-        e("v_lshlrev_b32 v%d, 4, v%d" % (V_T1, V_T1))                    # hi * 16
+        e("v_lshrrev_b32 v%d, 5, v0" % V_LB4)
+        e("v_and_b32 v%d, 1, v%d" % (V_LB4, V_LB4))
+        e("v_lshlrev_b32 v%d, 4, v%d" % (V_LB4, V_LB4))                  # hi * 16
         for sl in range(NSLOT):
             self.lit(S_T0, sl * SLOT)
             e("v_add_u32 v%d, s%d, v%d" % (V_FRAG + sl, S_T0, V_LANE16))
-            e("v_add_u32 v%d, s%d, v%d" % (V_BIAS + sl, S_T0, V_T1))
+            e("v_add_u32 v%d, s%d, v%d" % (V_BIAS + sl, S_T0, V_LB4))
+        for k in range(3):
+            e("v_add_u32 v%d, s%d, v%d" % (V_DMA + k, S_W4K, V_LANE16))
+            if k:
+                e("v_add_u32 v%d, 0x%x, v%d" % (V_DMA + k, 16384 * k, V_DMA + k))
         e("v_and_b32 v%d, 31, v0" % V_LB4)
         e("v_lshlrev_b32 v%d, 2, v%d" % (V_LB4, V_LB4))
-        e("v_mov_b32 v%d, 0" % V_ZERO)
         e("s_mov_b32 s%d, -1" % S_LO32)
         e("s_mov_b32 s%d, 0" % (S_LO32 + 1))
         e("s_mov_b32 s%d, 1" % S_N0)
@@ -1036,14 +1246,20 @@ class Gen:
         e("s_mov_b32 s%d, -1" % S_HI0)
         e("s_mov_b32 s%d, 0" % (S_HI0 + 1))
         e("s_waitcnt lgkmcnt(0)")
-        e("s_add_u32 s%d, s%d, s%d" % (S_IMGW, S_IMG, S_W1K))
-        e("s_addc_u32 s%d, s%d, 0" % (S_IMGW + 1, S_IMG + 1))
+        # store masks of the logit blocks (constant): channel = 32 blk + (lane & 31) < n_out, lanes 0..31 only
+        for k, (blk, inst) in enumerate(self.logit_blocks()):
+            e("v_and_b32 v%d, 31, v0" % V_T0)
+            if blk:
+                e("v_add_u32 v%d, %d, v%d" % (V_T0, 32 * blk, V_T0))
+            e("v_cmp_gt_i32 vcc, s%d, v%d" % (S_NINST if inst else S_NSEM, V_T0))
+            e("s_and_b64 s[%d:%d], vcc, s[%d:%d]" % (S_MSK + 2 * k, S_MSK + 2 * k + 1, S_HI0, S_HI0 + 1))
         lend, lloop, lfin = self.label(), self.label(), self.label()
         e("s_mov_b32 s%d, s2" % S_GRP)
         e("s_cmp_ge_i32 s%d, s%d" % (S_GRP, S_NGRP))
         e("s_cbranch_scc1 %s" % lend)
         # chunks 0, 1, 2 -> slots 0, 1, 2
         for c in range(3):
+            self.chunk_base(c)
             for j in range(self.pieces_of(c)):
                 self.piece_tag[c] = self.piece(c, j)
         e("s_waitcnt vmcnt(0)")
@@ -1054,11 +1270,18 @@ class Gen:
         tags = [self.fetch_tile(t, S_GRP2) for t in range(2)]
         for t in range(2):
             self.wait_vm(tags[t])
-            for _, fn in self.encode_tile(t, None):
-                fn()
+            for part in ("x", "d"):
+                for _, fn in self.encode_tile(t, part):
+                    fn()
         self.advance_group_state()
-        e("s_memtime s[%d:%d]" % (S_CLK0, S_CLK0 + 1))
-        e("s_memrealtime s[%d:%d]" % (S_CLK0 + 2, S_CLK0 + 3))
+        if not self.trace:
+            e("s_memtime s[%d:%d]" % (S_CLK0, S_CLK0 + 1))
+            e("s_memrealtime s[%d:%d]" % (S_CLK0 + 2, S_CLK0 + 3))
+        else:
+            e("v_mov_b32 v%d, 0" % V_TRACE)
+            e("s_mov_b32 s101, 0")
+            e("s_memtime s[90:91]")                                  # the workgroup's start
+            e("s_waitcnt lgkmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
         self.lgkm.drain()
         self.prefetch_first_unit()
@@ -1080,8 +1303,32 @@ class Gen:
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_cmp_eq_u64 s[%d:%d], 0" % (S_CLK, S_CLK + 1))
         e("s_cbranch_scc1 %s" % lfin)
+        if self.trace:              # every workgroup: cycles of its first wave from start to end -> clk[64 + workgroup]
+            lw = self.label()
+            e("s_cmp_lg_u32 s%d, 0" % S_WAVE)
+            e("s_cbranch_scc1 %s" % lw)
+            e("s_memtime s[%d:%d]" % (S_CLK0, S_CLK0 + 1))
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_sub_u32 s%d, s%d, s90" % (S_CLK0, S_CLK0))
+            e("s_lshl_b32 s%d, s2, 2" % S_T0)
+            e("s_add_u32 s%d, s%d, 256" % (S_T0, S_T0))
+            e("v_mov_b32 v%d, s%d" % (V_T0, S_T0))
+            e("v_mov_b32 v%d, s%d" % (V_T1, S_CLK0))
+            e("s_mov_b64 exec, 1")
+            e("global_store_dword v%d, v%d, s[%d:%d]" % (V_T0, V_T1, S_CLK, S_CLK + 1))
+            e("s_mov_b64 exec, -1")
+            e("s_waitcnt vmcnt(0)")
+            self.o.append(lw + ":")
         e("s_cmp_lg_u32 s2, 0")
         e("s_cbranch_scc1 %s" % lfin)
+        if self.trace:
+            e("s_cmp_lg_u32 s%d, 0" % S_WAVE)
+            e("s_cbranch_scc1 %s" % lfin)
+            e("v_and_b32 v%d, 63, v0" % V_T0)
+            e("v_lshlrev_b32 v%d, 2, v%d" % (V_T0, V_T0))
+            e("global_store_dword v%d, v%d, s[%d:%d]" % (V_T0, V_TRACE, S_CLK, S_CLK + 1))
+            e("s_waitcnt vmcnt(0)")
+            e("s_branch %s" % lfin)
         e("s_memtime s[%d:%d]" % (S_T0 - 0, S_T0 + 1))
         e("s_memrealtime s[%d:%d]" % (S_SAVE, S_SAVE + 1))
         e("s_waitcnt lgkmcnt(0)")
@@ -1096,8 +1343,8 @@ class Gen:
         e("v_mov_b32 v21, s%d" % S_T1)
         e("v_mov_b32 v22, s%d" % S_SAVE)
         e("v_mov_b32 v23, s%d" % (S_SAVE + 1))
-        e("v_mov_b32 v%d, 0" % V_ZERO)
-        e("global_store_dwordx4 v%d, v[20:23], s[%d:%d]" % (V_ZERO, S_CLK, S_CLK + 1))
+        e("v_mov_b32 v%d, 0" % V_T0)
+        e("global_store_dwordx4 v%d, v[20:23], s[%d:%d]" % (V_T0, S_CLK, S_CLK + 1))
         e("s_waitcnt vmcnt(0)")
         self.o.append(lfin + ":")
         e("s_endpgm")
@@ -1137,6 +1384,15 @@ def main():
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())
+    names.append("k_mlp_tt_s2i1_trace")         # debug: per-unit s_memtime stamps instead of the clock pair (tools/tt_trace.py)
+    parts.append(Gen(2, 1, "k_mlp_tt_s2i1_trace", trace=True).kernel())
+    if len(sys.argv) > 3:                       # timing-only ablations of the trace build (results invalid)
+        for abl in (1, 2, 3, 4, 7):
+            names.append("k_mlp_tt_s2i1_trace_a%d" % abl)
+            parts.append(Gen(2, 1, names[-1], trace=True, abl=abl).kernel())
+    unit_names = ["%s %s" % (g.layers[u["layer"]]["name"], u["blocks"]) for g in [Gen(2, 1, "x")] for u in g.units]
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write("\n".join(unit_names) + "\n")
     parts.append(metadata(names))
     with open(out, "w") as f:
         f.write("\n".join(parts))

@@ -978,7 +978,9 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
         memset(&t, 0, sizeof(t));
         t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
         t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
-        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st);
+        const int dbg = desc->reserved[0];          // 0x7A: the trace build; 0x100 + a: its timing-only ablation a (tools/tt_trace.py)
+        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st, dbg == 0x7A || (dbg & ~7) == 0x100,
+                                 (dbg & ~7) == 0x100 ? (dbg & 7) : 0);
     }
     if (desc->plan == 1) {
         const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;

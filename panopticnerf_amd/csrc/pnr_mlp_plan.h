@@ -4,9 +4,8 @@
 //   plan 0 (classic):          trunk 0..D-1 | feature | views | rgb+sigma | [sem0, sem1] | [inst0, inst1]
 //   plan 1 (fused inference):  trunk 0..D-1 | feature | views | rgb+sigma | [sem0] | [inst0] | logits = {sem1, inst1} in ONE chunk;
 //                              layer 0 is one chunk of all W/32 blocks (32 MFMAs) instead of two of 16
-//   plan 2 (two-tile kernel, csrc/asm/gen_mlp_tt.py): plan 0's order (sem0 | sem1 | inst0 | inst1: sem1's reduction hides under
-//                              inst0's MFMAs) with layer 0, sem1 and inst1 as ONE chunk EACH (all blocks of the layer), and no
-//                              chunk above 33 fragments -- a layer whose 2-block chunk would be larger (the layer behind
+//   plan 2 (two-tile kernel, csrc/asm/gen_mlp_tt.py): plan 1's order (sem0 | inst0 | sem1 | inst1) with layer 0, sem1 and inst1
+//                              as ONE chunk EACH (all blocks of the layer), and no chunk above 33 fragments -- a layer whose 2-block chunk would be larger (the layer behind
 //                              the skip: 2 x 20 + 1, views: 2 x 18 + 1) is cut into 1-block chunks -- so that FOUR weight slots fit
 //                              the LDS; the number of chunks is then a multiple of 4 (slot = chunk % 4 is static)
 #pragma once
@@ -85,6 +84,11 @@ static inline void pnr_build_plan(const pnr_mlp_desc& d, PnrPlan& plan)
         if (d.n_inst) add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
         add(PNR_L_LOGITS, nbs, (nbs + nbi) * 32, PNR_SEG_FEAT, d.head_W);
         plan.layers.back().fbc = nbs + nbi;         // every logit block in one chunk
+    } else if (d.plan == 2) {
+        if (d.n_sem) add(PNR_L_SEM0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        if (d.n_inst) add(PNR_L_INST0, 0, d.head_W, PNR_SEG_FEAT, d.W);
+        if (d.n_sem) add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.head_W);
+        if (d.n_inst) add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.head_W);
     } else if (pnr_head_depth(d) == 1) {      // one Linear per head, straight from the tap (W inputs)
         if (d.n_sem) add(PNR_L_SEM1, 0, d.n_sem, PNR_SEG_FEAT, d.W);
         if (d.n_inst) add(PNR_L_INST1, 0, d.n_inst, PNR_SEG_FEAT, d.W);

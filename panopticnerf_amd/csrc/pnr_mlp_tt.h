@@ -19,4 +19,5 @@ struct PnrTTArgs {
 };
 static_assert(sizeof(PnrTTArgs) == 88, "k_mlp_tt reads its arguments at fixed offsets");
 
-int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream);
+// trace: the debug build of the kernel (per-unit s_memtime stamps of workgroup 0's first wave to `clk`, 256 bytes; tools/tt_trace.py)
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace = false, int trace_abl = 0);
