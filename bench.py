@@ -594,7 +594,8 @@ def main():
             flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-            kname = ("k_mlp_pp<fused compositing epilogue, plan %d>" % fdesc.plan if fused else
+            kname = ("k_mlp_tt<two-tile assembly, fused compositing epilogue, plan 2>" if fused and fdesc.plan == 2 else
+                     "k_mlp_pp<fused compositing epilogue, plan %d>" % fdesc.plan if fused else
                      "k_mlp_pp" if (ops.default_schedule() != 1 and args.precision == "bf16") else "k_mlp_fused")
             tkey = "k_mlp_pp_fused" if fused else "k_mlp_pp"
             roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),

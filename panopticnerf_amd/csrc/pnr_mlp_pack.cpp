@@ -11,6 +11,7 @@
 #include "pnr_common.h"
 #include "pnr_mlp_layout.h"
 #include "pnr_mlp_plan.h"
+#include "pnr_mlp_tt.h"
 
 int pnr_mlp_validate(const pnr_mlp_desc* d)
 {
@@ -329,6 +330,10 @@ PNR_EXPORT int pnr_mlp_pack_device(const pnr_mlp_desc* desc, const pnr_mlp_param
                                    void* workspace, void* packed, void* stream)
 {
     PNR_REQUIRE(workspace && packed, "pnr_mlp_pack_device: null pointer");
+    if (desc && !backward && desc->plan == 2) {      // the two-tile kernel's code object: loaded here, outside any stream capture
+        int rc0 = pnr_mlp_tt_prepare();
+        if (rc0 != PNR_OK) return rc0;
+    }
     Image im;
     int rc = describe(desc, params_dev, backward, im);
     if (rc != PNR_OK) return rc;

@@ -23,44 +23,56 @@ DevTable g_tab[64];
 std::mutex g_mu;
 }   // namespace
 
+static int tt_table(DevTable*& out)
+{
+    int dev = 0;
+    PNR_HIP(hipGetDevice(&dev));
+    PNR_REQUIRE(dev >= 0 && dev < 64, "pnr_mlp_tt: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevTable& t = g_tab[dev];
+    if (!t.tried) {
+        t.tried = true;
+        hipError_t e = hipModuleLoadData(&t.mod, k_co);
+        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[1][1], t.mod, "k_mlp_tt_s1i1");
+        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[2][1], t.mod, "k_mlp_tt_s2i1");
+        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn_trace[0], t.mod, "k_mlp_tt_s2i1_trace");
+        for (int a = 1; a < 8 && e == hipSuccess; ++a) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "k_mlp_tt_s2i1_trace_a%d", a);
+            if (hipModuleGetFunction(&t.fn_trace[a], t.mod, nm) != hipSuccess) { t.fn_trace[a] = nullptr; (void)hipGetLastError(); }
+        }
+        if (e != hipSuccess) {
+            pnr_set_error("pnr_mlp_tt: loading the two-tile code object failed: %s (the first call on a device must not be inside a "
+                          "stream capture)", hipGetErrorString(e));
+            t.tried = false;        // let the next call (outside a capture) try again
+            return PNR_EHIP;
+        }
+        t.ok = true;
+    }
+    PNR_REQUIRE(t.ok, "pnr_mlp_tt: the two-tile code object is not loaded");
+    out = &t;
+    return PNR_OK;
+}
+
+int pnr_mlp_tt_prepare(void)
+{
+    DevTable* t = nullptr;
+    return tt_table(t);
+}
+
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace, int trace_abl)
 {
     PNR_REQUIRE(nbs >= 1 && nbs <= 2 && nbi == 1, "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
                 "render in chunks", a.S);
-    int dev = 0;
-    PNR_HIP(hipGetDevice(&dev));
-    PNR_REQUIRE(dev >= 0 && dev < 64, "pnr_mlp_tt: device index %d out of range", dev);
-    hipFunction_t fn = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        DevTable& t = g_tab[dev];
-        if (!t.tried) {
-            t.tried = true;
-            hipError_t e = hipModuleLoadData(&t.mod, k_co);
-            if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[1][1], t.mod, "k_mlp_tt_s1i1");
-            if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[2][1], t.mod, "k_mlp_tt_s2i1");
-            if (e == hipSuccess) e = hipModuleGetFunction(&t.fn_trace[0], t.mod, "k_mlp_tt_s2i1_trace");
-            for (int a = 1; a < 8 && e == hipSuccess; ++a) {
-                char nm[64];
-                snprintf(nm, sizeof(nm), "k_mlp_tt_s2i1_trace_a%d", a);
-                if (hipModuleGetFunction(&t.fn_trace[a], t.mod, nm) != hipSuccess) { t.fn_trace[a] = nullptr; (void)hipGetLastError(); }
-            }
-            if (e != hipSuccess) {
-                pnr_set_error("pnr_mlp_tt: loading the two-tile code object failed: %s (the first call on a device must not be inside a "
-                              "stream capture)", hipGetErrorString(e));
-                t.tried = false;        // let the next call (outside a capture) try again
-                return PNR_EHIP;
-            }
-            t.ok = true;
-        }
-        PNR_REQUIRE(t.ok, "pnr_mlp_tt: the two-tile code object is not loaded");
-        fn = t.fn[nbs][nbi];
-        if (trace) {
-            PNR_REQUIRE(nbs == 2 && nbi == 1 && a.clk, "pnr_mlp_tt: the trace build exists for 2 + 1 logit blocks and needs the clock buffer");
-            fn = t.fn_trace[trace_abl & 7];
-            PNR_REQUIRE(fn, "pnr_mlp_tt: ablation %d of the trace build is not in this library (make EXTRA_TT=abl)", trace_abl & 7);
-        }
+    DevTable* t = nullptr;
+    int rc = tt_table(t);
+    if (rc != PNR_OK) return rc;
+    hipFunction_t fn = t->fn[nbs][nbi];
+    if (trace) {
+        PNR_REQUIRE(nbs == 2 && nbi == 1 && a.clk, "pnr_mlp_tt: the trace build exists for 2 + 1 logit blocks and needs the clock buffer");
+        fn = t->fn_trace[trace_abl & 7];
+        PNR_REQUIRE(fn, "pnr_mlp_tt: ablation %d of the trace build is not in this library (make EXTRA_TT=abl)", trace_abl & 7);
     }
     PnrTTArgs ka = a;
     const int cus = pnr_cu_count();

@@ -20,4 +20,6 @@ struct PnrTTArgs {
 static_assert(sizeof(PnrTTArgs) == 88, "k_mlp_tt reads its arguments at fixed offsets");
 
 // trace: the debug build of the kernel (per-unit s_memtime stamps of workgroup 0's first wave to `clk`, 256 bytes; tools/tt_trace.py)
+// load the code object on the current device if that has not happened yet (not capturable: called from the device packer)
+int pnr_mlp_tt_prepare(void);
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace = false, int trace_abl = 0);

@@ -504,6 +504,79 @@ def test_fused_inference_plan_equals_classic_plan_bit_for_bit(dev, R, N, heads, 
             ops.mlp_forward(d1, img1, rays, z, channel_major=True)
 
 
+def _tiles_workspace(desc, img, rays, z):
+    """pnr_mlp_forward_tiles into a 0xAB-filled workspace: (records (tiles, rec_floats), quadruples (S, 4))"""
+    import ctypes
+    from panopticnerf_amd import _lib
+    lib = _lib.load()
+    R, N = z.shape
+    S = R * N
+    nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, 0)
+    ws = torch.full((int(nbytes),), 0xAB, device=z.device, dtype=torch.uint8)
+    _lib.check(lib.pnr_mlp_forward_tiles(ctypes.byref(desc), ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(rays.data_ptr()),
+                                         ctypes.c_void_p(z.data_ptr()), R, N, ctypes.c_void_p(ws.data_ptr()),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pnr_mlp_forward_tiles")
+    rf = (1 + desc.n_sem + desc.n_inst + 3) & ~3
+    pad = (S + 255) // 256 * 8
+    rec = ws[: pad * rf * 4].view(torch.float32).reshape(pad, rf)[: (S + 31) // 32, : 1 + desc.n_sem + desc.n_inst]
+    ps = ws[pad * rf * 4: pad * rf * 4 + S * 16].view(torch.float32).reshape(S, 4)
+    return rec.clone(), ps.clone()
+
+
+@pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 1)])
+@pytest.mark.parametrize("R,N", [(300, 192), (37, 96), (1001, 64), (7, 32), (256, 256), (2051, 32)])
+def test_two_tile_assembly_kernel_equals_pingpong_bit_for_bit(dev, R, N, heads):
+    """k_mlp_tt (hand-placed gfx950 assembly, one wave per SIMD, two 32-sample tiles per wave, plan-2 image; csrc/asm/gen_mlp_tt.py)
+    against k_mlp_pp<fused, plan 1> on the same network, rays and z: the per-tile records (Q, every semantic and instance logit
+    sum) and the per-sample quadruples (lw, r, g, b) are the SAME BITS -- the arithmetic per value is operation for operation
+    the ping-pong kernel's.  One and two semantic logit blocks, ragged last groups, 1..8 tiles per ray, launches of one and of
+    several groups per workgroup; run twice (a second launch must not depend on what the first left in the LDS / registers)."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N + C)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d1, i1 = net.packed(1, dev, "bf16", fused=1)
+    d2, i2 = net.packed(1, dev, "bf16", fused=2)
+    assert d1.plan == 1 and d2.plan == 2
+    rec1, ps1 = _tiles_workspace(d1, i1, rays, z)
+    for rep in range(2):
+        rec2, ps2 = _tiles_workspace(d2, i2, rays, z)
+        assert torch.equal(rec1.view(torch.int32), rec2.view(torch.int32)), (rep, int((rec1.view(torch.int32) != rec2.view(torch.int32)).sum()))
+        assert torch.equal(ps1.view(torch.int32), ps2.view(torch.int32)), (rep, int((ps1.view(torch.int32) != ps2.view(torch.int32)).sum()))
+    # ... and through the whole fused call: every map
+    a = ops.mlp_forward_composite(d1, i1, rays, z, None, None, False, True)
+    b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_two_tile_kernel_is_the_default_where_it_exists_and_can_be_capped(dev, monkeypatch):
+    """The renderer's fused inference pass packs the BEST plan the geometry has (pnr_mlp_fused_plan: 2 = k_mlp_tt for the benched
+    network); PNR_FUSED_PLAN=1 (A/B runs) caps it at the ping-pong kernel's plan.  Same frame either way, bit for bit."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network, make_renderer
+    cfg = NS(N_samples=64, N_importance=128, num_classes=45, num_instances=32, precision="bf16", chunk_size=4096)
+    torch.manual_seed(11)
+    net = make_network(cfg).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[::517][:1000].contiguous().to(dev)
+    box, ids = synthetic.random_boxes(16, 45, 32)
+    batch = {"rays": rays[None], "bbox": box.to(dev), "bbox_ids": ids.to(dev)}
+    assert net.packed(1, dev, fused=True)[0].plan == 2
+    with torch.no_grad():
+        out2 = make_renderer(cfg, net).render(batch)
+        monkeypatch.setenv("PNR_FUSED_PLAN", "1")
+        net.invalidate_packed()
+        assert net.packed(1, dev, fused=True)[0].plan == 1
+        out1 = make_renderer(cfg, net).render(batch)
+    for k in out1:
+        assert torch.equal(out1[k], out2[k]), k
+
+
 def test_fused_path_is_what_the_renderer_runs_and_can_be_switched_off(dev):
     """Renderer.render (inference, bf16) takes the fused pass by default; cfg.fuse_composite = False keeps mlp_forward +
     composite.  Both give the same maps to fp32 rounding, identical z (the coarse weights feed sample_pdf: a weight that

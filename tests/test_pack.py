@@ -55,3 +55,30 @@ def test_pack_rejects_missing_parameters():
     net = make_network(NS(num_classes=0))
     with pytest.raises(RuntimeError, match="semantic"):
         ops.pack_mlp(desc, net.nerf_0.state_dict())
+
+
+def test_two_tile_plan_image_matches_the_assembly_generator():
+    """Plan 2 (the image k_mlp_tt consumes, csrc/asm/gen_mlp_tt.py): the generator carries its own copy of the chunk plan -- the chunk
+    table of the packed image must be exactly what the generated kernels assume (offsets, sizes), no chunk above 33 fragments
+    (four 33 KiB weight slots), a chunk count that is a multiple of 4 (slot = chunk % 4 is static); the geometry switch reports
+    plan 2 only where a kernel exists, and a plan-2 image renders the same dense network (numpy emulation)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_mlp_tt", os.path.join(root, "panopticnerf_amd", "csrc", "asm", "gen_mlp_tt.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    for C, K in ((45, 32), (19, 8)):
+        net = make_network(NS(num_classes=C, num_instances=K))
+        desc = ops.make_desc(n_sem=C, n_inst=K)
+        assert ops.fused_plan(desc, None) == 2 and ops.fused_plan(desc, 1) == 1
+        desc.plan = 2
+        img = ops.pack_mlp(desc, net.nerf_0.state_dict())
+        im = PackedImage(img)
+        g = G.Gen((C + 31) // 32, 1, "x")
+        assert im.n_chunks == g.NC and g.NC % 4 == 0 and im.max_frags <= 33
+        assert [(int(o), int(n)) for o, n in im.table] == [(c["off"], c["nfrag"]) for c in g.chunks]
+    # no instance head / other depths: no two-tile kernel -> plan 1 or 0
+    assert ops.fused_plan(ops.make_desc(n_sem=45, n_inst=0), None) == 1
+    assert ops.fused_plan(ops.make_desc(D=4, skip=1, n_sem=45, n_inst=32), None) == 1
+    assert ops.fused_plan(ops.make_desc(n_sem=100, n_inst=32), None) == 0
