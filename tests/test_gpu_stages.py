@@ -471,13 +471,14 @@ def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, he
     assert torch.equal(lean["rgb"], got["rgb"]) and torch.equal(lean["depth"], got["depth"])
 
 
-@pytest.mark.parametrize("heads,plan", [((45, 32), 1), ((45, 0), 1), ((19, 8), 1), ((4, 0), 1), ((0, 0), 0), ((100, 0), 0), ((19, 40), 0)])
+@pytest.mark.parametrize("heads,plan", [((45, 32), 2), ((45, 0), 1), ((19, 8), 2), ((4, 0), 1), ((0, 0), 0), ((100, 0), 0), ((19, 40), 0)])
 @pytest.mark.parametrize("R,N", [(510, 192), (129, 64)])
 def test_fused_inference_plan_equals_classic_plan_bit_for_bit(dev, R, N, heads, plan):
-    """Plan 1 (pnr_mlp_fused_plan: both head hidden layers first, then the semantic and instance logit layers as ONE chunk
-    of interleaved transposed blocks) is the same arithmetic per layer as the classic chunk order: every output of
-    pnr_mlp_forward_composite is bit-identical between the two images.  Geometries without a plan-1 kernel (no heads, more
-    than 2 + 1 logit blocks) report plan 0 and keep the classic order; the classic kernels refuse a plan-1 image."""
+    """The fused-inference plans (pnr_mlp_fused_plan: 1 = both head hidden layers first, then the semantic and instance logit
+    layers as ONE chunk of interleaved transposed blocks, k_mlp_pp; 2 = the two-tile assembly kernel k_mlp_tt's image, where the
+    geometry has one) are the same arithmetic per layer as the classic chunk order: every output of pnr_mlp_forward_composite is
+    bit-identical between the images.  Geometries without such a kernel (no heads, more than 2 + 1 logit blocks) report plan 0
+    and keep the classic order; the classic kernels refuse a plan-1 / plan-2 image."""
     from types import SimpleNamespace as NS
     from panopticnerf_amd import make_network
     C, K = heads
@@ -499,7 +500,8 @@ def test_fused_inference_plan_equals_classic_plan_bit_for_bit(dev, R, N, heads, 
     for k in a:
         assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
     if plan:
-        assert img1.numel() < img0.numel()          # one bias fragment for the merged chunk instead of one per logit block
+        if plan == 1:
+            assert img1.numel() < img0.numel()      # one bias fragment for the merged chunk instead of one per logit block
         with pytest.raises(RuntimeError, match="pnr_mlp_forward_composite only"):
             ops.mlp_forward(d1, img1, rays, z, channel_major=True)
 
