@@ -347,6 +347,8 @@ def main():
     ap.add_argument("--config", type=int, default=5, choices=[1, 2, 3, 4, 5], help="BASELINE.json configs[n-1]")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="headline form; default: strong with --gpus > 1, else weak")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--semantic-activation", default="logits", choices=["logits", "softmax"],
+                    help="what the learned semantic / instance fields composite (the reference's cfg.semantic_activation)")
     ap.add_argument("--chunk", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--cpu1-seconds", type=float, default=None,
@@ -411,7 +413,8 @@ def main():
             return out
     else:
         from panopticnerf_amd import benchlib, make_network, make_renderer, ops
-        cfg = synthetic.baseline_cfg(args.config, precision=args.precision, chunk_size=args.chunk, keep_weights=KEEP_W)
+        cfg = synthetic.baseline_cfg(args.config, precision=args.precision, chunk_size=args.chunk, keep_weights=KEEP_W,
+                                     semantic_activation=args.semantic_activation)
         torch.manual_seed(0)
         net = make_network(cfg).eval()
         synthetic.trained_like_(net)
@@ -574,7 +577,9 @@ def main():
             Rc = rc.shape[0]
             z = ops.stratified(rc, N_TOP)
             desc, img = net.packed(top, dev)
-            fdesc, fimg = net.packed(top, dev, fused=True)      # the image the fused pass consumes (its own chunk order)
+            # the image the fused pass consumes (its own chunk order), and the descriptor flag of its compositing mode
+            fdesc, fimg = net.packed(top, dev, fused=ops.fused_image(rend.sem_mode))
+            fdesc = ops.desc_for_mode(fdesc, rend.sem_mode)
             ch = 4 + N_SEM + N_INST
             raw = ops.alloc_raw(ch, Rc * N_TOP, dev)   # as Renderer allocates it
             ops.mlp_forward(desc, img, rc, z, out=raw)                       # fills raw for the compositing measurements below
@@ -595,7 +600,7 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
             kname = ("k_mlp_tt<two-tile assembly, fused compositing epilogue, plan 2>" if fused and fdesc.plan == 2 else
-                     "k_mlp_pp<fused compositing epilogue, plan %d>" % fdesc.plan if fused else
+                     "k_mlp_pp<fused %scompositing epilogue, plan %d>" % ("softmax " if rend.sem_mode == 1 else "", fdesc.plan) if fused else
                      "k_mlp_pp" if (ops.default_schedule() != 1 and args.precision == "bf16") else "k_mlp_fused")
             tkey = "k_mlp_pp_fused" if fused else "k_mlp_pp"
             roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
@@ -811,7 +816,8 @@ def main():
                                        % (c["name"], W_IMG, H_IMG, N_C, "+%d" % N_F if N_F else "", c["D"], c["W"], "s" if N_F else "",
                                           N_SEM, N_INST, "on" if c["bbox"] else "off"),
                            "baseline_config": args.config, "rays_per_frame": n_rays, "frames_per_step": frames_per_step,
-                           "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "keep_weights": KEEP_W, "parallelism": par},
+                           "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "keep_weights": KEEP_W,
+                           "semantic_activation": args.semantic_activation, "parallelism": par},
                 "scaling_modes": modes, "rccl": rccl,
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)

@@ -83,9 +83,16 @@ typedef struct pnr_mlp_desc {
                              the forward MLP kernels launched with this descriptor write {shader cycles, 100 MHz ticks} of
                              workgroup 0's first wave there (their ratio = the mean shader clock during the launch).  0 = off.
                              A descriptor field, not a setter: the library keeps no mutable state (round 5) */
-    int32_t reserved[1];  /* 0.  (0x7A with plan 2 and clk_probe set: the trace build of k_mlp_tt -- 64 per-unit s_memtime stamps of
-                             workgroup 0's first wave instead of the clock pair; tools/tt_trace.py) */
+    int32_t flags;     /* PNR_MLP_* bits, 0 by default */
 } pnr_mlp_desc;
+
+#define PNR_MLP_SOFTMAX 1      /* pnr_mlp_forward_composite / pnr_mlp_forward_tiles composite softmax(logits) over each learned field's
+                                  channels instead of the logits (the reference's semantic_activation = softmax; pnr_composite's
+                                  sem_mode 1).  Needs the plan-1 image (pnr_mlp_fused_plan >= 1 and pnr_mlp_desc.plan = 1): a head's
+                                  logit blocks must be in registers together; PNR_ERR_ARG otherwise */
+#define PNR_MLP_TRACE 0x7A00   /* diagnostics, with plan 2 and clk_probe set: the trace build of k_mlp_tt -- 64 per-unit s_memtime
+                                  stamps of workgroup 0's first wave instead of the clock pair; + a in 1..7: its timing-only
+                                  ablation a (tools/tt_trace.py) */
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
  * pts_w[i]/pts_b[i] for i < D.  Head pointers may be NULL when the head is absent; with head_depth = 1 a head is the single

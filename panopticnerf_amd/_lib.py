@@ -12,6 +12,7 @@ c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 
 PREC_BF16, PREC_FP32 = 0, 1
+MLP_SOFTMAX, MLP_TRACE = 1, 0x7A00        # pnr_mlp_desc.flags (include/pnr.h PNR_MLP_*)
 
 
 class LossCfg(ctypes.Structure):
@@ -27,7 +28,7 @@ class MlpDesc(ctypes.Structure):
                 ("xyz_L", ctypes.c_int32), ("dir_L", ctypes.c_int32),
                 ("n_sem", ctypes.c_int32), ("n_inst", ctypes.c_int32), ("head_W", ctypes.c_int32),
                 ("precision", ctypes.c_int32), ("plan", ctypes.c_int32), ("head_tap", ctypes.c_int32),
-                ("head_depth", ctypes.c_int32), ("schedule", ctypes.c_int32), ("clk_probe", ctypes.c_int32 * 2), ("reserved", ctypes.c_int32 * 1)]
+                ("head_depth", ctypes.c_int32), ("schedule", ctypes.c_int32), ("clk_probe", ctypes.c_int32 * 2), ("flags", ctypes.c_int32)]
 
 
 _fp = ctypes.POINTER(ctypes.c_float)

@@ -539,7 +539,7 @@ struct PPLogitsGeom {       // fragments of the chunk in consumption order i = k
     static constexpr int NF = FB * KS, BIAS_OFF = FB * KS * PNR_FRAG_BYTES;
     static constexpr int frag_off(int i) { return ((i % FB) * KS + (i / FB)) * PNR_FRAG_BYTES; }
 };
-template <int NBS, int NBI, class CTX>
+template <int NBS, int NBI, bool SOFTMAX, class CTX>
 __device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], const uint32_t (&shs)[32], const uint32_t (&shi)[32],
                                                  FuseState& st)
 {
@@ -562,6 +562,13 @@ __device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], con
         });
 #pragma unroll
         for (int b = 0; b < FB; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bj[b]));
+        if constexpr (SOFTMAX) {            // channels past the head's last: -inf (zero weights keep them there), exp() makes them 0
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int ch = (b < NBS ? b : b - NBS) * 32 + (c.lane & 31);
+                if (ch >= (b < NBS ? c.a.n_sem : c.a.n_inst)) bj[b] = -INFINITY;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < FB; ++b)
 #pragma unroll
@@ -595,6 +602,14 @@ __device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], con
 #endif
     c.m_done();
     c.refill_begin();
+    if constexpr (SOFTMAX) {            // a head's blocks together: the softmax runs over all of its channels
+        c.refill_one();
+        fuse_softmax_t<NBS>(st, c.hi, c.lane, c.a.n_sem, PNR_FUSE_REC_LOGITS, &acc[0]);
+        if constexpr (NBI > 0) {
+            c.refill_one();
+            fuse_softmax_t<NBI>(st, c.hi, c.lane, c.a.n_inst, PNR_FUSE_REC_LOGITS + c.a.n_sem, &acc[NBS]);
+        }
+    } else
     pp_static_for<FB>([&](auto B) {
         constexpr int b = B;
         c.refill_one();
@@ -605,7 +620,8 @@ __device__ __forceinline__ void pp_logits_merged(CTX& c, u32x4 (&A)[CTX::P], con
     c.advance();
 }
 
-// TAIL (FUSE only): 0 = classic plan (runtime loops over the logit blocks); 4 NBS + NBI = plan 1 with NBS semantic and NBI
+// TAIL (FUSE only): 0 = classic plan (runtime loops over the logit blocks); 4 NBS + NBI (+ 16: softmax compositing of the two
+// fields, pnr_mlp_fuse.h fuse_softmax_t) = plan 1 with NBS semantic and NBI
 // instance logit blocks merged into one chunk (pnr_mlp_plan.h)
 template <int W, bool TRAIN, bool FUSE = false, int TAIL = 0>
 __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
@@ -764,7 +780,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
         }
         if constexpr (TAIL > 0) {
             // plan 1: both head hidden layers, then every logit block in one chunk
-            constexpr int NBS = TAIL >> 2, NBI = TAIL & 3;
+            constexpr int NBS = (TAIL >> 2) & 3, NBI = TAIL & 3;
             uint32_t shs[GR], shi[GR];
             pp_layer_regs<CTX, PNR_L_SEM0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, shs, nullptr, srow);
             if constexpr (NBI > 0) pp_layer_regs<CTX, PNR_L_INST0, HR, 0, HFB, MODE_RELU, GR>(c, A, cur, dummy, shi, nullptr, srow);
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_pp(const MlpArgs a)
 #pragma unroll
                 for (int i = 0; i < GR; ++i) shi[i] = 0;
             }
-            pp_logits_merged<NBS, NBI>(c, A, shs, shi, fst);
+            pp_logits_merged<NBS, NBI, (TAIL >> 4) != 0>(c, A, shs, shi, fst);
         } else if (a.head_depth == 1) {     // one Linear per head, straight from the tap
             if (a.n_sem) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_sem, 4, samp, &fst);
             if (a.n_inst) pp_layer_out<TRAIN, FUSE, CTX, HR, 0>(c, A, cur, dummy, a.n_inst, 4 + a.n_sem, samp, &fst);
@@ -973,25 +989,31 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
     if (const char* e = getenv("PNR_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
     hipStream_t st = (hipStream_t)stream;
+    const bool softmax = (desc->flags & PNR_MLP_SOFTMAX) && desc->n_sem + desc->n_inst > 0;
     if (desc->plan == 2) {      // the two-tile assembly kernel (csrc/asm/gen_mlp_tt.py): same records, bit for bit
         PnrTTArgs t;
         memset(&t, 0, sizeof(t));
         t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
         t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
-        const int dbg = desc->reserved[0];          // 0x7A: the trace build; 0x100 + a: its timing-only ablation a (tools/tt_trace.py)
-        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st, dbg == 0x7A || (dbg & ~7) == 0x100,
-                                 (dbg & ~7) == 0x100 ? (dbg & 7) : 0);
+        PNR_REQUIRE(!softmax, "pnr_mlp_forward_composite: softmax compositing has no two-tile kernel; pack the plan-1 image");
+        const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + a in 1..7: the timing-only ablation a
+        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st, trace, trace ? (desc->flags & 7) : 0);
     }
     if (desc->plan == 1) {
         const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;
-        switch (4 * nbs + nbi) {
+        switch (4 * nbs + nbi + (softmax ? 16 : 0)) {
         case 4: return launch_mlp_pp<256, false, true, 4>(a, st);
         case 5: return launch_mlp_pp<256, false, true, 5>(a, st);
         case 8: return launch_mlp_pp<256, false, true, 8>(a, st);
         case 9: return launch_mlp_pp<256, false, true, 9>(a, st);
+        case 20: return launch_mlp_pp<256, false, true, 20>(a, st);
+        case 21: return launch_mlp_pp<256, false, true, 21>(a, st);
+        case 24: return launch_mlp_pp<256, false, true, 24>(a, st);
+        case 25: return launch_mlp_pp<256, false, true, 25>(a, st);
         default: PNR_REQUIRE(false, "pnr_mlp_forward_composite: no plan-1 kernel for %d + %d logit blocks", nbs, nbi);
         }
     }
+    PNR_REQUIRE(!softmax, "pnr_mlp_forward_composite: softmax compositing needs the plan-1 image (pnr_mlp_fused_plan >= 1, desc.plan = 1)");
     return desc->W == 256 ? launch_mlp_pp<256, false, true>(a, st) : launch_mlp_pp<128, false, true>(a, st);
 }
 

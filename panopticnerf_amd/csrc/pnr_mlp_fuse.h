@@ -107,3 +107,53 @@ __device__ __forceinline__ void fuse_logits_t(FuseState& st, int hi, int lane, i
     const int ch = fb * 32 + (lane & 31);
     if (hi == 0 && ch < n_out) st.rec[rec_base + ch] = s;
 }
+
+// semantic_activation = softmax (`k_composite` mode 1): the field is composited from softmax(logits) over its
+// channels instead of the logits.  NB transposed blocks of one head at once (lane = channel b*32 + (lane & 31), register r =
+// sample row(r, hi)): per sample register the max and the denominator are 32-lane butterflies inside the half-wave (four DPP
+// steps and one swizzle each), then s_c += lw_r / den_r * e_cr.  exp through v_exp_f32 on (x - max) log2(e) -- the rounding of
+// max * log2(e) is common to every channel of the sample and cancels in e / den.  The record keeps its layout (sums over the
+// tile's samples of lw * value): k_composite_combine is unchanged.
+// Channels past n_out arrive as -inf (pp_logits_merged starts their accumulators there; their weights are zero): exp gives 0.
+template <int NB>
+__device__ __forceinline__ void fuse_softmax_t(FuseState& st, int hi, int lane, int n_out, int rec_base, f32x16* acc)
+{
+    constexpr float L2E = 1.4426950408889634f;
+    // every butterfly step over the 16 sample registers at once (independent DPP operations back to back); the xor-16 step on the
+    // VALU as well (v_permlane16_swap): as ds_swizzle it was a serialised LDS-crossbar round trip per register, +9 % launch time
+    float m[16], d[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        m[r] = acc[0][r];
+#pragma unroll
+        for (int b = 1; b < NB; ++b) m[r] = max_raw(m[r], acc[b][r]);
+    }
+    group_max_batch<32, 16>(m);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float mm = -m[r] * L2E;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            acc[b][r] = __builtin_amdgcn_exp2f(fmaf(acc[b][r], L2E, mm));
+            d[r] = b ? d[r] + acc[b][r] : acc[b][r];
+        }
+    }
+    group_sum_batch<16, 16>(d);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = xor16_add_swap(d[r]);
+    float s[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float wr = st.lwr[r] * __builtin_amdgcn_rcpf(d[r]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s[b] = fmaf(wr, acc[b][r], s[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s[b] += __shfl_xor(s[b], 32, 64);
+        const int ch = b * 32 + (lane & 31);
+        if (hi == 0 && ch < n_out) st.rec[rec_base + ch] = s[b];
+    }
+}

@@ -433,17 +433,41 @@ def _maps(out, R, N, n_sem, n_inst, label_sem, label_inst, want_weights, dev):
 
 
 def fused_supported(desc, n_samples, sem_mode=0, noise=None):
-    """Can pnr_mlp_forward_composite take this level?  bf16, logits compositing, no sigma noise, N a multiple of 32."""
-    return (desc.precision == _lib.PREC_BF16 and int(sem_mode) == 0 and noise is None and n_samples % 32 == 0
-            and 32 <= n_samples <= 256 and desc.n_sem + desc.n_inst <= 128)
+    """Can pnr_mlp_forward_composite take this level?  bf16, no sigma noise, N a multiple of 32; softmax compositing
+    (sem_mode 1) where the geometry has the plan-1 kernel (a head's logit blocks in registers together), on the plan-1 image:
+    net.packed(level, device, fused=fused_image(sem_mode))."""
+    ok = (desc.precision == _lib.PREC_BF16 and int(sem_mode) in (0, 1) and noise is None and n_samples % 32 == 0
+          and 32 <= n_samples <= 256 and desc.n_sem + desc.n_inst <= 128)
+    if ok and int(sem_mode) == 1 and desc.n_sem + desc.n_inst > 0:
+        ok = int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc))) >= 1
+    return ok
+
+
+def desc_for_mode(desc, sem_mode):
+    """desc, or a copy of it, whose PNR_MLP_SOFTMAX flag says sem_mode (what pnr_mlp_forward_composite / _tiles composite)."""
+    want = _lib.MLP_SOFTMAX if int(sem_mode) == 1 else 0
+    if (desc.flags & _lib.MLP_SOFTMAX) == want:
+        return desc
+    d2 = _lib.MlpDesc()
+    ctypes.memmove(ctypes.byref(d2), ctypes.byref(desc), ctypes.sizeof(d2))
+    d2.flags = (desc.flags & ~_lib.MLP_SOFTMAX) | want
+    return d2
+
+
+def fused_image(sem_mode=0):
+    """The `fused` argument of PanopticNetwork.packed for a compositing mode: the best plan for logits, at most plan 1 for
+    softmax (the two-tile assembly kernel composites logits only)."""
+    return 1 if int(sem_mode) == 1 else True
 
 
 @_on_device
-def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True, out=None):
+def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True, out=None,
+                          sem_mode=0):
     """Rows a5 + a6 in one pass (inference): the fused MLP reduces every 32-sample tile to one compositing record in its
     epilogue and k_composite_combine finishes the rays -- the raw image (324 B per sample at 45 / 32 heads) is never
     written.  Same dict as composite().  Sums are associated per tile, so results equal mlp_forward + composite to fp32
-    rounding (not bit for bit)."""
+    rounding (not bit for bit).  sem_mode as in composite(): 1 composites softmax(logits) of each learned field
+    (PNR_MLP_SOFTMAX; plan-1 image only, see fused_supported)."""
     rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
     label_sem = _chk(label_sem, "label_sem", torch.int32)
     label_inst = _chk(label_inst, "label_inst", torch.int32)
@@ -451,6 +475,7 @@ def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None
     n_sem, n_inst = desc.n_sem, desc.n_inst
     dev = z.device
     lib = _lib.load()
+    desc = desc_for_mode(desc, sem_mode)
     nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, int(bool(want_weights)))
     if nbytes < 0:
         raise RuntimeError("pnr_mlp_forward_composite: unsupported geometry (n_samples=%d must be a multiple of 32)" % N)

@@ -129,8 +129,8 @@ class Renderer:
                 mine = {k: v for k, v in mine.items() if v is not None}
                 if self.fuse and ops.fused_supported(net.nerf(lv).desc(net.precision), zz.shape[1], self.sem_mode, noise):
                     # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite, its own chunk order)
-                    desc, img = net.packed(lv, dev, fused=True)
-                    res = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w, out=mine)
+                    desc, img = net.packed(lv, dev, fused=ops.fused_image(self.sem_mode))
+                    res = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w, out=mine, sem_mode=self.sem_mode)
                 else:
                     desc, img = net.packed(lv, dev)
                     raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)

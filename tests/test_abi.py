@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.MlpDesc) == 64          # 13 named ints + clk_probe[2] + reserved[1]
+    assert ctypes.sizeof(_lib.MlpDesc) == 64          # 13 named ints + clk_probe[2] + flags
     assert ctypes.sizeof(_lib.MlpParamsHost) == 18 * ctypes.sizeof(ctypes.c_void_p)
     # pnr_loss_cfg: the binding's fields are, in order and type, the header's (a silent mismatch would scramble the weights)
     import re
@@ -134,7 +134,12 @@ def test_fused_pass_eligibility_and_workspace_arithmetic():
     d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
     assert ops.fused_supported(d, 192) and ops.fused_supported(d, 32) and ops.fused_supported(d, 256)
     assert not ops.fused_supported(d, 100) and not ops.fused_supported(d, 16) and not ops.fused_supported(d, 288)
-    assert not ops.fused_supported(d, 192, sem_mode=1) and not ops.fused_supported(d, 192, noise=torch.zeros(1))
+    assert ops.fused_supported(d, 192, sem_mode=1) and not ops.fused_supported(d, 192, noise=torch.zeros(1))
+    # softmax compositing: only where a head's logit blocks are in registers together (the plan-1 kernel)
+    assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 19, 40, 128, "bf16"), 192, sem_mode=1)
+    assert ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 19, 40, 128, "bf16"), 192, sem_mode=0)
+    assert ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 0, 0, 128, "bf16"), 192, sem_mode=1)       # no learned field: nothing to normalise
+    assert ops.fused_image(0) is True and ops.fused_image(1) == 1
     assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "fp32"), 192)
     assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 100, 60, 128, "bf16"), 192)
     ws = lib.pnr_mlp_forward_composite_workspace_bytes

@@ -429,15 +429,19 @@ def test_mlp_pingpong_equals_lockstep_bit_for_bit(dev, R, N, train):
 
 
 # ----------------------------------------------------------------------------- a5 + a6 fused: no raw image round trip
+@pytest.mark.parametrize("sem_mode", [0, 1])
 @pytest.mark.parametrize("heads", [(45, 32), (6, 0), (0, 0)])
 @pytest.mark.parametrize("R,N,labels,white", [(510, 192, True, False), (512, 64, True, True), (37, 32, False, False),
                                               (129, 256, True, False), (1, 96, False, True)])
-def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, heads):
+def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, heads, sem_mode):
     """pnr_mlp_forward_composite (per-tile records in the MLP's epilogue + k_composite_combine) against pnr_mlp_forward +
     pnr_composite on the same inputs: every map, the per-sample weights and the fixed (bbox-prior) fields.  The two paths
     associate the per-ray sums differently (per 32-sample tile, then over tiles), so they agree to fp32 rounding: 2e-6 of
     the map's scale; the fixed fields additionally round through 2^-30 fixed point per tile.  Ragged sample counts (R*N not a
-    multiple of 256), one ray, several tiles per ray, labels on and off, white background."""
+    multiple of 256), one ray, several tiles per ray, labels on and off, white background.
+    sem_mode 1 (semantic_activation = softmax, PNR_MLP_SOFTMAX): the learned fields composite softmax(logits) -- the fused pass
+    normalises in the logit chunk's epilogue (v_exp_f32 / v_rcp_f32 in place of expf / the division: 4e-6), on the plan-1 image;
+    the plan-0 and plan-2 images refuse the flag."""
     from types import SimpleNamespace as NS
     from panopticnerf_amd import make_network
     C, K = heads
@@ -455,18 +459,29 @@ def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, he
             ls = torch.where(hit, torch.randint(0, C, (R, N), device=dev, generator=g), -1).int()
         if K:
             li = torch.where(hit, torch.randint(0, K, (R, N), device=dev, generator=g), -1).int()
-    assert ops.fused_supported(desc, N)
+    assert ops.fused_supported(desc, N, sem_mode)
     raw = ops.mlp_forward(desc, img, rays, z, channel_major=True)
-    want = ops.composite(raw, z, rays, C, K, True, None, ls, li, 0, white, True)
+    want = ops.composite(raw, z, rays, C, K, True, None, ls, li, sem_mode, white, True)
+    if sem_mode == 1 and (C or K):
+        for fused in (False, 2):
+            d_bad, i_bad = net.packed(1, dev, "bf16", fused=fused)
+            if d_bad.plan != 1:
+                with pytest.raises(RuntimeError, match="softmax compositing"):
+                    ops.mlp_forward_composite(d_bad, i_bad, rays, z, ls, li, white, True, sem_mode=1)
+        desc, img = net.packed(1, dev, "bf16", fused=ops.fused_image(sem_mode))
+        assert desc.plan == 1
+        # sum_c sum_i w_i p_ic = sum_i w_i: the mode is really on
+        assert float((want["semantic"].sum(-1) - want["acc"]).abs().max()) < 1e-4
     for rep in range(2):
-        got = ops.mlp_forward_composite(desc, img, rays, z, ls, li, white, True)
+        got = ops.mlp_forward_composite(desc, img, rays, z, ls, li, white, True, sem_mode=sem_mode)
         assert set(got) == set(want)
         for k in want:
             scale = max(1.0, float(want[k].abs().max()))
             err = float((got[k] - want[k]).abs().max())
-            assert err <= (4e-6 if k.startswith("fix_") else 2e-6) * scale * (N // 32), (k, err, scale, rep)
+            tol = 4e-6 if k.startswith("fix_") or (sem_mode == 1 and k in ("semantic", "instance")) else 2e-6
+            assert err <= tol * scale * (N // 32), (k, err, scale, rep)
     # without the weights / labels the other outputs are unchanged
-    lean = ops.mlp_forward_composite(desc, img, rays, z, None, None, white, False)
+    lean = ops.mlp_forward_composite(desc, img, rays, z, None, None, white, False, sem_mode=sem_mode)
     assert "weights" not in lean and "fix_semantic" not in lean
     assert torch.equal(lean["rgb"], got["rgb"]) and torch.equal(lean["depth"], got["depth"])
 
