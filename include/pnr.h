@@ -351,6 +351,21 @@ int pnr_sample_labels(const float* z, int64_t n_rays, int n_samples, const float
                       const int32_t* hit_box, const int32_t* hit_count, int max_hits,
                       const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream);
 
+/* a8 + a3 (+ a8) in one launch -- the coarse level's per-ray preamble: hit lists exactly as pnr_bbox_hits writes them, z_out (R,N)
+ * exactly as pnr_stratified (over the hull of each ray's kept intervals with hull != 0, as pnr_restrict_rays + pnr_stratified),
+ * and, when label_sem / label_inst are given, the labels pnr_sample_labels would produce for z_out.  max_hits in [1, 8]
+ * (larger lists: the separate entry points).  Replaces, with pnr_sample_pdf_labels, four of the reference render_rays' per-chunk
+ * steps by one launch each. */
+int pnr_ray_setup(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits, const int32_t* box_ids,
+                  int n_samples, int lindisp, const float* t_rand, int hull, float* hit_t, int32_t* hit_box,
+                  int32_t* hit_count, float* z_out, int32_t* label_sem, int32_t* label_inst, void* stream);
+
+/* a7 + a8 in one launch: z_fine (R, n_coarse + n_fine) exactly as pnr_sample_pdf, and label_sem / label_inst (same shape)
+ * exactly as pnr_sample_labels(z_fine, ...) -- the wave that merged a ray's samples labels them. */
+int pnr_sample_pdf_labels(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse, int n_fine,
+                          float* z_fine, const float* hit_t, const int32_t* hit_box, const int32_t* hit_count,
+                          int max_hits, const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream);
+
 /* ---- diagnostics.  Measurement helpers (hipEvent timing, MFMA / HBM ceilings of the device) live in libpnr_bench.so
  * (include/pnr_bench.h), not here: every export of this library is stream-ordered, never synchronises and keeps no mutable
  * state -- the one diagnostic hook of the MLP kernels is a descriptor field (pnr_mlp_desc.clk_probe). */

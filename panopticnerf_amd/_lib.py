@@ -95,6 +95,8 @@ SIGNATURES = {
     "pnr_bbox_hits": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_f, c_f, c_f]),
     "pnr_restrict_rays": (c_int, [c_f, c_i64, c_f, c_f, c_int, c_f, c_f]),
     "pnr_sample_labels": (c_int, [c_f, c_i64, c_int, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
+    "pnr_ray_setup": (c_int, [c_f, c_i64, c_f, c_int, c_int, c_f, c_int, c_int, c_f, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "pnr_sample_pdf_labels": (c_int, [c_f, c_f, c_f, c_i64, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_f, c_f, c_f, c_f]),
     "pnr_mlp_forward_tiles": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_f]),
     "pnr_composite_combine": (c_int, [ctypes.POINTER(MlpDesc), c_f, c_f, c_i64, c_int, c_f, c_f, c_int,
                                       c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

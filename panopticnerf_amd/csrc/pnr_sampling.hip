@@ -7,6 +7,7 @@
 // Reference functions these replace (the reference source
 // is not in the mount, include/pnr.h explains the citation form).
 #include "pnr_common.h"
+#include <string.h>
 
 #pragma clang fp contract(off)
 
@@ -32,6 +33,19 @@ __device__ __forceinline__ float strat_z(float nr, float fr, int i, int N, int l
     }
     const float a = (1.0f / nr) * omt, b = (1.0f / fr) * t;
     return 1.0f / (a + b);
+}
+
+// sample i of a ray's N: the stratified depth, jittered inside its bin by *t when t is given (k_stratified, k_ray_setup)
+__device__ __forceinline__ float strat_sample(float nr, float fr, int i, int N, int lindisp, const float* t)
+{
+    const float zi = strat_z(nr, fr, i, N, lindisp);
+    if (!t) return zi;
+    const float z0 = strat_z(nr, fr, 0, N, lindisp), zl = strat_z(nr, fr, N - 1, N, lindisp);
+    const float lo = (i == 0) ? z0 : 0.5f * (zi + strat_z(nr, fr, i - 1, N, lindisp));
+    const float up = (i == N - 1) ? zl : 0.5f * (strat_z(nr, fr, i + 1, N, lindisp) + zi);
+    const float w = up - lo;
+    const float m = w * *t;
+    return lo + m;
 }
 
 // Ray generation: one thread per ray, two float4 stores; write-bound (32 B/ray).
@@ -65,18 +79,7 @@ __global__ __launch_bounds__(256) void k_stratified(const float* __restrict__ ra
          s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = s / N;
         const int i = (int)(s - r * N);
-        const float nr = rays[r * 8 + 6], fr = rays[r * 8 + 7];
-        const float zi = strat_z(nr, fr, i, N, lindisp);
-        float z = zi;
-        if (t_rand) {
-            const float z0 = strat_z(nr, fr, 0, N, lindisp), zl = strat_z(nr, fr, N - 1, N, lindisp);
-            const float lo = (i == 0) ? z0 : 0.5f * (zi + strat_z(nr, fr, i - 1, N, lindisp));
-            const float up = (i == N - 1) ? zl : 0.5f * (strat_z(nr, fr, i + 1, N, lindisp) + zi);
-            const float w = up - lo;
-            const float m = w * t_rand[s];
-            z = lo + m;
-        }
-        z_out[s] = z;
+        z_out[s] = strat_sample(rays[r * 8 + 6], rays[r * 8 + 7], i, N, lindisp, t_rand ? t_rand + s : nullptr);
     }
 }
 
@@ -125,12 +128,35 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, int6
 // oracle's sequential fp32 order (the bit-exact index requirement, SURVEY.md section 7 "hard
 // parts"); everything else is lane-parallel: bins, pdf, one upper_bound per u, and a bitonic
 // sort of the Nc+Nf union in LDS (a rank-based merge when the new samples are already ascending).  LDS: 7 KiB.
+// the kept interval a sample at depth zz takes its label from: the one with the smallest t_in among those containing it (-1: none)
+template <class F>
+__device__ __forceinline__ int label_hit(float zz, int cnt, F interval)
+{
+    int best = -1;
+    float bt = 0.0f;
+    for (int h = 0; h < cnt; ++h) {
+        float ti, to;
+        interval(h, ti, to);
+        if (ti <= zz && zz <= to && (best < 0 || ti < bt)) {
+            best = h;
+            bt = ti;
+        }
+    }
+    return best;
+}
+
+// With lab.label_sem set the wave that merged a ray's samples also labels them (k_sample_labels' rule on the sorted z it still
+// holds in LDS): the fine level's labels without a second pass over z (pnr_sample_pdf_labels; one launch less per chunk).
+struct PdfLabelArgs {
+    const float* hit_t; const int32_t* hit_box; const int32_t* hit_count; int max_hits; const int32_t* box_ids;
+    int32_t* label_sem; int32_t* label_inst;
+};
 #define PDF_MAXC 256
 #define PDF_MAXT 512
 __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, const float* __restrict__ weights,
                                                     const float* __restrict__ u, int64_t R, int Nc, int Nf,
                                                     float* __restrict__ zs_out, int32_t* __restrict__ inds_out,
-                                                    float* __restrict__ zfine_out)
+                                                    float* __restrict__ zfine_out, const PdfLabelArgs lab)
 {
     __shared__ float s_z[PDF_MAXC], s_w[PDF_MAXC], s_pdf[PDF_MAXC], s_cdf[PDF_MAXC], s_bins[PDF_MAXC];
     __shared__ float s_sort[PDF_MAXT], s_out[PDF_MAXT];
@@ -139,6 +165,25 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
     const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
     int P = 1;
     while (P < Nt) P <<= 1;
+    auto labels = [&](int64_t r, const float* sorted) {       // sorted: the ray's Nt merged depths in LDS (written before a barrier)
+        if (!lab.label_sem) return;
+        const int mh = lab.max_hits;
+        const int cnt = lab.hit_count[r] < mh ? lab.hit_count[r] : mh;
+        for (int i = lane; i < Nt; i += 64) {
+            const int best = label_hit(sorted[i], cnt, [&](int h, float& ti, float& to) {
+                ti = lab.hit_t[(r * mh + h) * 2];
+                to = lab.hit_t[(r * mh + h) * 2 + 1];
+            });
+            int ls = -1, li = -1;
+            if (best >= 0) {
+                const int m = lab.hit_box[r * mh + best];
+                ls = lab.box_ids[m * 2];
+                li = lab.box_ids[m * 2 + 1];
+            }
+            lab.label_sem[r * Nt + i] = ls;
+            lab.label_inst[r * Nt + i] = li;
+        }
+    };
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         for (int i = lane; i < Nc; i += 64) {
             s_z[i] = z[r * Nc + i];
@@ -246,6 +291,7 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
                 }
                 __syncthreads();
                 for (int i = lane; i < Nt; i += 64) zfine_out[r * Nt + i] = s_out[i];
+                labels(r, s_out);
                 __syncthreads();
                 continue;
             }
@@ -268,6 +314,7 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
                 }
             }
             for (int i = lane; i < Nt; i += 64) zfine_out[r * Nt + i] = s_sort[i];
+            labels(r, s_sort);
         }
         __syncthreads();
     }
@@ -330,6 +377,107 @@ __global__ __launch_bounds__(256) void k_bbox_hits(const float* __restrict__ ray
     }
 }
 
+// a8 + a3 + a8 in one launch (the coarse level's per-ray preamble: k_bbox_hits, k_restrict_rays' hull, k_stratified and
+// k_sample_labels were four launches and three passes over the hit lists).  Phase 1, one thread per ray: the slab tests with the
+// ray's kept intervals in LDS ([entry][thread]: conflict-free; k_bbox_hits keeps them in global memory) -- same operations in the
+// same order, so the hit lists are k_bbox_hits' bit for bit.  Phase 2, one wave per 64 rays, lane = sample: z and the labels,
+// written in whole rows.  max_hits <= 8 (19 KiB of LDS); the separate kernels remain for larger lists.
+#define SETUP_MAXH 8
+struct RaySetupArgs {
+    const float* rays; int64_t R; const float* box; int M; int max_hits; const int32_t* box_ids;
+    int N, lindisp, hull; const float* t_rand;
+    float* hit_t; int32_t* hit_box; int32_t* hit_count; float* z; int32_t* label_sem; int32_t* label_inst;
+};
+__global__ __launch_bounds__(256) void k_ray_setup(const RaySetupArgs a)
+{
+    __shared__ float s_ti[SETUP_MAXH][256], s_to[SETUP_MAXH][256], s_nr[256], s_fr[256];
+    __shared__ int s_hb[SETUP_MAXH][256], s_cnt[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mh = a.max_hits, N = a.N;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < a.R; base += (int64_t)gridDim.x * 256) {
+        const int64_t r = base + tid;
+        if (r < a.R) {
+            const float4 ra = *reinterpret_cast<const float4*>(a.rays + r * 8), rb = *reinterpret_cast<const float4*>(a.rays + r * 8 + 4);
+            const float o0 = ra.x, o1 = ra.y, o2 = ra.z, d0 = ra.w, d1 = rb.x, d2 = rb.y;
+            float nr = rb.z, fr = rb.w;
+            for (int h = 0; h < mh; ++h) { s_hb[h][tid] = -1; s_ti[h][tid] = 0.0f; s_to[h][tid] = 0.0f; }
+            int cnt = 0;
+            for (int m = 0; m < a.M; ++m) {
+                const float* b = a.box + m * 15;
+                const float p0 = o0 - b[0], p1 = o1 - b[1], p2 = o2 - b[2];
+                float tmin = nr, tmax = fr;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const float r0 = b[3 + 3 * x], r1 = b[4 + 3 * x], r2 = b[5 + 3 * x];
+                    const float ol = (r0 * p0 + r1 * p1) + r2 * p2;
+                    const float dl = (r0 * d0 + r1 * d1) + r2 * d2;
+                    const float inv = 1.0f / dl;
+                    const float e = b[12 + x];
+                    const float t1 = (-e - ol) * inv, t2 = (e - ol) * inv;
+                    tmin = fmaxf(tmin, fminf(t1, t2));
+                    tmax = fminf(tmax, fmaxf(t1, t2));
+                }
+                if (tmin <= tmax) {             // k_bbox_hits' insertion: the max_hits nearest, ascending (t_in, box index)
+                    const int n = cnt < mh ? cnt : mh;
+                    int pos = n;
+                    while (pos > 0 && s_ti[pos - 1][tid] > tmin) --pos;
+                    if (pos < mh) {
+                        for (int k = (n < mh ? n : mh - 1); k > pos; --k) {
+                            s_ti[k][tid] = s_ti[k - 1][tid];
+                            s_to[k][tid] = s_to[k - 1][tid];
+                            s_hb[k][tid] = s_hb[k - 1][tid];
+                        }
+                        s_ti[pos][tid] = tmin;
+                        s_to[pos][tid] = tmax;
+                        s_hb[pos][tid] = m;
+                    }
+                    ++cnt;
+                }
+            }
+            a.hit_count[r] = cnt;
+            const int kept = cnt < mh ? cnt : mh;
+            for (int h = 0; h < mh; ++h) {
+                *reinterpret_cast<float2*>(a.hit_t + (r * mh + h) * 2) = make_float2(s_ti[h][tid], s_to[h][tid]);
+                a.hit_box[r * mh + h] = s_hb[h][tid];
+            }
+            if (a.hull && kept > 0) {           // k_restrict_rays: the hull of the kept intervals replaces [near, far]
+                float lo = s_ti[0][tid], hi = s_to[0][tid];
+                for (int h = 1; h < kept; ++h) {
+                    lo = fminf(lo, s_ti[h][tid]);
+                    hi = fmaxf(hi, s_to[h][tid]);
+                }
+                nr = lo; fr = hi;
+            }
+            s_nr[tid] = nr; s_fr[tid] = fr; s_cnt[tid] = kept;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 64; ++rr) {
+            const int t = wv * 64 + rr;
+            const int64_t ray = base + t;
+            if (ray >= a.R) break;                      // wave-uniform
+            const float nr = s_nr[t], fr = s_fr[t];
+            const int cnt = s_cnt[t];
+            for (int i = lane; i < N; i += 64) {
+                const int64_t s = ray * N + i;
+                const float zz = strat_sample(nr, fr, i, N, a.lindisp, a.t_rand ? a.t_rand + s : nullptr);
+                a.z[s] = zz;
+                if (a.label_sem) {
+                    const int best = label_hit(zz, cnt, [&](int h, float& ti, float& to) { ti = s_ti[h][t]; to = s_to[h][t]; });
+                    int ls = -1, li = -1;
+                    if (best >= 0) {
+                        const int m = s_hb[best][t];
+                        ls = a.box_ids[m * 2];
+                        li = a.box_ids[m * 2 + 1];
+                    }
+                    a.label_sem[s] = ls;
+                    a.label_inst[s] = li;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sample_labels(const float* __restrict__ z, int64_t R, int N,
                                                         const float* __restrict__ hit_t,
                                                         const int32_t* __restrict__ hit_box,
@@ -344,15 +492,10 @@ __global__ __launch_bounds__(256) void k_sample_labels(const float* __restrict__
         const int64_t r = s / N;
         const float zz = z[s];
         const int cnt = hit_count[r] < max_hits ? hit_count[r] : max_hits;     // hit_count is the true count (overflow)
-        int best = -1;
-        float bt = 0.0f;
-        for (int h = 0; h < cnt; ++h) {
-            const float ti = hit_t[(r * max_hits + h) * 2], to = hit_t[(r * max_hits + h) * 2 + 1];
-            if (ti <= zz && zz <= to && (best < 0 || ti < bt)) {
-                best = h;
-                bt = ti;
-            }
-        }
+        const int best = label_hit(zz, cnt, [&](int h, float& ti, float& to) {
+            ti = hit_t[(r * max_hits + h) * 2];
+            to = hit_t[(r * max_hits + h) * 2 + 1];
+        });
         int ls = -1, li = -1;
         if (best >= 0) {
             const int m = hit_box[r * max_hits + best];
@@ -429,9 +572,55 @@ PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float*
     PNR_REQUIRE(n_fine >= 1 && n_coarse + n_fine <= PDF_MAXT, "pnr_sample_pdf: n_coarse+n_fine=%d > %d",
                 n_coarse + n_fine, PDF_MAXT);
     if (n_rays <= 0) return PNR_OK;
+    PdfLabelArgs lab;
+    memset(&lab, 0, sizeof(lab));
     hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, (hipStream_t)stream,
-                       z, weights, u, n_rays, n_coarse, n_fine, z_samples, inds, z_fine);
+                       z, weights, u, n_rays, n_coarse, n_fine, z_samples, inds, z_fine, lab);
     PNR_CHECK_LAUNCH("pnr_sample_pdf");
+    return PNR_OK;
+}
+
+// a7 + a8: z_fine as pnr_sample_pdf, and the labels pnr_sample_labels would give for it, in the same launch
+PNR_EXPORT int pnr_sample_pdf_labels(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse, int n_fine,
+                                     float* z_fine, const float* hit_t, const int32_t* hit_box, const int32_t* hit_count,
+                                     int max_hits, const int32_t* box_ids, int32_t* label_sem, int32_t* label_inst, void* stream)
+{
+    PNR_REQUIRE(n_rays <= 0 || (z && weights && z_fine), "pnr_sample_pdf_labels: null pointer");
+    PNR_REQUIRE(n_rays <= 0 || (hit_t && hit_box && hit_count && box_ids && label_sem && label_inst), "pnr_sample_pdf_labels: null pointer");
+    PNR_REQUIRE(n_coarse >= 3 && n_coarse <= PDF_MAXC, "pnr_sample_pdf_labels: n_coarse=%d outside [3,%d]", n_coarse, PDF_MAXC);
+    PNR_REQUIRE(n_fine >= 1 && n_coarse + n_fine <= PDF_MAXT, "pnr_sample_pdf_labels: n_coarse+n_fine=%d > %d", n_coarse + n_fine, PDF_MAXT);
+    PNR_REQUIRE(max_hits >= 1, "pnr_sample_pdf_labels: bad max_hits");
+    if (n_rays <= 0) return PNR_OK;
+    PdfLabelArgs lab;
+    lab.hit_t = hit_t; lab.hit_box = hit_box; lab.hit_count = hit_count; lab.max_hits = max_hits; lab.box_ids = box_ids;
+    lab.label_sem = label_sem; lab.label_inst = label_inst;
+    hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, (hipStream_t)stream,
+                       z, weights, u, n_rays, n_coarse, n_fine, (float*)nullptr, (int32_t*)nullptr, z_fine, lab);
+    PNR_CHECK_LAUNCH("pnr_sample_pdf_labels");
+    return PNR_OK;
+}
+
+// a8 + a3 (+ a8): hit lists as pnr_bbox_hits, z as pnr_stratified (over the hull of the kept intervals with hull != 0:
+// pnr_restrict_rays), labels as pnr_sample_labels (label_sem / label_inst may both be null), in one launch.  max_hits <= 8.
+PNR_EXPORT int pnr_ray_setup(const float* rays, int64_t n_rays, const float* box, int n_box, int max_hits, const int32_t* box_ids,
+                             int n_samples, int lindisp, const float* t_rand, int hull, float* hit_t, int32_t* hit_box,
+                             int32_t* hit_count, float* z_out, int32_t* label_sem, int32_t* label_inst, void* stream)
+{
+    PNR_REQUIRE(n_rays >= 0 && n_samples >= 1, "pnr_ray_setup: bad size R=%lld N=%d", (long long)n_rays, n_samples);
+    PNR_REQUIRE(max_hits >= 1 && max_hits <= SETUP_MAXH, "pnr_ray_setup: max_hits=%d outside [1,%d] (use the separate entry points)",
+                max_hits, SETUP_MAXH);
+    PNR_REQUIRE(n_box >= 0 && (n_box == 0 || box), "pnr_ray_setup: bad box table");
+    if (n_rays == 0) return PNR_OK;
+    PNR_REQUIRE(rays && hit_t && hit_box && hit_count && z_out, "pnr_ray_setup: null pointer");
+    PNR_REQUIRE((label_sem != nullptr) == (label_inst != nullptr) && (!label_sem || box_ids || n_box == 0),
+                "pnr_ray_setup: labels need both outputs and box_ids");
+    PNR_REQUIRE((((uintptr_t)rays) & 15) == 0 && (((uintptr_t)hit_t) & 7) == 0, "pnr_ray_setup: rays must be 16-byte aligned");
+    RaySetupArgs a;
+    a.rays = rays; a.R = n_rays; a.box = box; a.M = n_box; a.max_hits = max_hits; a.box_ids = box_ids;
+    a.N = n_samples; a.lindisp = lindisp; a.hull = hull; a.t_rand = t_rand;
+    a.hit_t = hit_t; a.hit_box = hit_box; a.hit_count = hit_count; a.z = z_out; a.label_sem = label_sem; a.label_inst = label_inst;
+    hipLaunchKernelGGL(k_ray_setup, dim3(pnr_grid_cap((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    PNR_CHECK_LAUNCH("pnr_ray_setup");
     return PNR_OK;
 }
 

@@ -591,6 +591,53 @@ def bbox_hits(rays, box, max_hits=8):
     return hit_t, hit_box, hit_count
 
 
+RAY_SETUP_MAX_HITS = 8      # pnr_ray_setup keeps the hit lists of 256 rays in LDS
+
+
+@_on_device
+def ray_setup(rays, box, box_ids=None, n_samples=64, max_hits=8, lindisp=False, t_rand=None, hull=False, out=None):
+    """The coarse level's per-ray preamble in ONE launch (pnr_ray_setup): (hit_t, hit_box, hit_count) as bbox_hits, z (R,N) as
+    stratified -- over the hull of the kept intervals with hull=True, as restrict_rays + stratified --, and (label_sem,
+    label_inst) as sample_labels when box_ids is given (else None, None).  Bit for bit the separate ops; max_hits <= 8."""
+    rays, box, t_rand = _chk(rays, "rays"), _chk(box, "box"), _chk(t_rand, "t_rand")
+    box_ids = _chk(box_ids, "box_ids", torch.int32)
+    R, M, N = rays.shape[0], box.shape[0], int(n_samples)
+    dev = rays.device
+    if t_rand is not None:
+        assert tuple(t_rand.shape) == (R, N)
+    hit_t = torch.empty((R, max_hits, 2), device=dev, dtype=torch.float32)
+    hit_box = torch.empty((R, max_hits), device=dev, dtype=torch.int32)
+    hit_count = torch.empty((R,), device=dev, dtype=torch.int32)
+    z = _own(out, (R, N), torch.float32, dev, "ray_setup")
+    ls = li = None
+    if box_ids is not None:
+        ls = torch.empty((R, N), device=dev, dtype=torch.int32)
+        li = torch.empty((R, N), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().pnr_ray_setup(_p(rays), R, _p(box), M, int(max_hits), _p(box_ids), N, int(bool(lindisp)), _p(t_rand),
+                                         int(bool(hull)), _p(hit_t), _p(hit_box), _p(hit_count), _p(z), _p(ls), _p(li), _stream()),
+               "pnr_ray_setup")
+    return (hit_t, hit_box, hit_count), z, ls, li
+
+
+@_on_device
+def sample_pdf_labels(z, weights, n_importance, hits, box_ids, u=None, out=None):
+    """sample_pdf + sample_labels of its result in ONE launch (pnr_sample_pdf_labels): (z_fine (R,Nc+Nf), label_sem, label_inst).
+    hits = (hit_t, hit_box, hit_count) of bbox_hits / ray_setup.  Bit for bit the separate ops."""
+    z, weights, u = _chk(z, "z"), _chk(weights, "weights"), _chk(u, "u")
+    hit_t, hit_box, hit_count = _chk(hits[0], "hit_t"), _chk(hits[1], "hit_box", torch.int32), _chk(hits[2], "hit_count", torch.int32)
+    box_ids = _chk(box_ids, "box_ids", torch.int32)
+    R, Nc = z.shape
+    dev = z.device
+    Nt = Nc + int(n_importance)
+    z_fine = _own(out, (R, Nt), torch.float32, dev, "sample_pdf_labels")
+    ls = torch.empty((R, Nt), device=dev, dtype=torch.int32)
+    li = torch.empty((R, Nt), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().pnr_sample_pdf_labels(_p(z), _p(weights), _p(u), R, Nc, int(n_importance), _p(z_fine), _p(hit_t), _p(hit_box),
+                                                 _p(hit_count), hit_box.shape[1], _p(box_ids), _p(ls), _p(li), _stream()),
+               "pnr_sample_pdf_labels")
+    return z_fine, ls, li
+
+
 @_on_device
 def restrict_rays(rays, hit_t, hit_count):
     """rays with near / far replaced by the hull of each ray's kept bbox intervals (pnr_restrict_rays); no hit: unchanged."""

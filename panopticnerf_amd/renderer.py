@@ -100,22 +100,30 @@ class Renderer:
         C, K = n0.n_sem, n0.n_inst
         dev = rays.device
         ret = {}
-        hits = None
-        if box is not None:
-            hits = ops.bbox_hits(rays, box, self.max_hits)
-            if self.strict_hits:          # accumulated on the device; checked ONCE at the end of render() (a single sync)
-                over = torch.stack([(hits[2] > self.max_hits).sum(), hits[2].max()])
-                self._overflow = over if self._overflow is None else torch.stack([self._overflow[0] + over[0],
-                                                                                  torch.maximum(self._overflow[1], over[1])])
+        hits = lab0 = None
         if t_rand is None and self.perturb > 0 and train:
             t_rand = torch.rand((rays.shape[0], Nc), device=dev)
-        rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and self.bbox_sampling == "hull") else rays
         own = (lambda key: out.get(key)) if (out and not grad) else (lambda key: None)
-        z = ops.stratified(rays_s, Nc, self.lindisp, t_rand, out=own("z_vals_0"))
+        hull = self.bbox_sampling == "hull"
+        if box is not None and self.max_hits <= ops.RAY_SETUP_MAX_HITS:
+            # rows a8 + a3 in one launch: hit lists, z and the coarse labels (pnr_ray_setup; bit for bit the separate kernels)
+            hits, z, ls0, li0 = ops.ray_setup(rays, box, box_ids, Nc, self.max_hits, self.lindisp, t_rand, hull, out=own("z_vals_0"))
+            lab0 = (ls0, li0)
+        else:
+            if box is not None:
+                hits = ops.bbox_hits(rays, box, self.max_hits)
+            rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and hull) else rays
+            z = ops.stratified(rays_s, Nc, self.lindisp, t_rand, out=own("z_vals_0"))
+        if hits is not None and self.strict_hits:          # accumulated on the device; checked ONCE at the end of render() (a single sync)
+            over = torch.stack([(hits[2] > self.max_hits).sum(), hits[2].max()])
+            self._overflow = over if self._overflow is None else torch.stack([self._overflow[0] + over[0],
+                                                                              torch.maximum(self._overflow[1], over[1])])
 
-        def level(lv, zz):
+        def level(lv, zz, labels=None):
             ls = li = None
-            if hits is not None:
+            if labels is not None:
+                ls, li = labels
+            elif hits is not None:
                 ls, li = ops.sample_labels(zz, hits[0], hits[1], hits[2], box_ids)
             noise = None
             if self.raw_noise_std > 0 and train:
@@ -140,12 +148,17 @@ class Renderer:
             ret[f"z_vals_{lv}"] = zz
             return res
 
-        o0 = level(0, z)
+        o0 = level(0, z, lab0)
         if Nf > 0:
             if u is None and self.perturb > 0 and train:
                 u = torch.rand((rays.shape[0], Nf), device=dev)
-            z_fine, _, _ = ops.sample_pdf(z, o0["weights"].detach().contiguous(), Nf, u, want_samples=False, out=own("z_vals_1"))
-            level(1, z_fine)
+            w0 = o0["weights"].detach().contiguous()
+            if hits is not None:        # rows a7 + a8 in one launch: the wave that merged a ray's samples labels them
+                z_fine, ls1, li1 = ops.sample_pdf_labels(z, w0, Nf, hits, box_ids, u, out=own("z_vals_1"))
+                level(1, z_fine, (ls1, li1))
+            else:
+                z_fine, _, _ = ops.sample_pdf(z, w0, Nf, u, want_samples=False, out=own("z_vals_1"))
+                level(1, z_fine)
         return ret
 
     def _empty_outputs(self, lead, has_box, dev):

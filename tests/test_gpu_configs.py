@@ -82,7 +82,8 @@ def test_render_baseline_configs(dev, cfg_golden, n, prec):
         # bf16: the last sample's 1e10 interval makes alpha_last a step function of sign(sigma_last); a ray whose
         # sigma_last sits within bf16 noise of zero may flip -- such rays are judged in fp32 mode only
         ok = torch.ones(24, dtype=torch.bool) if prec == "fp32" else raw[:, -1, 3].abs() > 2e-2
-        assert ok.sum() >= 16
+        print("config %d %s level %d: %d of 24 rays excluded (|sigma_last| <= 2e-2)" % (n, prec, lv, 24 - int(ok.sum())))
+        assert ok.sum() >= 20          # at most 4 of 24: the exclusion must stay the exception it is described as
         tol = 1e-4 if prec == "fp32" else 1e-2
         for k in ("rgb", "acc", "weights", "semantic", "instance", "fix_semantic", "fix_instance"):
             if f"{k}_{lv}" in out:

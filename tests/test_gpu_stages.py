@@ -658,6 +658,75 @@ def test_bbox_restricted_sampling_switch(dev):
         make_renderer(NS(bbox_sampling="intervals", **cfg), net)
 
 
+@pytest.mark.parametrize("R,N,M,mh", [(1000, 64, 40, 8), (257, 32, 64, 3), (64, 100, 12, 8), (5, 192, 40, 1), (300, 64, 0, 8)])
+@pytest.mark.parametrize("hull", [False, True])
+@pytest.mark.parametrize("jitter,lindisp", [(False, False), (True, False), (False, True)])
+def test_ray_setup_is_the_four_separate_kernels_bit_for_bit(dev, R, N, M, mh, hull, jitter, lindisp):
+    """pnr_ray_setup (bbox_hits + restrict_rays' hull + stratified + sample_labels in one launch) against the C oracle's functions
+    and against the separate entry points: hit lists (also the unused entries and the true count of an overflowing ray), z and
+    both label images, bit for bit.  Ragged ray counts (not a multiple of the 256-ray workgroup or the 64-ray wave), N above and
+    below the wave width, an empty box table, max_hits 1 / 3 / 8 with overflow, jittered and lindisp sampling."""
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous()
+    box, ids = synthetic.random_boxes(max(M, 1), 6, 3, seed=R)
+    box, ids = box[:M].contiguous(), ids[:M].contiguous()
+    g = torch.Generator().manual_seed(N)
+    t_rand = torch.rand((R, N), generator=g) if jitter else None
+    d = lambda t: None if t is None else t.to(dev)
+    hits, z, ls, li = ops.ray_setup(d(rays), d(box), d(ids), N, mh, lindisp, d(t_rand), hull)
+    # the C oracle, stage by stage
+    ht, hb, hc = co.bbox_hits(rays.numpy(), box.numpy(), mh)
+    assert np.array_equal(hits[0].cpu().numpy(), ht) and np.array_equal(hits[1].cpu().numpy(), hb) and np.array_equal(hits[2].cpu().numpy(), hc)
+    if M:
+        assert (hc > mh).any() or mh == 8          # the small lists overflow: nearest kept, true count reported
+    rr = co.restrict_rays(rays.numpy(), ht, hc) if hull else rays.numpy()
+    zw = co.stratified(rr, N, lindisp=lindisp, t_rand=None if t_rand is None else t_rand.numpy())
+    assert np.array_equal(z.cpu().numpy(), zw)
+    lsw, liw = co.sample_labels(zw, ht, hb, hc, ids.numpy())
+    assert np.array_equal(ls.cpu().numpy(), lsw) and np.array_equal(li.cpu().numpy(), liw)
+    if M:
+        assert (lsw >= 0).any()
+    # the separate entry points
+    h2 = ops.bbox_hits(d(rays), d(box), mh)
+    for a, b in zip(hits, h2):
+        assert torch.equal(a, b)
+    rs = ops.restrict_rays(d(rays), h2[0], h2[2]) if hull else d(rays)
+    z2 = ops.stratified(rs, N, lindisp, d(t_rand))
+    assert torch.equal(z, z2)
+    l2 = ops.sample_labels(z2, *h2, d(ids))
+    assert torch.equal(ls, l2[0]) and torch.equal(li, l2[1])
+    # without box ids: hit lists and z only
+    h3, z3, n1, n2 = ops.ray_setup(d(rays), d(box), None, N, mh, lindisp, d(t_rand), hull)
+    assert n1 is None and n2 is None and torch.equal(z3, z) and all(torch.equal(a, b) for a, b in zip(h3, hits))
+    with pytest.raises(RuntimeError, match="max_hits"):
+        ops.ray_setup(d(rays), d(box), d(ids), N, 9)
+
+
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (32, 32), (8, 5)])
+@pytest.mark.parametrize("random_u", [False, True])
+def test_sample_pdf_labels_is_sample_pdf_then_sample_labels_bit_for_bit(dev, Nc, Nf, random_u):
+    """pnr_sample_pdf_labels (the wave that merged a ray's samples labels them) against pnr_sample_pdf + pnr_sample_labels and the
+    C oracle: z_fine and both label images bit for bit, with deterministic u (the merge path) and random u (the bitonic-sort path)."""
+    R = 777
+    rays = synthetic.camera_rays()[::601][:R].contiguous()
+    box, ids = synthetic.random_boxes(40, 6, 3, seed=5)
+    g = torch.Generator().manual_seed(Nc + Nf)
+    w = torch.rand((R, Nc), generator=g) ** 4
+    u = torch.rand((R, Nf), generator=g) if random_u else None
+    d = lambda t: None if t is None else t.to(dev)
+    hits = ops.bbox_hits(d(rays), d(box), 8)
+    z = ops.stratified(d(rays), Nc)
+    zf, ls, li = ops.sample_pdf_labels(z, d(w), Nf, hits, d(ids), d(u))
+    zf2, _, _ = ops.sample_pdf(z, d(w), Nf, d(u), want_samples=False)
+    assert torch.equal(zf, zf2)
+    l2 = ops.sample_labels(zf2, *hits, d(ids))
+    assert torch.equal(ls, l2[0]) and torch.equal(li, l2[1]) and bool((ls >= 0).any())
+    zs, _ = co.sample_pdf(z.cpu().numpy(), w.numpy(), Nf, u=None if u is None else u.numpy())
+    zw = co.merge_sorted(z.cpu().numpy(), zs)
+    assert np.array_equal(zf.cpu().numpy(), zw)
+    lsw, liw = co.sample_labels(zw, *(h.cpu().numpy() for h in hits), ids.numpy())
+    assert np.array_equal(ls.cpu().numpy(), lsw) and np.array_equal(li.cpu().numpy(), liw)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("tap,depth", [("feature", 2), ("trunk", 1), ("feature", 1)])
 @pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (4, 128, [1], 6, 0)])
