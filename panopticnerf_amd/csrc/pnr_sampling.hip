@@ -380,8 +380,10 @@ __global__ __launch_bounds__(256) void k_bbox_hits(const float* __restrict__ ray
 // a8 + a3 + a8 in one launch (the coarse level's per-ray preamble: k_bbox_hits, k_restrict_rays' hull, k_stratified and
 // k_sample_labels were four launches and three passes over the hit lists).  Phase 1, one thread per ray: the slab tests with the
 // ray's kept intervals in LDS ([entry][thread]: conflict-free; k_bbox_hits keeps them in global memory) -- same operations in the
-// same order, so the hit lists are k_bbox_hits' bit for bit.  Phase 2, one wave per 64 rays, lane = sample: z and the labels,
-// written in whole rows.  max_hits <= 8 (19 KiB of LDS); the separate kernels remain for larger lists.
+// same order, so the hit lists are k_bbox_hits' bit for bit.  Phase 2, lane = sample: z and the labels, written in whole rows.
+// 64 rays per 4-wave workgroup: phase 1 occupies one wave (one thread per ray is all the parallelism it has; as one wave per SIMD
+// of a 256-ray workgroup, phase 2 ran at 42 us against the separate kernels' 26), the other three are in the phase 2 of the CU's
+// other workgroups.  65,536 rays x 64 samples, 64 boxes: 50 us against 27 + 11 + 15 for the three kernels (profiles/r05l).  max_hits <= 8 (7 KiB of LDS); the separate kernels remain for larger lists.
 #define SETUP_MAXH 8
 struct RaySetupArgs {
     const float* rays; int64_t R; const float* box; int M; int max_hits; const int32_t* box_ids;
@@ -390,17 +392,18 @@ struct RaySetupArgs {
 };
 __global__ __launch_bounds__(256) void k_ray_setup(const RaySetupArgs a)
 {
-    __shared__ float s_ti[SETUP_MAXH][256], s_to[SETUP_MAXH][256], s_nr[256], s_fr[256];
-    __shared__ int s_hb[SETUP_MAXH][256], s_cnt[256];
+    __shared__ float2 s_t[SETUP_MAXH][64];      // (t_in, t_out)
+    __shared__ float s_nr[64], s_fr[64];
+    __shared__ int s_hb[SETUP_MAXH][64], s_cnt[64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mh = a.max_hits, N = a.N;
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < a.R; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < a.R; base += (int64_t)gridDim.x * 64) {
         const int64_t r = base + tid;
-        if (r < a.R) {
+        if (tid < 64 && r < a.R) {              // phase 1: the block's first wave (the others are in another block's phase 2)
             const float4 ra = *reinterpret_cast<const float4*>(a.rays + r * 8), rb = *reinterpret_cast<const float4*>(a.rays + r * 8 + 4);
             const float o0 = ra.x, o1 = ra.y, o2 = ra.z, d0 = ra.w, d1 = rb.x, d2 = rb.y;
             float nr = rb.z, fr = rb.w;
-            for (int h = 0; h < mh; ++h) { s_hb[h][tid] = -1; s_ti[h][tid] = 0.0f; s_to[h][tid] = 0.0f; }
+            for (int h = 0; h < SETUP_MAXH; ++h) { s_hb[h][tid] = -1; s_t[h][tid] = make_float2(0.0f, 0.0f); }
             int cnt = 0;
             for (int m = 0; m < a.M; ++m) {
                 const float* b = a.box + m * 15;
@@ -420,15 +423,13 @@ __global__ __launch_bounds__(256) void k_ray_setup(const RaySetupArgs a)
                 if (tmin <= tmax) {             // k_bbox_hits' insertion: the max_hits nearest, ascending (t_in, box index)
                     const int n = cnt < mh ? cnt : mh;
                     int pos = n;
-                    while (pos > 0 && s_ti[pos - 1][tid] > tmin) --pos;
+                    while (pos > 0 && s_t[pos - 1][tid].x > tmin) --pos;
                     if (pos < mh) {
                         for (int k = (n < mh ? n : mh - 1); k > pos; --k) {
-                            s_ti[k][tid] = s_ti[k - 1][tid];
-                            s_to[k][tid] = s_to[k - 1][tid];
+                            s_t[k][tid] = s_t[k - 1][tid];
                             s_hb[k][tid] = s_hb[k - 1][tid];
                         }
-                        s_ti[pos][tid] = tmin;
-                        s_to[pos][tid] = tmax;
+                        s_t[pos][tid] = make_float2(tmin, tmax);
                         s_hb[pos][tid] = m;
                     }
                     ++cnt;
@@ -437,40 +438,68 @@ __global__ __launch_bounds__(256) void k_ray_setup(const RaySetupArgs a)
             a.hit_count[r] = cnt;
             const int kept = cnt < mh ? cnt : mh;
             for (int h = 0; h < mh; ++h) {
-                *reinterpret_cast<float2*>(a.hit_t + (r * mh + h) * 2) = make_float2(s_ti[h][tid], s_to[h][tid]);
+                *reinterpret_cast<float2*>(a.hit_t + (r * mh + h) * 2) = s_t[h][tid];
                 a.hit_box[r * mh + h] = s_hb[h][tid];
             }
             if (a.hull && kept > 0) {           // k_restrict_rays: the hull of the kept intervals replaces [near, far]
-                float lo = s_ti[0][tid], hi = s_to[0][tid];
+                float lo = s_t[0][tid].x, hi = s_t[0][tid].y;
                 for (int h = 1; h < kept; ++h) {
-                    lo = fminf(lo, s_ti[h][tid]);
-                    hi = fmaxf(hi, s_to[h][tid]);
+                    lo = fminf(lo, s_t[h][tid].x);
+                    hi = fmaxf(hi, s_t[h][tid].y);
                 }
                 nr = lo; fr = hi;
             }
             s_nr[tid] = nr; s_fr[tid] = fr; s_cnt[tid] = kept;
         }
         __syncthreads();
-        for (int rr = 0; rr < 64; ++rr) {
-            const int t = wv * 64 + rr;
-            const int64_t ray = base + t;
-            if (ray >= a.R) break;                      // wave-uniform
-            const float nr = s_nr[t], fr = s_fr[t];
-            const int cnt = s_cnt[t];
-            for (int i = lane; i < N; i += 64) {
-                const int64_t s = ray * N + i;
-                const float zz = strat_sample(nr, fr, i, N, a.lindisp, a.t_rand ? a.t_rand + s : nullptr);
-                a.z[s] = zz;
-                if (a.label_sem) {
-                    const int best = label_hit(zz, cnt, [&](int h, float& ti, float& to) { ti = s_ti[h][t]; to = s_to[h][t]; });
-                    int ls = -1, li = -1;
-                    if (best >= 0) {
-                        const int m = s_hb[best][t];
-                        ls = a.box_ids[m * 2];
-                        li = a.box_ids[m * 2 + 1];
+        // Phase 2: each of the four waves takes 16 of the 64 rays, one ray in hand at a time.  Everything a ray needs from LDS is
+        // requested for RU rays at once (wave-uniform addresses: broadcast reads), so the chains overlap; the hit loop runs over
+        // registers with the ray's own (wave-uniform) count.
+        constexpr int RU = 2;
+        for (int rr = wv * 16; rr < wv * 16 + 16; rr += RU) {
+            if (base + rr >= a.R) break;                            // wave-uniform
+            float nr[RU], fr[RU];
+            int cnt[RU], hb[RU][SETUP_MAXH];
+            float2 iv[RU][SETUP_MAXH];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int t = rr + u;
+                // wave-uniform values: scalar registers (as vector registers these 26 values per ray set the occupancy)
+                auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+                nr[u] = uni(s_nr[t]); fr[u] = uni(s_fr[t]);
+                cnt[u] = __builtin_amdgcn_readfirstlane(s_cnt[t]);
+#pragma unroll
+                for (int h = 0; h < SETUP_MAXH; ++h) {
+                    const float2 v = s_t[h][t];
+                    iv[u][h] = make_float2(uni(v.x), uni(v.y));
+                    hb[u][h] = __builtin_amdgcn_readfirstlane(s_hb[h][t]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t ray = base + rr + u;
+                if (ray >= a.R) break;                              // wave-uniform
+                for (int i = lane; i < N; i += 64) {
+                    const int64_t s = ray * N + i;
+                    const float zz = strat_sample(nr[u], fr[u], i, N, a.lindisp, a.t_rand ? a.t_rand + s : nullptr);
+                    a.z[s] = zz;
+                    if (a.label_sem) {
+                        int best = -1, m = -1;
+                        float bt = 0.0f;
+#pragma unroll
+                        for (int h = 0; h < SETUP_MAXH; ++h) {      // label_hit, unrolled over registers
+                            if (h >= cnt[u]) break;
+                            const float ti = iv[u][h].x, to = iv[u][h].y;
+                            if (ti <= zz && zz <= to && (best < 0 || ti < bt)) { best = h; bt = ti; m = hb[u][h]; }
+                        }
+                        int ls = -1, li = -1;
+                        if (best >= 0) {
+                            ls = a.box_ids[m * 2];
+                            li = a.box_ids[m * 2 + 1];
+                        }
+                        a.label_sem[s] = ls;
+                        a.label_inst[s] = li;
                     }
-                    a.label_sem[s] = ls;
-                    a.label_inst[s] = li;
                 }
             }
         }
@@ -619,7 +648,7 @@ PNR_EXPORT int pnr_ray_setup(const float* rays, int64_t n_rays, const float* box
     a.rays = rays; a.R = n_rays; a.box = box; a.M = n_box; a.max_hits = max_hits; a.box_ids = box_ids;
     a.N = n_samples; a.lindisp = lindisp; a.hull = hull; a.t_rand = t_rand;
     a.hit_t = hit_t; a.hit_box = hit_box; a.hit_count = hit_count; a.z = z_out; a.label_sem = label_sem; a.label_inst = label_inst;
-    hipLaunchKernelGGL(k_ray_setup, dim3(pnr_grid_cap((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_ray_setup, dim3(pnr_grid_cap((n_rays + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
     PNR_CHECK_LAUNCH("pnr_ray_setup");
     return PNR_OK;
 }

@@ -8,7 +8,7 @@ for cfg in "$@"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
     -fvisibility=hidden -I$R/include -I$C $flags -shared -o $R/build/ab/libpnr_$name.so \
-    $C/*.hip -x hip $C/pnr_api.cpp $C/pnr_mlp_pack.cpp 2>&1 | grep -E "error" &
+    -I$R/build/obj $C/*.hip -x hip $C/pnr_api.cpp $C/pnr_mlp_pack.cpp $C/pnr_mlp_tt.cpp 2>&1 | grep -E "error" &    # build/obj: the two-tile kernel's code object (make all)
 done
 wait
 # the same assembly lint `make all` runs, on the variant's flags (a finding is reported, the library is kept: ablation builds
