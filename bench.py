@@ -602,7 +602,7 @@ def main():
             kname = ("k_mlp_tt<two-tile assembly, fused compositing epilogue, plan 2>" if fused and fdesc.plan == 2 else
                      "k_mlp_pp<fused %scompositing epilogue, plan %d>" % ("softmax " if rend.sem_mode == 1 else "", fdesc.plan) if fused else
                      "k_mlp_pp" if (ops.default_schedule() != 1 and args.precision == "bf16") else "k_mlp_fused")
-            tkey = "k_mlp_pp_fused" if fused else "k_mlp_pp"
+            tkey = ("k_mlp_tt_fused" if fdesc.plan == 2 else "k_mlp_pp_fused") if fused else "k_mlp_pp"
             roofline = {"kernel": "%s (%s level, %d rays x %d samples, %dx%d MLP)" % (kname, "fine" if top else "coarse", Rc, N_TOP, c["D"], c["W"]),
                         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": traffic(tkey, Rc, args.config),

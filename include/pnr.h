@@ -19,6 +19,8 @@
  *   pnr_sample_pdf      sample_pdf + sorted merge with the coarse z       (8a row a7)
  *   pnr_bbox_hits       ray / 3D-bbox intersection (bbox prior)           (8a row a8)
  *   pnr_sample_labels   per-sample fixed semantic / instance labels        (8a row a8)
+ *   pnr_ray_setup       a8 + a3 + a8 of the coarse level in one launch    (8a rows a3, a8)
+ *   pnr_sample_pdf_labels   a7 + a8 of the fine level in one launch       (8a rows a7, a8)
  *
  * Conventions:
  *   - every pointer is a DEVICE pointer unless the name ends in _host;

@@ -13,9 +13,9 @@ def kernel_stats(path):
     print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'pct':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
     for r in rows[:14]:
         print(f"{r[0][:72]:72s} {r[1]:6d} {r[2] / 1e6:10.3f} {100 * r[2] / tot:6.2f} {r[3] / 1e3:10.1f} {r[4] / 1e3:10.1f} {r[5] / 1e3:10.1f}")
-    # the bench's dominant launch: fine-level MLP chunks are the longest k_mlp_fused dispatches
+    # the bench's dominant launch: fine-level MLP chunks are the longest k_mlp_tt / k_mlp_pp / k_mlp_fused dispatches
     big = cur.execute("select (end-start)/1e3, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                      "from kernels where (name like '%k_mlp_fused%' or name like '%k_mlp_pp%') order by 1 desc").fetchall()
+                      "from kernels where (name like '%k_mlp_fused%' or name like '%k_mlp_pp%' or name like '%k_mlp_tt%') order by 1 desc").fetchall()
     if big:
         top = [b for b in big if b[0] > 0.7 * big[0][0]]
         print(f"fused MLP fine-level chunk launches (>70% of longest): n={len(top)} avg={sum(b[0] for b in top) / len(top):.1f} us "

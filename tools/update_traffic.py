@@ -22,12 +22,13 @@ fetch_db, write_db, note = sys.argv[1:4]
 trace_db = sys.argv[4] if len(sys.argv) > 4 else None
 sys.path.insert(0, ROOT)
 from panopticnerf_amd.renderer import chunk_plan      # the largest dispatch of a full frame is the renderer's first chunk
-LAUNCH_RAYS = {"k_mlp_pp_fused": chunk_plan(1408 * 376, 65536)[0][1], "k_composite": 65536}
+LAUNCH_RAYS = {"k_mlp_pp_fused": chunk_plan(1408 * 376, 65536)[0][1], "k_mlp_tt_fused": chunk_plan(1408 * 376, 65536)[0][1], "k_composite": 65536}
 try:      # kernels that did not run in these passes keep their last recorded entry (e.g. k_composite when the step is fused)
     out = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
 except (OSError, ValueError):
     out = {}
-for key, pat in (("k_mlp_pp_fused", "%k_mlp_pp%"), ("k_composite", "%k_composite<true, 64%")):
+# the fused MLP launch of the profiled frames: the two-tile assembly kernel where the geometry has it (round 5), else the ping-pong kernel
+for key, pat in (("k_mlp_tt_fused", "%k_mlp_tt%"), ("k_mlp_pp_fused", "%k_mlp_pp%"), ("k_composite", "%k_composite<true, 64%")):
     f, w = biggest(fetch_db, "FETCH_SIZE", pat), biggest(write_db, "WRITE_SIZE", pat)
     if f is None or w is None:
         continue
