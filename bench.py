@@ -663,9 +663,9 @@ def main():
                         extra.setdefault("recorded_on_builder_box", {"note": "rocprofv3 kernel-trace averages of the committed profile of this bench command, measured on "
                                                                              "the builder's box (another MI355X, another power / clock state) -- NOT this run; this run's own "
                                                                              "numbers are roofline_composite[_coarse].{achieved, frac}"})["k_composite" if N == 192 else "k_composite_coarse"] = rec
-                # the pure-read probe walks the image 4 samples per lane; it is a ceiling only where that mapping is the kernel's
-                if read_gbs > gbs:
-                    out.update(pure_read_same_pattern_gbs=round(read_gbs, 1), frac_of_pure_read=round(gbs / read_gbs, 4))
+                # the pure-read probe walks the image in the mapping pnr_composite uses at this N (4 samples per lane; 8 lanes x 8
+                # samples for 32 < N <= 64, round 5): what HBM delivers for the pattern with no arithmetic
+                out.update(pure_read_same_pattern_gbs=round(read_gbs, 1), frac_of_pure_read=round(gbs / read_gbs, 4))
                 return out
 
             # weights are written where the renderer needs them: the coarse level of a coarse+fine render (sample_pdf input)

@@ -33,6 +33,11 @@ int pnrb_time_mlp_forward_tiles(const pnr_mlp_desc* desc, const void* packed, co
  * (random_operands = 0) or with pseudo-random operands that change from MFMA to MFMA (1: the toggle rate of real data -- on
  * MI355X the clock then drops from ~2.37 to ~1.83 GHz and the rate from ~2.46 to ~1.83 PFLOP/s).  scratch: >= 32 device bytes. */
 int pnrb_probe_mfma_peak(int random_operands, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host, void* stream);
+
+/* The same loop on random operands with the ORDER of operand changes as the variable (0: both change every MFMA; 1: the two-tile
+ * kernel's (b0,t0) (b0,t1) (b1,t0) (b1,t1); 2: the snake (b0,t0) (b0,t1) (b1,t1) (b1,t0); 3: only A changes; 4: only B changes):
+ * what the part's power limit makes of operand toggling.  Synchronises the stream. */
+int pnrb_probe_mfma_order(int pattern, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host, void* stream);
 /* What HBM delivers for k_composite's own access pattern with no arithmetic: a pure read of the channel-major raw image, per
  * wave the 8 channel rows of a batch of one ray, 8 loads in flight.  scratch: >= 1 KiB. */
 int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,

@@ -18,6 +18,7 @@ SIGNATURES = {
     "pnrb_time_mlp_forward": (c_int, [ctypes.POINTER(_lib.MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_i64, c_i64, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_time_mlp_forward_tiles": (c_int, [ctypes.POINTER(_lib.MlpDesc), c_f, c_f, c_f, c_i64, c_int, c_f, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_mfma_peak": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
+    "pnrb_probe_mfma_order": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, _fp, c_f]),
     "pnrb_proto_two_tile_image_bytes": (c_i64, []),
     "pnrb_proto_two_tile": (c_int, [c_f, c_i64, c_int, c_int, c_f, _fp, _fp, _fp, c_f]),
@@ -87,6 +88,18 @@ def time_mlp_forward_tiles(desc, packed, rays, z, iters=5):
         _check(load().pnrb_time_mlp_forward_tiles(ctypes.byref(desc), _p(packed), _p(rays), _p(z), R, N, _p(ws), int(iters), _p(scratch),
                                                   ctypes.byref(ms), ctypes.byref(mhz), _stream()), "pnrb_time_mlp_forward_tiles")
     return float(ms.value), float(mhz.value)
+
+
+def probe_mfma_order(pattern, iters=12000, device=None):
+    """(TFLOP/s, shader MHz) of the register-only bf16 MFMA loop on random operands with operand-change order `pattern`
+    (pnrb_probe_mfma_order: 0 both change every MFMA, 1 the two-tile order, 2 the snake, 3 only A changes, 4 only B)."""
+    dev = torch.device(device if device is not None else "cuda")
+    tf, mhz = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    with torch.cuda.device(dev):
+        scratch = torch.zeros(4, device=dev, dtype=torch.int64)
+        _check(load().pnrb_probe_mfma_order(int(pattern), int(iters), _p(scratch), ctypes.byref(tf), ctypes.byref(mhz), _stream()),
+               "pnrb_probe_mfma_order")
+    return float(tf.value), float(mhz.value)
 
 
 def probe_mfma_peak(random_operands, iters=20000, device=None):

@@ -191,6 +191,102 @@ PNR_EXPORT int pnrb_probe_mfma_peak(int random_operands, int iters, void* scratc
     return PNR_OK;
 }
 
+// pnrb_probe_mfma_order: the same register-only loop on random operands, with the ORDER in which the operands change from MFMA to
+// MFMA as the variable (the part is power-limited and the power of an MFMA depends on what toggles at its inputs).  A k-step of a
+// two-block x two-tile unit is four MFMAs on four accumulators, A = a weight fragment (block b), B = an activation slice (tile t):
+//   0  every MFMA has a new A and a new B (k_mfma_peak<true>)
+//   1  (b0,t0) (b0,t1) (b1,t0) (b1,t1): k_mlp_tt's order -- A changes twice, B four times per k-step
+//   2  (b0,t0) (b0,t1) (b1,t1) (b1,t0): the "snake" -- A twice, B three times
+//   3  A changes every MFMA, B never        4  B changes every MFMA, A never
+template <int PATTERN>
+__global__ __launch_bounds__(512) void k_mfma_order(unsigned long long* out, int iters)
+{
+    f32x16 acc[4] = {};
+    bf16x8 a[8], b[8];
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int k = 0; k < 8; ++k)
+        for (int i = 0; i < 8; ++i) {
+            h = h * 1664525u + 1013904223u;
+            a[k][i] = (__bf16)(((int)(h >> 9) & 0xffff) / 32768.0f - 1.0f);
+            h = h * 1664525u + 1013904223u;
+            b[k][i] = (__bf16)(((int)(h >> 9) & 0xffff) / 32768.0f - 1.0f);
+        }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (A index, B index) of the k-step's four MFMAs; accumulator = (block, tile) in patterns 1 and 2
+            constexpr int P = PATTERN;
+            const int a0 = 2 * k, a1 = 2 * k + 1, b0 = 2 * k, b1 = 2 * k + 1;
+            if constexpr (P == 0) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[b0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[b1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(a0 + 3) & 7], b[(b0 + 5) & 7], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(a1 + 3) & 7], b[(b1 + 5) & 7], acc[3], 0, 0, 0);
+            } else if constexpr (P == 1) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[b0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[b1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[b0], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[b1], acc[3], 0, 0, 0);
+            } else if constexpr (P == 2) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[b0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[b1], acc[1], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[b1], acc[3], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[b0], acc[2], 0, 0, 0);
+            } else if constexpr (P == 3) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a0], b[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[a1], b[0], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(a0 + 3) & 7], b[0], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(a1 + 3) & 7], b[0], acc[3], 0, 0, 0);
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[b0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[b1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[(b0 + 5) & 7], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[(b1 + 5) & 7], acc[3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) out[2] = 1;
+}
+
+PNR_EXPORT int pnrb_probe_mfma_order(int pattern, int iters, void* scratch, float* tflops_out_host, float* mhz_out_host, void* stream)
+{
+    PNR_REQUIRE(iters >= 1 && scratch && tflops_out_host && mhz_out_host && pattern >= 0 && pattern <= 4, "pnrb_probe_mfma_order: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    PNR_HIP(hipGetDevice(&dev));
+    PNR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipEvent_t e0, e1;
+    PNR_HIP(hipEventCreate(&e0));
+    PNR_HIP(hipEventCreate(&e1));
+    unsigned long long* out = (unsigned long long*)scratch;
+    for (int rep = 0; rep < 2; ++rep) {
+        PNR_HIP(hipEventRecord(e0, st));
+        switch (pattern) {
+        case 0: hipLaunchKernelGGL(k_mfma_order<0>, dim3(cus), dim3(512), 0, st, out, iters); break;
+        case 1: hipLaunchKernelGGL(k_mfma_order<1>, dim3(cus), dim3(512), 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL(k_mfma_order<2>, dim3(cus), dim3(512), 0, st, out, iters); break;
+        case 3: hipLaunchKernelGGL(k_mfma_order<3>, dim3(cus), dim3(512), 0, st, out, iters); break;
+        default: hipLaunchKernelGGL(k_mfma_order<4>, dim3(cus), dim3(512), 0, st, out, iters); break;
+        }
+        PNR_CHECK_LAUNCH("pnrb_probe_mfma_order");
+        PNR_HIP(hipEventRecord(e1, st));
+        PNR_HIP(hipEventSynchronize(e1));
+    }
+    float ms = 0.0f;
+    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2] = {0, 1};
+    PNR_HIP(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+    *tflops_out_host = (float)((double)iters * 16.0 * 2.0 * 32 * 32 * 16 * 8 * cus / (ms * 1e-3) / 1e12);
+    *mhz_out_host = h[1] ? (float)(100.0 * (double)h[0] / (double)h[1]) : 0.0f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PNR_OK;
+}
+
 // pnrb_probe_raw_read: a pure read of a channel-major raw image in k_composite's own order (per wave: the 8 channel rows of
 // a batch of one ray, N/4 lanes x 16 B each, 8 loads in flight, 8 waves per SIMD) -- what HBM delivers for this access
 // pattern with no arithmetic at all.  bench.py quotes k_composite against it next to the 8 TB/s datasheet peak.
@@ -215,6 +311,32 @@ __global__ __launch_bounds__(256) void k_raw_read(const float* raw, int64_t sc, 
 }
 
 // raw (n_channels, R*N) channel-major with channel stride raw_stride_c, N % 4 == 0, N <= 256.  gbs_out: host float.
+// the same for k_composite2's mapping at 32 < N <= 64: 8 lanes per ray x 8 consecutive samples (two float4 loads per lane and channel
+// row), 8 rays per wave, 8 rows in flight
+__global__ __launch_bounds__(256) void k_raw_read2(const float* raw, int64_t sc, int64_t R, int N, int CH, float* sink)
+{
+    const int lane = threadIdx.x & 63, q = lane & 7, g = lane >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.0f;
+    for (int64_t grp = wave; grp < (R + 7) / 8; grp += n_waves) {
+        const int64_t ray = grp * 8 + g;
+        const bool a0 = ray < R && q * 8 < N, a1 = ray < R && q * 8 + 4 < N;
+        const float* p = raw + (ray < R ? ray : R - 1) * N + (a0 ? q * 8 : 0);
+        for (int c0 = 0; c0 < CH; c0 += 8) {
+            float4 v[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = c0 + j < CH;
+                v[j][0] = (a0 && in) ? *reinterpret_cast<const float4*>(p + (int64_t)(c0 + j) * sc) : make_float4(0, 0, 0, 0);
+                v[j][1] = (a1 && in) ? *reinterpret_cast<const float4*>(p + (int64_t)(c0 + j) * sc + 4) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += ((v[j][0].x + v[j][0].y) + (v[j][0].z + v[j][0].w)) + ((v[j][1].x + v[j][1].y) + (v[j][1].z + v[j][1].w));
+        }
+    }
+    if (acc == 12345.678f) sink[threadIdx.x] = acc;
+}
+
 PNR_EXPORT int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels,
                                   int iters, void* scratch, float* gbs_out_host, void* stream)
 {
@@ -224,11 +346,14 @@ PNR_EXPORT int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64
     hipEvent_t e0, e1;
     PNR_HIP(hipEventCreate(&e0));
     PNR_HIP(hipEventCreate(&e1));
-    const int grid = pnr_grid_cap((n_rays + 3) / 4, 8);
-    hipLaunchKernelGGL(k_raw_read, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
+    // the mapping pnr_composite uses at this N: 8 lanes x 8 samples for 32 < N <= 64 (k_composite2), else 4 samples per lane
+    const bool second = n_samples > 32 && n_samples <= 64 && (n_samples % 8) == 0;
+    const int grid = pnr_grid_cap(second ? (n_rays + 31) / 32 : (n_rays + 3) / 4, 8);
+    auto kern = second ? k_raw_read2 : k_raw_read;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
     PNR_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(k_raw_read, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
     PNR_CHECK_LAUNCH("pnrb_probe_raw_read");
     PNR_HIP(hipEventRecord(e1, st));
     PNR_HIP(hipEventSynchronize(e1));
