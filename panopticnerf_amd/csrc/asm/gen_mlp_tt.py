@@ -26,6 +26,12 @@ import struct
 import sys
 from contextlib import contextmanager
 
+import os
+# Cache policy of the LDS-DMA weight pieces: the DEFAULT one.  With " nt" (what k_mlp_pp uses, -1 % there) this kernel's weight stream
+# missed the L2 for 20 % of its 69 GB per fine-level launch -- 13.8 GB of fabric traffic per launch (rocprofv3 FETCH_SIZE; k_mlp_pp: 2.1 GB,
+# the default policy: 0.09 GB) -- and the part paid for it in clock: 11.5 ms at 1773-1793 MHz with nt, 10.66 ms at 1863-1877 MHz without
+# (same box, profiles/r05p).  tools/build_tt_variant.sh builds A/B variants (PNR_TT_DMA_POLICY=" nt" | " sc0" | " sc1").
+DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)
 NSLOT, SLOT = 4, 33 * 1024
@@ -317,7 +323,7 @@ class Gen:
             self.e("s_add_u32 m0, s%d, 0x%x" % (S_W4K, m0))
             self.e("s_nop 0")                   # SALU write of M0 -> LDS-DMA: one wait state
         self.m0 = None if skip else m0          # (a guarded piece: the waves that skipped it did not write M0)
-        tag = self.vm_op("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d nt" % (V_DMA + m, S_PIECE, S_PIECE + 1, i * 1024), certain)
+        tag = self.vm_op("global_load_lds_dwordx4 v%d, s[%d:%d] offset:%d%s" % (V_DMA + m, S_PIECE, S_PIECE + 1, i * 1024, DMA_POLICY), certain)
         if skip:
             self.o.append(skip + ":")
         return tag
