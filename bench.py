@@ -620,11 +620,19 @@ def main():
                 rec_b = 4 * (((1 + N_SEM + N_INST) + 3) // 4 * 4)
                 alg = S * (16 + 4) + (S // 32) * rec_b
                 roofline["traffic_algorithmic"] = alg
-                roofline["traffic_note"] = ("%.1fx the algorithmic %.2f GB: the weight pieces are requested with the `nt` policy, so ~3 %% of the 69 GB "
-                                            "L2 -> LDS weight stream misses the L2 and is re-fetched over the fabric (0.2 TB/s: nowhere near a bound). "
-                                            "Same-box A/B (profiles/r04j): nt 10.97-11.08 ms at 1800-1813 MHz, default policy 11.17 ms at 1823-1830 "
-                                            "MHz -- the extra traffic costs ~1 %% of clock and the launch is still 1.0-1.8 %% faster; with the default "
-                                            "policy the launch moved 1.07x its algorithmic bytes (profiles/r03d)" % (roofline["traffic"] / alg, alg / 1e9))
+                ratio = roofline["traffic"] / alg
+                if fdesc.plan == 2:
+                    roofline["traffic_note"] = ("%.2fx the algorithmic %.2f GB: k_mlp_tt requests its weight pieces with the DEFAULT cache policy and the 69 GB "
+                                                "L2 -> LDS weight stream stays in the L2.  With `nt` (what k_mlp_pp uses) 20 %% of that stream missed the L2 -- "
+                                                "13.8 GB of fabric traffic per launch, 37x the algorithmic bytes -- and the power-limited part answered with a lower "
+                                                "clock: same-box A/Bs profiles/r05p, r05q: 10.6-10.7 ms at 1818-1877 MHz without nt, 11.3-11.5 ms at 1773-1798 MHz "
+                                                "with it" % (ratio, alg / 1e9))
+                else:
+                    roofline["traffic_note"] = ("%.1fx the algorithmic %.2f GB: k_mlp_pp requests its weight pieces with the `nt` policy, so ~3 %% of the 69 GB "
+                                                "L2 -> LDS weight stream misses the L2 and is re-fetched over the fabric (0.2 TB/s).  Same-box A/Bs: nt "
+                                                "10.97-11.08 ms against 11.17 ms with the default policy in round 4 (profiles/r04j), a wash in round 5 "
+                                                "(profiles/r05q: 1087-1089 against 1083-1094 Msamples/s); with the default policy the launch moves 1.07x its "
+                                                "algorithmic bytes (profiles/r03d)" % (ratio, alg / 1e9))
             if fused or (ops.default_schedule() != 1 and args.precision == "bf16"):
                 # the weight stream of the same launch: every workgroup (256 samples: 8 waves x one 32-sample tile in registers)
                 # streams the whole packed image L2 -> LDS by LDS-DMA once per group.  NOT a ceiling: reported next to what the
