@@ -153,13 +153,17 @@ struct PdfLabelArgs {
 };
 #define PDF_MAXC 256
 #define PDF_MAXT 512
-__global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, const float* __restrict__ weights,
+template <int MAXC, int MAXT>
+__device__ __forceinline__ void sample_pdf_body(const float* __restrict__ z, const float* __restrict__ weights,
                                                     const float* __restrict__ u, int64_t R, int Nc, int Nf,
                                                     float* __restrict__ zs_out, int32_t* __restrict__ inds_out,
                                                     float* __restrict__ zfine_out, const PdfLabelArgs lab)
 {
-    __shared__ float s_z[PDF_MAXC], s_w[PDF_MAXC], s_pdf[PDF_MAXC], s_cdf[PDF_MAXC], s_bins[PDF_MAXC];
-    __shared__ float s_sort[PDF_MAXT], s_out[PDF_MAXT];
+    // MAXC / MAXT: the LDS footprint sets how many rays a CU has in flight, and this kernel is all latency (dependent LDS searches,
+    // a dozen barriers per ray): 9.4 KiB per ray held 17 waves per CU, the <64, 256> instance (64 + 128 samples: every BASELINE
+    // config) 3.4 KiB holds the CU's 32
+    __shared__ float s_z[MAXC], s_w[MAXC], s_pdf[MAXC], s_cdf[MAXC], s_bins[MAXC];
+    __shared__ float s_sort[MAXT], s_out[MAXT];
     __shared__ float s_total, s_part[32];
     const int lane = threadIdx.x;
     const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
@@ -318,6 +322,21 @@ __global__ __launch_bounds__(64) void k_sample_pdf(const float* __restrict__ z, 
         }
         __syncthreads();
     }
+}
+
+// two instances: <64, 256> (64 + 128 samples: every BASELINE config) at 64 registers and 3.4 KiB of LDS holds 8 waves per SIMD; the
+// general one (up to 256 + 256 samples) is bound by its 9.1 KiB of LDS per ray
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_sample_pdf(const float* __restrict__ z, const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
+                  float* __restrict__ zs_out, int32_t* __restrict__ inds_out, float* __restrict__ zfine_out, const PdfLabelArgs lab)
+{
+    sample_pdf_body<64, 256>(z, weights, u, R, Nc, Nf, zs_out, inds_out, zfine_out, lab);
+}
+__global__ __launch_bounds__(64)
+void k_sample_pdf_big(const float* __restrict__ z, const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
+                      float* __restrict__ zs_out, int32_t* __restrict__ inds_out, float* __restrict__ zfine_out, const PdfLabelArgs lab)
+{
+    sample_pdf_body<PDF_MAXC, PDF_MAXT>(z, weights, u, R, Nc, Nf, zs_out, inds_out, zfine_out, lab);
 }
 
 // ------------------------------------------------------------------------------- a8
@@ -593,6 +612,19 @@ PNR_EXPORT int pnr_embed(const float* x, int64_t n, int L, float* out, void* str
     return PNR_OK;
 }
 
+static void launch_sample_pdf(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse, int n_fine,
+                              float* z_samples, int32_t* inds, float* z_fine, const PdfLabelArgs& lab, hipStream_t st)
+{
+    int P = 1;
+    while (P < n_coarse + n_fine) P <<= 1;              // the bitonic path pads the union to a power of two
+    if (n_coarse <= 64 && P <= 256)
+        hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, st, z, weights, u, n_rays, n_coarse, n_fine,
+                           z_samples, inds, z_fine, lab);
+    else
+        hipLaunchKernelGGL(k_sample_pdf_big, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, st, z, weights, u, n_rays, n_coarse,
+                           n_fine, z_samples, inds, z_fine, lab);
+}
+
 PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float* u, int64_t n_rays, int n_coarse,
                               int n_fine, float* z_samples, int32_t* inds, float* z_fine, void* stream)
 {
@@ -603,8 +635,7 @@ PNR_EXPORT int pnr_sample_pdf(const float* z, const float* weights, const float*
     if (n_rays <= 0) return PNR_OK;
     PdfLabelArgs lab;
     memset(&lab, 0, sizeof(lab));
-    hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, (hipStream_t)stream,
-                       z, weights, u, n_rays, n_coarse, n_fine, z_samples, inds, z_fine, lab);
+    launch_sample_pdf(z, weights, u, n_rays, n_coarse, n_fine, z_samples, inds, z_fine, lab, (hipStream_t)stream);
     PNR_CHECK_LAUNCH("pnr_sample_pdf");
     return PNR_OK;
 }
@@ -623,8 +654,7 @@ PNR_EXPORT int pnr_sample_pdf_labels(const float* z, const float* weights, const
     PdfLabelArgs lab;
     lab.hit_t = hit_t; lab.hit_box = hit_box; lab.hit_count = hit_count; lab.max_hits = max_hits; lab.box_ids = box_ids;
     lab.label_sem = label_sem; lab.label_inst = label_inst;
-    hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, (hipStream_t)stream,
-                       z, weights, u, n_rays, n_coarse, n_fine, (float*)nullptr, (int32_t*)nullptr, z_fine, lab);
+    launch_sample_pdf(z, weights, u, n_rays, n_coarse, n_fine, nullptr, nullptr, z_fine, lab, (hipStream_t)stream);
     PNR_CHECK_LAUNCH("pnr_sample_pdf_labels");
     return PNR_OK;
 }
