@@ -34,7 +34,7 @@ import os
 DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)
-NSLOT, SLOT = 4, 33 * 1024
+NSLOT, SLOT = 4, int(os.environ.get("PNR_TT_SLOT_KIB", "33")) * 1024      # (A/B builds: the slot stride, tools/build_tt_variant.sh)
 P = 4                                   # fragment ring (quads)
 D, SKIP = 8, 4
 
