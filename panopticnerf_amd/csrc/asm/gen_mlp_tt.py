@@ -35,6 +35,12 @@ DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)
 NSLOT, SLOT = 4, int(os.environ.get("PNR_TT_SLOT_KIB", "33")) * 1024      # (A/B builds: the slot stride, tools/build_tt_variant.sh)
+ACC_PERM = [int(x) for x in os.environ.get("PNR_TT_ACC_PERM", "0,1,2,3,4,5,6,7").split(",")]     # register block of accumulator i (A/B builds)
+SLOT_POS = [int(x) for x in os.environ.get("PNR_TT_SLOT_ORDER", "0,1,2,3").split(",")]      # physical position of logical slot c % 4
+
+
+def slot_base(sl):
+    return SLOT_POS[sl] * SLOT
 P = 4                                   # fragment ring (quads)
 D, SKIP = 8, 4
 
@@ -318,7 +324,7 @@ class Gen:
             self.e("s_cbranch_scc1 %s" % skip)
         # the instruction's immediate offset moves BOTH addresses (memory and LDS): M0 carries the run's base only -- and stays
         # what it is for the four pieces of a run (nothing else in the loop writes M0; trace builds do)
-        m0 = slot * SLOT + 16 * m * 1024
+        m0 = slot_base(slot) + 16 * m * 1024
         if self.m0 != m0 or skip or self.trace:
             self.e("s_add_u32 m0, s%d, 0x%x" % (S_W4K, m0))
             self.e("s_nop 0")                   # SALU write of M0 -> LDS-DMA: one wait state
@@ -810,7 +816,7 @@ class Gen:
 
     # ------------------------------------------------------------------ accumulators
     def acc_reg(self, i):
-        return V_ACC + 16 * i
+        return V_ACC + 16 * ACC_PERM[i]
 
     def acc_take(self, n):
         assert len(self.acc_free) >= n, ("accumulators exhausted", self.acc_free)
@@ -843,7 +849,7 @@ class Gen:
                 if l["mode"] == "logits":       # transposed product: every register = bias of channel lane & 31
                     def first(key=key, slot=slot, take=take):           # the address lives in the accumulator's first register, read last
                         take()
-                        self.e("v_add_u32 v%d, 0x%x, v%d" % (self.acc_reg(u["accs"][key]), slot * SLOT, V_LB4))
+                        self.e("v_add_u32 v%d, 0x%x, v%d" % (self.acc_reg(u["accs"][key]), slot_base(slot), V_LB4))
                     ops.append(first)
                     for r in list(range(1, 16)) + [0]:
                         ops.append(lambda key=key, r=r, off=bias_off + b_in_chunk * 128: u["arm_tags"].append(
@@ -1235,7 +1241,7 @@ class Gen:
         e("v_and_b32 v%d, 1, v%d" % (V_LB4, V_LB4))
         e("v_lshlrev_b32 v%d, 4, v%d" % (V_LB4, V_LB4))                  # hi * 16
         for sl in range(NSLOT):
-            self.lit(S_T0, sl * SLOT)
+            self.lit(S_T0, slot_base(sl))
             e("v_add_u32 v%d, s%d, v%d" % (V_FRAG + sl, S_T0, V_LANE16))
             e("v_add_u32 v%d, s%d, v%d" % (V_BIAS + sl, S_T0, V_LB4))
         for k in range(3):
