@@ -630,9 +630,9 @@ def main():
                 else:
                     roofline["traffic_note"] = ("%.1fx the algorithmic %.2f GB: k_mlp_pp requests its weight pieces with the `nt` policy, so ~3 %% of the 69 GB "
                                                 "L2 -> LDS weight stream misses the L2 and is re-fetched over the fabric (0.2 TB/s).  Same-box A/Bs: nt "
-                                                "10.97-11.08 ms against 11.17 ms with the default policy in round 4 (profiles/r04j), a wash in round 5 "
+                                                "10.97-11.08 ms against 11.17 ms with the default policy in round 4 (profiles/r04/r04j), a wash in round 5 "
                                                 "(profiles/r05q: 1087-1089 against 1083-1094 Msamples/s); with the default policy the launch moves 1.07x its "
-                                                "algorithmic bytes (profiles/r03d)" % (ratio, alg / 1e9))
+                                                "algorithmic bytes (profiles/r03/r03d)" % (ratio, alg / 1e9))
             if fused or (ops.default_schedule() != 1 and args.precision == "bf16"):
                 # the weight stream of the same launch: every workgroup (256 samples: 8 waves x one 32-sample tile in registers)
                 # streams the whole packed image L2 -> LDS by LDS-DMA once per group.  NOT a ceiling: reported next to what the

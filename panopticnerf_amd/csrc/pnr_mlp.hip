@@ -533,7 +533,7 @@ __device__ __forceinline__ void pp_layer_out(CTX& c, u32x4 (&A)[CTX::P], const u
 // head_W = 128), block b < NBS from the semantic head's hidden activations, the others from the instance head's.  One
 // M phase of 8 (NBS + NBI) MFMAs on NBS + NBI interleaved accumulator chains instead of NBS + NBI single-chain chunks of 8
 // whose L phases (refill of a full-size chunk each, prologue, epilogue) nothing covered: 4400 + 2300 cycles per sample group
-// in the per-chunk trace (profiles/r03a) for 1536 cycles of MFMA.
+// in the per-chunk trace (profiles/r03/r03a) for 1536 cycles of MFMA.
 template <int FB, int KS>
 struct PPLogitsGeom {       // fragments of the chunk in consumption order i = ks * FB + b (block-major in the image)
     static constexpr int NF = FB * KS, BIAS_OFF = FB * KS * PNR_FRAG_BYTES;

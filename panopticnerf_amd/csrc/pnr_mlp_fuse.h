@@ -10,7 +10,7 @@
 // sigmoid(rgb_i)}, the fixed (bbox-prior) fields = histogram of w over the labels, logits_c = sum_k T_k S_c(k).
 // Round 2 also reduced acc / depth / rgb and the label histogram per tile inside this epilogue (five 32-lane butterflies,
 // three sigmoids, LDS atomics, 32 B of stores): ~2700 cycles of an L phase whose partner group has only the 24 MFMAs of the
-// rgb / sigma chunk to run -- exposed twice per sample group (per-chunk trace, profiles/r03a).  Everything that is O(1) per
+// rgb / sigma chunk to run -- exposed twice per sample group (per-chunk trace, profiles/r03/r03a).  Everything that is O(1) per
 // sample went to the combine kernel, where it costs nothing that matters; what stays here is what needs the logits in registers.
 // Same formulas as k_composite (pnr_composite.hip; no reference file is mounted): alpha = 1 - exp(-relu(sigma)
 // * dist * |d|), dist = z_{i+1} - z_i, 1e10 for the ray's last sample.  The sums are associated differently than in
