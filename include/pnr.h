@@ -152,11 +152,12 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
 /* Chunk order for images that only pnr_mlp_forward_composite will consume: the BEST plan `desc`'s geometry has.
  *   1: the fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then
  *      BOTH head hidden layers, then the two logit layers as ONE chunk (k_mlp_pp: 8 waves, one 32-sample tile per wave);
- *   2: the two-tile plan (the benched geometry: D = 8, skip = 4, L = 10 / 4, both heads, head_tap 0): no chunk above 33
- *      fragments, consumed by k_mlp_tt -- hand-placed gfx950 assembly, one wave per SIMD, two tiles per wave, every LDS weight
- *      fragment feeds two MFMAs (csrc/asm/gen_mlp_tt.py);
+ *   2: the two-tile plan (the 8 x 256 network of the BASELINE configs: D = 8, skip = 4, L = 10 / 4, head_tap 0; no heads, a
+ *      semantic head of up to 64 classes, or that plus an instance head of up to 32): no chunk above 33 fragments, consumed by
+ *      k_mlp_tt -- hand-placed gfx950 assembly, one wave per SIMD, two tiles per wave, every LDS weight fragment feeds two MFMAs
+ *      (csrc/asm/gen_mlp_tt.py);
  *   0: the classic order, which every entry point accepts.
- * Set desc.plan to the returned value (or to any smaller supported one) before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it
+ * Set desc.plan to the returned value (or to a smaller supported one: plan 1 needs a semantic head) before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it
  * for the forward call.  Same arithmetic per layer under every plan: records and maps are bit-identical. */
 int pnr_mlp_fused_plan(const pnr_mlp_desc* desc);
 int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights);

@@ -11,8 +11,8 @@ Same arithmetic as k_mlp_pp<256, false, FUSE, plan 1> (pnr_mlp.hip, pnr_mlp_fuse
 order per value: outputs (per-tile records, per-sample quadruples) are BIT-IDENTICAL (tests/test_gpu_stages.py).  Consumes the
 plan-2 image (pnr_mlp_plan.h): plan 1's chunk order, every chunk <= 33 fragments, sem1 / inst1 one chunk each.
 
-Geometry (fixed): D = 8, W = 256, skip = 4, xyz_L = 10, dir_L = 4, head_W = 128, head_tap 0; NBS = 1 | 2 semantic and NBI = 0 | 1
-instance logit blocks -> four kernels k_mlp_tt_s<NBS>i<NBI>.
+Geometry (fixed): D = 8, W = 256, skip = 4, xyz_L = 10, dir_L = 4, head_W = 128, head_tap 0; NBS = 0 | 1 | 2 semantic logit blocks, with
+NBS >= 1 also NBI = 0 | 1 instance logit blocks -> five kernels k_mlp_tt_s<NBS>i<NBI> (s0i0: no heads; s<n>i0: no instance head).
 
 Time structure per 256-sample group (one workgroup; tile = (wave, t), record index grp * 8 + wave * 2 + t):
   image chunk c lives in LDS slot c % 4 (33 KiB each); during chunk c every wave issues its LDS-DMA pieces of chunk c + 3; at
@@ -174,10 +174,12 @@ class Gen:
         add("rgbs", 1, [("g", 8), ("hh", 16)], 1, "rgbs")
         # heads: sem0 | inst0 | sem1 | inst1 -- a logit layer never follows its own hidden layer directly (the hidden layer's last
         # blocks would have to be packed inside the logit unit's first MFMA gaps), sem1's reduction runs beside inst1
-        add("sem0", 4, [("hh", 16)], 2, "relu")
+        if self.nbs:
+            add("sem0", 4, [("hh", 16)], 2, "relu")
         if self.nbi:
             add("inst0", 4, [("hh", 16)], 2, "relu")
-        add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
+        if self.nbs:
+            add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
         if self.nbi:
             add("inst1", 1, [("shi", 8)], 1, "logits")
         self.layers = L
@@ -189,6 +191,11 @@ class Gen:
                 self.chunks.append(dict(layer=li, fb=fb, nfb=l["fbc"], off=off, nfrag=nfrag))
                 off += nfrag
         self.total_frags = off
+        # slot = chunk % 4 is static, so a group is a multiple of four chunks: geometries whose image has 42 (no heads) or 45 (no
+        # instance head) chunks get DUMMY chunks at the group's end -- one piece of image fragment 0 into the slot, a hand-over,
+        # no unit.  The image itself is unchanged (pnr_build_plan knows nothing of them)
+        while len(self.chunks) % NSLOT:
+            self.chunks.append(dict(layer=None, fb=0, nfb=0, off=0, nfrag=1, dummy=True))
         self.NC = len(self.chunks)
         assert self.NC % NSLOT == 0, self.NC
         assert max(c["nfrag"] for c in self.chunks) <= 33
@@ -407,6 +414,8 @@ class Gen:
         """the MFMA stream of one group: list of units, each = (chunk, layer, blocks, ...)"""
         U = []
         for ci, c in enumerate(self.chunks):
+            if c.get("dummy"):
+                continue
             l = self.layers[c["layer"]]
             step = 2 if l["mode"] != "logits" else c["nfb"]
             if l["name"] == "rgbs":
@@ -913,7 +922,7 @@ class Gen:
             self.drain_side()                       # (nothing left normally) the early side work uses the g area
         if l["name"] == "views" and u["blocks"] == [1]:
             self.park()
-        if l["name"] == "sem0" and u["blocks"][0] == 0:
+        if l["name"] == ("sem0" if self.nbs else "inst0") and u["blocks"][0] == 0:
             self.unpark()
         if l["name"] == "views" and u["blocks"] == [2]:
             self.g2_acc = self.acc_take(1)[0]       # home of g block 2 (packed during the next unit) until the rgb / sigma unit is issued
@@ -1027,6 +1036,8 @@ class Gen:
             self.queue_inputs_late()
             self.acc_release([self.g2_acc])         # g is dead: every MFMA of the rgb / sigma unit has been issued
             self.g2_acc = None
+            if not self.nbs:                        # no head follows (its first unit would do this): the parked inputs go home
+                self.unpark()
         else:
             # logit blocks keep their accumulators until the group's tail (tail_logits): all blocks of a tile are reduced TOGETHER there,
             # three independent FMA chains beside each other -- one block at a time is a chain of 16 dependent FMAs and two LDS
@@ -1038,6 +1049,21 @@ class Gen:
             if not self.abl & 2:
                 self.wait_vm(self.piece_tag.get(c2))
                 e("s_barrier")
+            # dummy chunks behind the group's last real chunk: their share of the weight stream (the pieces of chunk + 3) and their
+            # hand-over, with whatever side work is queued between the pieces
+            d = u["chunk"] + 1
+            while d < self.NC and self.chunks[d].get("dummy"):
+                e("; ==== dummy chunk %d (slot %d)" % (d, d % NSLOT))
+                c3 = (d + 3) % self.NC
+                for j in ([] if self.abl & 1 else range(self.pieces_of(c3))):
+                    if j == 0:
+                        self.chunk_base(c3)
+                    self.piece_tag[c3] = self.piece(c3, j)
+                    self.drain_side(2)
+                if not self.abl & 2:
+                    self.wait_vm(self.piece_tag.get((d + 2) % self.NC))
+                    e("s_barrier")
+                d += 1
 
     def logit_blocks(self):
         return [(b, False) for b in range(self.nbs)] + [(0, True)] * self.nbi
@@ -1048,6 +1074,8 @@ class Gen:
         exchanges between the half-waves, tile 1's FMAs beside them, then the stores.  Masks and the instance columns' pointers are
         precomputed (S_MSK, S_REC_I)."""
         e = self.e
+        if not self.logit_units:
+            return
         blocks = []
         for u in self.logit_units:
             inst = self.layers[u["layer"]]["name"] == "inst1"
@@ -1391,7 +1419,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
     parts = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 5", ""]
     names = []
-    for nbs, nbi in ((1, 1), (2, 1)):
+    for nbs, nbi in ((1, 1), (2, 1), (0, 0), (1, 0), (2, 0)):
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())

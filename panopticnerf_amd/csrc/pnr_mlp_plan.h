@@ -24,11 +24,14 @@ static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
     const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
     return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1 && pnr_head_depth(d) == 2;
 }
-// plan 2 (the two-tile kernel's image): the geometry its generated kernels exist for -- the benched network
+// plan 2 (the two-tile kernel's image): the geometries its generated kernels exist for -- the 8 x 256 network of BASELINE configs 2..5
+// with no heads, a semantic head of 1..2 logit blocks, or a semantic and a 1-block instance head (csrc/asm/gen_mlp_tt.py)
 #define PNR_PLAN2_MAX_CHUNK_FRAGS 33
 static inline int pnr_plan2_supported(const pnr_mlp_desc& d)
 {
-    return pnr_plan1_supported(d) && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 && d.head_tap == 0 && d.n_inst > 0;
+    const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
+    return d.precision == PNR_PREC_BF16 && d.W == 256 && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 && d.head_tap == 0 &&
+           nbs <= 2 && nbi <= (nbs ? 1 : 0) && (nbs == 0 || (d.head_W == 128 && pnr_head_depth(d) == 2));
 }
 
 #ifndef PNR_PLAN1_TRUNK0_MERGE

@@ -33,8 +33,12 @@ static int tt_table(DevTable*& out)
     if (!t.tried) {
         t.tried = true;
         hipError_t e = hipModuleLoadData(&t.mod, k_co);
-        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[1][1], t.mod, "k_mlp_tt_s1i1");
-        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn[2][1], t.mod, "k_mlp_tt_s2i1");
+        static const int geo[5][2] = {{1, 1}, {2, 1}, {0, 0}, {1, 0}, {2, 0}};      // (semantic, instance) logit blocks of the generated kernels
+        for (int k = 0; k < 5 && e == hipSuccess; ++k) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "k_mlp_tt_s%di%d", geo[k][0], geo[k][1]);
+            e = hipModuleGetFunction(&t.fn[geo[k][0]][geo[k][1]], t.mod, nm);
+        }
         if (e == hipSuccess) e = hipModuleGetFunction(&t.fn_trace[0], t.mod, "k_mlp_tt_s2i1_trace");
         for (int a = 1; a < 8 && e == hipSuccess; ++a) {
             char nm[64];
@@ -62,7 +66,7 @@ int pnr_mlp_tt_prepare(void)
 
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace, int trace_abl)
 {
-    PNR_REQUIRE(nbs >= 1 && nbs <= 2 && nbi == 1, "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
+    PNR_REQUIRE(nbs >= 0 && nbs <= 2 && nbi >= 0 && nbi <= (nbs ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
                 "render in chunks", a.S);
     DevTable* t = nullptr;

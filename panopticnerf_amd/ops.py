@@ -145,7 +145,10 @@ def fused_plan(desc, limit=None):
     environment's PNR_FUSED_PLAN, for A/B runs) caps it."""
     best = int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc)))
     cap = limit if limit is not None else os.environ.get("PNR_FUSED_PLAN")
-    return best if cap is None else min(best, int(cap))
+    if cap is None or int(cap) >= best:
+        return best
+    # below the best plan: plan 1 exists only for networks with a semantic head (the merged logit chunk), else the classic order
+    return 1 if (int(cap) >= 1 and desc.n_sem > 0) else 0
 
 
 def _param_struct(desc, params, device):

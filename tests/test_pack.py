@@ -68,17 +68,20 @@ def test_two_tile_plan_image_matches_the_assembly_generator():
     spec = importlib.util.spec_from_file_location("gen_mlp_tt", os.path.join(root, "panopticnerf_amd", "csrc", "asm", "gen_mlp_tt.py"))
     G = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(G)
-    for C, K in ((45, 32), (19, 8)):
+    for C, K in ((45, 32), (19, 8), (45, 0), (19, 0), (0, 0)):
         net = make_network(NS(num_classes=C, num_instances=K))
         desc = ops.make_desc(n_sem=C, n_inst=K)
-        assert ops.fused_plan(desc, None) == 2 and ops.fused_plan(desc, 1) == 1
+        assert ops.fused_plan(desc, None) == 2 and ops.fused_plan(desc, 1) == (1 if C else 0)
         desc.plan = 2
         img = ops.pack_mlp(desc, net.nerf_0.state_dict())
         im = PackedImage(img)
-        g = G.Gen((C + 31) // 32, 1, "x")
-        assert im.n_chunks == g.NC and g.NC % 4 == 0 and im.max_frags <= 33
-        assert [(int(o), int(n)) for o, n in im.table] == [(c["off"], c["nfrag"]) for c in g.chunks]
-    # no instance head / other depths: no two-tile kernel -> plan 1 or 0
-    assert ops.fused_plan(ops.make_desc(n_sem=45, n_inst=0), None) == 1
+        g = G.Gen((C + 31) // 32, (K + 31) // 32, "x")
+        # the kernel pads its group to a multiple of four chunks with DUMMY chunks (a piece of fragment 0, no unit): not in the image
+        real = [c for c in g.chunks if not c.get("dummy")]
+        assert all(c.get("dummy") for c in g.chunks[len(real):]) and all((c["off"], c["nfrag"]) == (0, 1) for c in g.chunks[len(real):])
+        assert im.n_chunks == len(real) and g.NC % 4 == 0 and g.NC - len(real) < 4 and im.max_frags <= 33
+        assert [(int(o), int(n)) for o, n in im.table] == [(c["off"], c["nfrag"]) for c in real]
+    # an instance head alone / other depths / too many logits: no two-tile kernel -> plan 1 or 0
+    assert ops.fused_plan(ops.make_desc(n_sem=0, n_inst=32), None) == 0
     assert ops.fused_plan(ops.make_desc(D=4, skip=1, n_sem=45, n_inst=32), None) == 1
     assert ops.fused_plan(ops.make_desc(n_sem=100, n_inst=32), None) == 0
