@@ -1083,6 +1083,12 @@ class Gen:
                 blocks.append((u, bi, blk, inst))
         nb = len(blocks)
         lwr = (V_TMP, V_RING)
+
+        def lwr_reg(t, r):
+            # weight r of tile t lives one register further round its block of 16: the FMA below reads lwr[r] and register r of an
+            # accumulator, and with both at the same offset from a multiple of 16 they sat in the same VGPR bank (register number
+            # mod 4) -- every FMA of the tail paid a bank conflict
+            return lwr[t] + ((r + 1) & 15)
         sums = ([V_PTMP + k for k in range(nb)], [V_IN + 1 + k for k in range(nb)])
         oth = ([V_PTMP + 3 + k for k in range(nb)], [V_IN + 4, V_IN + 5, V_IN + 9][:nb])
         adr = V_PTMP + 7
@@ -1096,10 +1102,10 @@ class Gen:
                     e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i, V_LW + t, row))
                     e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i + 1, V_LW + t, row + 4))
                 for i in range(8):
-                    e("v_mov_b32 v%d, s%d" % (lwr[t] + 8 * half + i, S_LW + 2 * i + 1))
+                    e("v_mov_b32 v%d, s%d" % (lwr_reg(t, 8 * half + i), S_LW + 2 * i + 1))
                 e("s_mov_b64 exec, s[%d:%d]" % (S_HI0, S_HI0 + 1))
                 for i in range(8):
-                    e("v_mov_b32 v%d, s%d" % (lwr[t] + 8 * half + i, S_LW + 2 * i))
+                    e("v_mov_b32 v%d, s%d" % (lwr_reg(t, 8 * half + i), S_LW + 2 * i))
                 e("s_mov_b64 exec, -1")
         tag_lwr = [None, None]
         e("v_xor_b32 v%d, 32, v%d" % (adr, V_TID))
@@ -1107,16 +1113,21 @@ class Gen:
         e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
         tags = [None, None]
 
-        def fmas(t):
-            self.wait_lgkm(tag_lwr[t])
+        def fmas(ts):
+            # the chains of the tiles in `ts` side by side: a chain is 16 DEPENDENT FMAs, and three of them interleaved still ran at
+            # ~10 cycles per instruction (one wave per SIMD: nobody else fills the result latency); six run at the issue rate
+            for t in ts:
+                self.wait_lgkm(tag_lwr[t])
             for r in range(16):
-                for k, (u, bi, blk, inst) in enumerate(blocks):
-                    a = self.acc_reg(u["accs"][(bi, t)])
-                    if r == 0:
-                        e("v_fma_f32 v%d, v%d, v%d, 0" % (sums[t][k], lwr[t], a))
-                    else:
-                        e("v_fmac_f32 v%d, v%d, v%d" % (sums[t][k], lwr[t] + r, a + r))
-            tags[t] = [self.lds_read("ds_bpermute_b32 v%d, v%d, v%d" % (oth[t][k], adr, sums[t][k])) for k in range(nb)]
+                for t in ts:
+                    for k, (u, bi, blk, inst) in enumerate(blocks):
+                        a = self.acc_reg(u["accs"][(bi, t)])
+                        if r == 0:
+                            e("v_fma_f32 v%d, v%d, v%d, 0" % (sums[t][k], lwr_reg(t, 0), a))
+                        else:
+                            e("v_fmac_f32 v%d, v%d, v%d" % (sums[t][k], lwr_reg(t, r), a + r))
+            for t in ts:
+                tags[t] = [self.lds_read("ds_bpermute_b32 v%d, v%d, v%d" % (oth[t][k], adr, sums[t][k])) for k in range(nb)]
 
         def stores(t):
             for k in range(nb):                     # the sums under the FULL exec mask, then the masked stores
@@ -1127,9 +1138,8 @@ class Gen:
                 base = (S_REC_I if inst else S_REC_T) + 2 * t
                 self.vm_op("global_store_dword v%d, v%d, s[%d:%d] offset:%d%s" % (V_LB4, oth[t][k], base, base + 1, 4 + 128 * blk, STORE_NT))
             e("s_mov_b64 exec, -1")
-        fmas(0)
         self.stamp(len(self.units) + 4)
-        fmas(1)
+        fmas((0, 1))
         self.stamp(len(self.units) + 5)
         stores(0)
         stores(1)

@@ -64,7 +64,7 @@ def main():
     print("last eight groups' end-to-end cycles:", [(order[i + 1] - order[i]) & 0xffffffff for i in range(7)])
     print("%-4s %-22s %6s %8s %8s %7s" % ("unit", "what", "MFMAs", "cycles", "32xMFMA", "excess"))
     nu = len(g.units)
-    print("tail: lwr + tile 0's FMAs %d, tile 1's FMAs %d, stores %d cycles" % ((t[nu + 4] - t[nu]) & 0xffffffff, (t[nu + 5] - t[nu + 4]) & 0xffffffff,
+    print("tail: local weights of both tiles %d, the FMA chains of both tiles %d, exchange + stores %d cycles" % ((t[nu + 4] - t[nu]) & 0xffffffff, (t[nu + 5] - t[nu + 4]) & 0xffffffff,
                                                                                  (t[nu + 1] - t[nu + 5]) & 0xffffffff))
     for i in range(len(names) - 1):
         d = (t[i + 1] - t[i]) & 0xffffffff
