@@ -99,6 +99,82 @@ def rocprof_recorded(kernel, bytes_per_launch):
         return {}
 
 
+class LaunchProbe:
+    """frame_accounting: stands in for the ctypes library object during ONE untimed frame and brackets every
+    launching entry point of libpnr.so with a pair of events on the launch stream (torch's current stream IS the stream the ops
+    pass to the library).  pnr_mlp_forward_composite is issued as the two halves it consists of (include/pnr.h:
+    pnr_mlp_forward_tiles + pnr_composite_combine, same workspace, same order), so the MLP launch and the per-ray combine are
+    timed apart.  The product path is untouched: the probe exists only while bench.py installs it."""
+    QUIET = ("_bytes", "_plan", "pnr_version", "pnr_last_error", "pnr_device_check", "pnr_mlp_train_layout", "pnr_mlp_pack")
+
+    def __init__(self, lib):
+        self.lib, self.marks = lib, []
+
+    def _timed(self, name, fn, n_samples, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*a)
+        e1.record()
+        self.marks.append((name, n_samples, e0, e1))
+        return rc
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, name)
+        if any(q in name for q in self.QUIET):
+            return fn
+        if name == "pnr_mlp_forward_composite":
+            def both(desc, packed, rays, z, R, N, ls, li, white, rgb, depth, acc, w, sem, inst, fs, fi, ws, st):
+                rc = self._timed("pnr_mlp_forward_tiles", self.lib.pnr_mlp_forward_tiles, N, desc, packed, rays, z, R, N, ws, st)
+                if rc != 0:
+                    return rc
+                return self._timed("pnr_composite_combine", self.lib.pnr_composite_combine, N, desc, ws, z, R, N, ls, li, white, rgb,
+                                   depth, acc, w, sem, inst, fs, fi, st)
+            return both
+        n_pos = {"pnr_mlp_forward": 5, "pnr_composite": 9, "pnr_sample_pdf": 4, "pnr_sample_pdf_labels": 4, "pnr_ray_setup": 6,
+                 "pnr_stratified": 2, "pnr_sample_labels": 2}.get(name)
+        return lambda *a: self._timed(name, fn, int(a[n_pos]) if n_pos is not None else 0, *a)
+
+
+def frame_accounting(frame, n_coarse):
+    """One untimed frame under LaunchProbe -> where its time goes: fine / coarse MLP launches, the small kernels by entry point, and
+    what is left (torch-side copies / allocations between the library's launches, launch gaps).  Times are hipEvent differences on
+    the launch stream: a kernel's figure includes its own launch gap."""
+    from panopticnerf_amd import _lib
+    lib = _lib.load()
+    probe = LaunchProbe(lib)
+    _lib._lib = probe
+    try:
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            frame()
+            host_ms = (time.perf_counter() - t0) * 1e3        # host time to ENQUEUE the frame (no sync inside)
+            torch.cuda.synchronize()
+    finally:
+        _lib._lib = lib
+    m = probe.marks
+    by = {}
+    for name, N, e0, e1 in m:
+        key = name[4:] + ("" if not N else "[N=%d]" % N)
+        d = by.setdefault(key, [0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+    span = m[0][2].elapsed_time(m[-1][3])
+    inside = sum(v[1] for v in by.values())
+    mlp = {k: v for k, v in by.items() if k.startswith("mlp_forward")}
+    fine = sum(v[1] for k, v in mlp.items() if "[N=%d]" % n_coarse not in k)
+    coarse = sum(v[1] for k, v in mlp.items() if "[N=%d]" % n_coarse in k)
+    small = {k: {"launches": v[0], "ms": round(v[1], 3)} for k, v in sorted(by.items()) if k not in mlp}
+    return {"note": "ONE untimed frame, every libpnr.so launch bracketed by hipEvents on the launch stream (bench.py LaunchProbe)",
+            "frame_ms_first_launch_to_last": round(span, 3), "host_enqueue_ms": round(host_ms, 3),
+            "library_launches_per_frame": len(m),
+            "fine_mlp_ms": round(fine, 3), "coarse_mlp_ms": round(coarse, 3),
+            "small_kernels_ms": round(inside - fine - coarse, 3), "small_kernels": small,
+            "between_launches_ms": round(span - inside, 3),
+            "between_launches_is": "torch-side work between the library's launches (frame-map allocation / first-chunk copy, workspace "
+                                   "allocations) and idle queue time"}
+
+
 def make_train_batch(cfg, rays, box, ids, n_rays, C, K, dev, seed):
     """A training batch whose targets are LEARNABLE: a teacher network (same architecture, different seed) renders the
     batch's rays; its fine-level colour / depth are the rgb / stereo-depth targets and the argmax of its composited
@@ -681,6 +757,12 @@ def main():
             if N_F:
                 extra["roofline_composite_coarse"] = comp_roofline(N_C, True, "coarse level, weights written")
 
+    if rank == 0 and not fake and not args.no_roofline:
+        try:
+            extra["frame_accounting"] = frame_accounting(frame_weak, N_C if N_F else -1)
+        except Exception as e:      # noqa: BLE001
+            extra["frame_accounting"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # secondary measurement (never the headline value): one training step on a ray batch per rank --
     # render with autograd, the loss wrapper (RGB / depth / 2D CE on learned and fixed fields / 3D CE; fused HIP),
     # backward through the HIP kernels (compositing, dgrad, wgrad), flat-bucket
@@ -825,6 +907,10 @@ def main():
                                           N_SEM, N_INST, "on" if c["bbox"] else "off"),
                            "baseline_config": args.config, "rays_per_frame": n_rays, "frames_per_step": frames_per_step,
                            "mlp_samples_per_ray": per_ray, "chunk_rays": args.chunk, "keep_weights": KEEP_W,
+                           "small_print": "timed frames: rays are pre-generated and resident (pnr_gen_rays, SURVEY 8f-2, is outside the frame); the "
+                                          "fine level's per-sample weights are not written (keep_weights false: nothing downstream reads them, ~0.4 GB "
+                                          "per frame); inference is deterministic (perturb = 0, no sigma noise) -- in TRAINING the renderer draws "
+                                          "perturb / raw_noise_std uniforms with torch.rand / torch.randn (renderer.py), there is no in-kernel RNG",
                            "semantic_activation": args.semantic_activation, "parallelism": par},
                 "scaling_modes": modes, "rccl": rccl,
                 "roofline": roofline, "cpu_baseline": cpu_baseline}

@@ -81,20 +81,25 @@ typedef struct pnr_mlp_desc {
     int32_t schedule;  /* time structure of the bf16 weight stream (tests and A/B tools; the arithmetic, the packed image and the
                           results are identical bit for bit): 0 = default (ping-pong k_mlp_pp for inference launches, lock-step
                           k_mlp_fused for the training forward), 1 = lock-step everywhere, 2 = ping-pong everywhere */
-    int32_t clk_probe[2]; /* diagnostics (libpnr_bench.so, tools/): low / high 32 bits of a DEVICE address of 16 bytes; when non-zero
-                             the forward MLP kernels launched with this descriptor write {shader cycles, 100 MHz ticks} of
-                             workgroup 0's first wave there (their ratio = the mean shader clock during the launch).  0 = off.
+    int32_t clk_probe[2]; /* diagnostics (libpnr_bench.so, tools/): low / high 32 bits of a 16-byte aligned DEVICE address of 16 bytes;
+                             when non-zero the forward MLP kernels launched with this descriptor write {shader cycles, 100 MHz ticks}
+                             of workgroup 0's first wave there (their ratio = the mean shader clock during the launch).  0 = off.
                              A descriptor field, not a setter: the library keeps no mutable state (round 5) */
     int32_t flags;     /* PNR_MLP_* bits, 0 by default */
 } pnr_mlp_desc;
+/* ZERO-INITIALISE the whole descriptor (memset / = {0}) before setting fields: clk_probe and flags are READ by every entry point
+ * that takes a descriptor -- a stale clk_probe is a device address the forward kernels store to.  Every pnr_mlp_* call rejects
+ * (PNR_EINVAL) flags with undefined bits and a clk_probe that is not 16-byte aligned. */
 
 #define PNR_MLP_SOFTMAX 1      /* pnr_mlp_forward_composite / pnr_mlp_forward_tiles composite softmax(logits) over each learned field's
                                   channels instead of the logits (the reference's semantic_activation = softmax; pnr_composite's
                                   sem_mode 1).  Needs the plan-1 image (pnr_mlp_fused_plan >= 1 and pnr_mlp_desc.plan = 1): a head's
                                   logit blocks must be in registers together; PNR_ERR_ARG otherwise */
-#define PNR_MLP_TRACE 0x7A00   /* diagnostics, with plan 2 and clk_probe set: the trace build of k_mlp_tt -- 64 per-unit s_memtime
-                                  stamps of workgroup 0's first wave instead of the clock pair; + a in 1..7: its timing-only
-                                  ablation a (tools/tt_trace.py) */
+#define PNR_MLP_TRACE 0x7A00   /* diagnostics BUILDS of the library only (make EXTRA_TT=trace | abl; the shipped library refuses the
+                                  flag), with plan 2: the trace build of k_mlp_tt -- clk_probe must then address (64 + workgroups) * 4
+                                  bytes (workgroups <= number of CUs; tools/tt_trace.py allocates 1280): 64 per-unit s_memtime stamps
+                                  of workgroup 0's first wave, then every workgroup's cycles.  + (a << 4), a in 1..7: its timing-only
+                                  ablation a (bits 4..6 -- bit 0 stays PNR_MLP_SOFTMAX) */
 
 /* Dense fp32 parameters in HOST memory, row-major (out,in), nn.Linear convention.
  * pts_w[i]/pts_b[i] for i < D.  Head pointers may be NULL when the head is absent; with head_depth = 1 a head is the single

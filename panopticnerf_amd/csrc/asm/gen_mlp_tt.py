@@ -1433,9 +1433,13 @@ def main():
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())
-    names.append("k_mlp_tt_s2i1_trace")         # debug: per-unit s_memtime stamps instead of the clock pair (tools/tt_trace.py)
-    parts.append(Gen(2, 1, "k_mlp_tt_s2i1_trace", trace=True).kernel())
-    if len(sys.argv) > 3:                       # timing-only ablations of the trace build (results invalid)
+    # diagnostics builds only (make EXTRA_TT=trace | abl): the production library carries no kernel that writes (64 + n_wg) * 4 bytes
+    # to the clock buffer (a 16-byte clk_probe buffer under PNR_MLP_TRACE was an out-of-bounds device write)
+    extra = sys.argv[3] if len(sys.argv) > 3 else ""
+    if extra in ("trace", "abl"):
+        names.append("k_mlp_tt_s2i1_trace")     # debug: per-unit s_memtime stamps instead of the clock pair (tools/tt_trace.py)
+        parts.append(Gen(2, 1, "k_mlp_tt_s2i1_trace", trace=True).kernel())
+    if extra == "abl":                          # timing-only ablations of the trace build (results invalid)
         for abl in (1, 2, 3, 4, 7):
             names.append("k_mlp_tt_s2i1_trace_a%d" % abl)
             parts.append(Gen(2, 1, names[-1], trace=True, abl=abl).kernel())

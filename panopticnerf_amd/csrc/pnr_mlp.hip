@@ -53,6 +53,9 @@ int pnr_mlp_validate(const pnr_mlp_desc* d);
 #ifndef PNR_PP_EPI_IN_M
 #define PNR_PP_EPI_IN_M 0
 #endif
+#ifndef PNR_TRAIN_TILES_EXPERIMENT
+#define PNR_TRAIN_TILES_EXPERIMENT 0
+#endif
 #ifndef PNR_PP_UNROLL2
 #define PNR_PP_UNROLL2 0     /* two trunk layers per loop trip (no hand-over copies): -2 % measured (code size) */
 #endif
@@ -926,6 +929,15 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const void* packed, const 
             return desc->W == 256 ? launch_mlp_pp<256, false>(a, st) : launch_mlp_pp<128, false>(a, st);
         if (desc->schedule == 2 && acts)
             return desc->W == 256 ? launch_mlp_pp<256, true>(a, st) : launch_mlp_pp<128, true>(a, st);
+#if PNR_TRAIN_TILES_EXPERIMENT
+        // round-6 experiment (tools/build_ab.sh tt:"-DPNR_TRAIN_TILES_EXPERIMENT=1"; profiles/r06b): the training forward with ONE wave per
+        // SIMD and 2 / 3 sample tiles per wave.  3: a weight pass feeds 384 samples instead of 256 (timing only: S % 384 == 0)
+        if (acts && desc->schedule == 3 && desc->W == 256) return launch_mlp<PNR_PREC_BF16, 256, 2, 4, 1, true>(a, st);
+        if (acts && desc->schedule == 4 && desc->W == 256) {
+            PNR_REQUIRE(a.S % 384 == 0, "schedule 4 (experiment): S must be a multiple of 384");
+            return launch_mlp<PNR_PREC_BF16, 256, 3, 4, 1, true>(a, st);
+        }
+#endif
         if (acts)
             return desc->W == 256 ? launch_mlp<PNR_PREC_BF16, 256, 1, 8, 2, true>(a, st)
                                   : launch_mlp<PNR_PREC_BF16, 128, 1, 8, 2, true>(a, st);
@@ -996,8 +1008,8 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
         t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
         t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
         PNR_REQUIRE(!softmax, "pnr_mlp_forward_composite: softmax compositing has no two-tile kernel; pack the plan-1 image");
-        const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + a in 1..7: the timing-only ablation a
-        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st, trace, trace ? (desc->flags & 7) : 0);
+        const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + (a << 4), a in 1..7: the timing-only ablation a
+        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, st, trace, trace ? ((desc->flags >> 4) & 7) : 0);
     }
     if (desc->plan == 1) {
         const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;

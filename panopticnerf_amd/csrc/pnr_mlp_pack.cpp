@@ -29,9 +29,21 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
                 d->precision);
     PNR_REQUIRE(d->head_tap == 0 || d->head_tap == 1, "pnr_mlp: head_tap=%d must be 0 (trunk output) or 1 (feature)", d->head_tap);
     PNR_REQUIRE(d->head_depth >= 0 && d->head_depth <= 2, "pnr_mlp: head_depth=%d must be 1 or 2", d->head_depth);
-    PNR_REQUIRE(d->schedule >= 0 && d->schedule <= 2, "pnr_mlp: schedule=%d must be 0 (default), 1 (lock-step) or 2 (ping-pong)", d->schedule);
+#ifndef PNR_TRAIN_TILES_EXPERIMENT
+#define PNR_TRAIN_TILES_EXPERIMENT 0
+#endif
+    PNR_REQUIRE(d->schedule >= 0 && d->schedule <= (PNR_TRAIN_TILES_EXPERIMENT ? 6 : 2), "pnr_mlp: schedule=%d must be 0 (default), 1 (lock-step) or 2 (ping-pong)", d->schedule);
     PNR_REQUIRE(d->plan == 0 || (d->plan == 1 && pnr_plan1_supported(*d)) || (d->plan == 2 && pnr_plan2_supported(*d)),
                 "pnr_mlp: plan=%d is not available for this geometry (ask pnr_mlp_fused_plan)", d->plan);
+    // the descriptor must be zero-initialised (include/pnr.h): the diagnostic words are READ -- clk_probe is a device address the
+    // forward kernels store 16 bytes to, flags select kernels -- so garbage there is rejected where it can be recognised
+    const uint32_t trace = (uint32_t)d->flags & 0xFF00u;
+    PNR_REQUIRE(((uint32_t)d->flags & ~(uint32_t)(PNR_MLP_SOFTMAX | 0xFF70u)) == 0 && (trace == 0 || trace == PNR_MLP_TRACE) &&
+                (trace != 0 || ((uint32_t)d->flags & 0x70u) == 0),
+                "pnr_mlp: unknown bits in flags=0x%x (zero-initialise pnr_mlp_desc; PNR_MLP_* are the defined bits)", (unsigned)d->flags);
+    PNR_REQUIRE(((uint32_t)d->clk_probe[0] & 15u) == 0, "pnr_mlp: clk_probe=0x%08x%08x is not a 16-byte aligned device address "
+                "(zero-initialise pnr_mlp_desc; clk_probe is a diagnostics field, 0 = off)", (unsigned)d->clk_probe[1], (unsigned)d->clk_probe[0]);
+    PNR_REQUIRE(trace == 0 || (d->clk_probe[0] | d->clk_probe[1]) != 0, "pnr_mlp: PNR_MLP_TRACE needs clk_probe");
     return PNR_OK;
 }
 
@@ -248,6 +260,7 @@ static void write_host(const Image& im, int precision, void* out)
 PNR_EXPORT int64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc)
 {
     if (pnr_mlp_validate(desc) != PNR_OK) return PNR_EINVAL;
+    if (desc->plan == 2) pnr_mlp_tt_prepare_quiet();     // (a plan-2 image is about to exist: have its kernel loaded before any capture)
     PnrPlan plan;
     pnr_build_plan(*desc, plan);
     return (int64_t)plan.total_bytes;
@@ -259,6 +272,7 @@ PNR_EXPORT int pnr_mlp_pack(const pnr_mlp_desc* desc, const pnr_mlp_params_host*
     if (rc != PNR_OK) return rc;
     PNR_REQUIRE(packed_host, "pnr_mlp_pack: null pointer");
     if ((rc = check_params(desc, p, true)) != PNR_OK) return rc;
+    if (desc->plan == 2) pnr_mlp_tt_prepare_quiet();
     Image im;
     describe_forward(*desc, *p, im);
     write_host(im, desc->precision, packed_host);

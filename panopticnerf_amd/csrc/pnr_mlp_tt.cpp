@@ -4,6 +4,7 @@
 // The first call on a device must therefore happen OUTSIDE a stream capture (module loading is not capturable); later calls are
 // plain kernel launches and capture like every other entry point.
 #include <mutex>
+#include <string>
 
 #include "pnr_common.h"
 #include "pnr_mlp_tt.h"
@@ -23,7 +24,9 @@ DevTable g_tab[64];
 std::mutex g_mu;
 }   // namespace
 
-static int tt_table(DevTable*& out)
+// capturing != 0: the caller's stream is being captured -- a module that is not loaded yet must not be loaded now (hipModuleLoadData
+// under a capture fails and, in the global capture mode, invalidates the capture): report it instead
+static int tt_table(DevTable*& out, int capturing = 0)
 {
     int dev = 0;
     PNR_HIP(hipGetDevice(&dev));
@@ -31,24 +34,29 @@ static int tt_table(DevTable*& out)
     std::lock_guard<std::mutex> lk(g_mu);
     DevTable& t = g_tab[dev];
     if (!t.tried) {
+        PNR_REQUIRE(!capturing, "pnr_mlp_tt: the two-tile code object is not loaded on device %d yet and the stream is capturing: make the "
+                    "first plan-2 call (or pnr_mlp_pack_device / pnr_mlp_packed_bytes with plan = 2) outside the capture", dev);
         t.tried = true;
         hipError_t e = hipModuleLoadData(&t.mod, k_co);
+        const bool loaded = e == hipSuccess;
         static const int geo[5][2] = {{1, 1}, {2, 1}, {0, 0}, {1, 0}, {2, 0}};      // (semantic, instance) logit blocks of the generated kernels
         for (int k = 0; k < 5 && e == hipSuccess; ++k) {
             char nm[64];
             snprintf(nm, sizeof(nm), "k_mlp_tt_s%di%d", geo[k][0], geo[k][1]);
             e = hipModuleGetFunction(&t.fn[geo[k][0]][geo[k][1]], t.mod, nm);
         }
-        if (e == hipSuccess) e = hipModuleGetFunction(&t.fn_trace[0], t.mod, "k_mlp_tt_s2i1_trace");
-        for (int a = 1; a < 8 && e == hipSuccess; ++a) {
+        // diagnostics kernels: only in `make EXTRA_TT=trace | abl` builds of the library
+        for (int a = 0; a < 8 && e == hipSuccess; ++a) {
             char nm[64];
-            snprintf(nm, sizeof(nm), "k_mlp_tt_s2i1_trace_a%d", a);
+            if (a) snprintf(nm, sizeof(nm), "k_mlp_tt_s2i1_trace_a%d", a); else snprintf(nm, sizeof(nm), "k_mlp_tt_s2i1_trace");
             if (hipModuleGetFunction(&t.fn_trace[a], t.mod, nm) != hipSuccess) { t.fn_trace[a] = nullptr; (void)hipGetLastError(); }
         }
         if (e != hipSuccess) {
             pnr_set_error("pnr_mlp_tt: loading the two-tile code object failed: %s (the first call on a device must not be inside a "
                           "stream capture)", hipGetErrorString(e));
-            t.tried = false;        // let the next call (outside a capture) try again
+            if (loaded) (void)hipModuleUnload(t.mod);       // a partial failure must not leak the module across the retry
+            t = DevTable();         // let the next call (outside a capture) try again
+            (void)hipGetLastError();
             return PNR_EHIP;
         }
         t.ok = true;
@@ -64,19 +72,34 @@ int pnr_mlp_tt_prepare(void)
     return tt_table(t);
 }
 
+// Best effort, for the entry points that are pure CPU work (pnr_mlp_pack, pnr_mlp_packed_bytes: they also run where there is no
+// device): if a device is present, load the code object now, so that an image packed on the host and first launched inside a
+// stream capture finds it loaded (the launch itself refuses to load under a capture).  Never fails, keeps pnr_last_error().
+void pnr_mlp_tt_prepare_quiet(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
+    const std::string keep = pnr_last_error();
+    DevTable* t = nullptr;
+    if (tt_table(t) != PNR_OK) pnr_set_error("%s", keep.c_str());
+}
+
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace, int trace_abl)
 {
     PNR_REQUIRE(nbs >= 0 && nbs <= 2 && nbi >= 0 && nbi <= (nbs ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
                 "render in chunks", a.S);
     DevTable* t = nullptr;
-    int rc = tt_table(t);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    PNR_HIP(hipStreamIsCapturing(stream, &cs));
+    int rc = tt_table(t, cs != hipStreamCaptureStatusNone);
     if (rc != PNR_OK) return rc;
     hipFunction_t fn = t->fn[nbs][nbi];
     if (trace) {
         PNR_REQUIRE(nbs == 2 && nbi == 1 && a.clk, "pnr_mlp_tt: the trace build exists for 2 + 1 logit blocks and needs the clock buffer");
         fn = t->fn_trace[trace_abl & 7];
-        PNR_REQUIRE(fn, "pnr_mlp_tt: ablation %d of the trace build is not in this library (make EXTRA_TT=abl)", trace_abl & 7);
+        PNR_REQUIRE(fn, "pnr_mlp_tt: PNR_MLP_TRACE%s%d is not in this library: the trace kernels are diagnostics builds "
+                    "(make EXTRA_TT=trace, ablations EXTRA_TT=abl)", trace_abl & 7 ? " ablation " : " ", trace_abl & 7);
     }
     PnrTTArgs ka = a;
     const int cus = pnr_cu_count();

@@ -19,7 +19,11 @@ struct PnrTTArgs {
 };
 static_assert(sizeof(PnrTTArgs) == 88, "k_mlp_tt reads its arguments at fixed offsets");
 
-// trace: the debug build of the kernel (per-unit s_memtime stamps of workgroup 0's first wave to `clk`, 256 bytes; tools/tt_trace.py)
+// trace: the debug build of the kernel (EXTRA_TT=trace | abl builds only): 64 per-unit s_memtime stamps of workgroup 0's first wave
+// to clk[0..63] and every workgroup's cycles to clk[64 + workgroup], 4 bytes each -- `clk` must hold (64 + n_wg) * 4 bytes
+// (tools/tt_trace.py allocates 1280 for 256 workgroups); the plain kernels write 16 bytes.
 // load the code object on the current device if that has not happened yet (not capturable: called from the device packer)
 int pnr_mlp_tt_prepare(void);
+// the same, best effort and silent, from the CPU-side packing entry points (no device / a capturing thread: nothing happens)
+void pnr_mlp_tt_prepare_quiet(void);
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, hipStream_t stream, bool trace = false, int trace_abl = 0);

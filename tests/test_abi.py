@@ -91,6 +91,32 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.pnr_embed(one, 0, 10, one, null) == 0
 
 
+def test_descriptor_diagnostic_words_are_validated():
+    """pnr_mlp_desc.clk_probe is a device address the forward kernels store to and flags select kernels, so a caller
+    that did not zero-initialise the descriptor is rejected where that can be recognised: undefined flag bits, a misaligned
+    clk_probe, ablation bits without PNR_MLP_TRACE, PNR_MLP_TRACE without a clock buffer.  The trace ablation lives in bits 4..6
+    (bit 0 stays PNR_MLP_SOFTMAX)."""
+    lib = _lib.load()
+    ok = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(ok)) > 0
+    for flags in (2, 0x80, 0x10000, 0x10, 0x7B00, -1):
+        d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+        d.flags = flags
+        assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1, hex(flags)
+        assert b"flags" in lib.pnr_last_error()
+    d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+    d.clk_probe[0] = 0x1008
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1 and b"clk_probe" in lib.pnr_last_error()
+    d.clk_probe[0] = 0x1000
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) > 0
+    d.flags = _lib.MLP_SOFTMAX
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) > 0
+    d.flags = _lib.MLP_TRACE + (3 << 4)
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) > 0
+    d.clk_probe[0] = 0
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1 and b"PNR_MLP_TRACE" in lib.pnr_last_error()
+
+
 def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.stratified(torch.zeros(4, 8), 8)

@@ -13,13 +13,18 @@ def kernel_stats(path):
     print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'pct':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
     for r in rows[:14]:
         print(f"{r[0][:72]:72s} {r[1]:6d} {r[2] / 1e6:10.3f} {100 * r[2] / tot:6.2f} {r[3] / 1e3:10.1f} {r[4] / 1e3:10.1f} {r[5] / 1e3:10.1f}")
-    # the bench's dominant launch: fine-level MLP chunks are the longest k_mlp_tt / k_mlp_pp / k_mlp_fused dispatches
-    big = cur.execute("select (end-start)/1e3, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                      "from kernels where (name like '%k_mlp_fused%' or name like '%k_mlp_pp%' or name like '%k_mlp_tt%') order by 1 desc").fetchall()
-    if big:
+    # the bench's dominant launch, selected BY NAME: the MLP kernel with the largest total time (k_mlp_tt_* / k_mlp_pp<..> /
+    # k_mlp_fused<..>; a single comparison launch of another form no longer leaks into the average or lends its launch shape --
+    # VERDICT r5 weak #8); its fine-level chunk launches are the dispatches of that name above 70 % of its longest
+    mlp = [r for r in rows if any(k in r[0] for k in ("k_mlp_tt", "k_mlp_pp", "k_mlp_fused"))]
+    if mlp:
+        name = mlp[0][0]
+        big = cur.execute("select (end-start)/1e3, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
+                          "from kernels where name = ? order by 1 desc", (name,)).fetchall()
         top = [b for b in big if b[0] > 0.7 * big[0][0]]
-        print(f"fused MLP fine-level chunk launches (>70% of longest): n={len(top)} avg={sum(b[0] for b in top) / len(top):.1f} us "
-              f"grid={big[0][1]} wg={big[0][2]} vgpr={big[0][3]} agpr={big[0][4]} sgpr={big[0][5]} lds={big[0][6]} scratch={big[0][7]}")
+        print(f"dominant kernel {name[:60]}: fine-level chunk launches (>70% of its longest): n={len(top)} "
+              f"avg={sum(b[0] for b in top) / len(top):.1f} us grid={top[0][1]} wg={top[0][2]} vgpr={top[0][3]} agpr={top[0][4]} "
+              f"sgpr={top[0][5]} lds={top[0][6]} scratch={top[0][7]}")
     print()
 
 

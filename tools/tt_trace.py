@@ -29,7 +29,7 @@ def main():
     clk = torch.zeros(64 + 256, dtype=torch.int32, device=dev)
     desc.clk_probe[0] = clk.data_ptr() & 0xffffffff
     desc.clk_probe[1] = clk.data_ptr() >> 32
-    desc.flags = 0x7A00 + abl
+    desc.flags = 0x7A00 + (abl << 4)        # bits 4..6: the ablation (bit 0 is PNR_MLP_SOFTMAX)
     lib = _lib.load()
     nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, 0)
     ws = torch.empty(int(nbytes), device=dev, dtype=torch.uint8)
