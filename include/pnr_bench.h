@@ -43,18 +43,6 @@ int pnrb_probe_mfma_order(int pattern, int iters, void* scratch, float* tflops_o
 int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,
                         void* scratch, float* gbs_out_host, void* stream);
 
-/* TIMING-ONLY prototypes of the fused MLP's steady hidden-layer loop with ONE wave per SIMD and TWO 32-sample tiles per wave
- * (every LDS weight fragment feeds two MFMAs; round-4 verdict item 1; csrc/bench/pnr_proto_two_tile.hip).  Nothing is
- * computed that anybody checks.  image: pnrb_proto_two_tile_image_bytes() device bytes of pseudo-random bf16 weight fragments
- * (40 chunks x (32 KiB of weights + a 1 KiB fp32 bias fragment)).  flags: 7 = the prototype; 6 / 3 / 2 / 0 = without the LDS-DMA
- * pieces / the pack-ReLU epilogue / both / also without fragment reads.  Outputs (host floats): mean ms per launch, mean shader
- * MHz and cycles per MFMA of workgroup 0's first wave.  _asm: the hand-placed assembly form (panopticnerf_amd/pnr_two_tile_proto.co). */
-int64_t pnrb_proto_two_tile_image_bytes(void);
-int pnrb_proto_two_tile(const void* image, int64_t n_samples, int flags, int iters, void* scratch, float* ms_out_host,
-                        float* mhz_out_host, float* cyc_per_mfma_out_host, void* stream);
-int pnrb_proto_two_tile_asm(const char* co_path, const void* image, int64_t n_samples, int flags, int iters, void* scratch,
-                            float* ms_out_host, float* mhz_out_host, float* cyc_per_mfma_out_host, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

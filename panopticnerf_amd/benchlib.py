@@ -20,11 +20,7 @@ SIGNATURES = {
     "pnrb_probe_mfma_peak": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_mfma_order": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, _fp, c_f]),
-    "pnrb_proto_two_tile_image_bytes": (c_i64, []),
-    "pnrb_proto_two_tile": (c_int, [c_f, c_i64, c_int, c_int, c_f, _fp, _fp, _fp, c_f]),
-    "pnrb_proto_two_tile_asm": (c_int, [ctypes.c_char_p, c_f, c_i64, c_int, c_int, c_f, _fp, _fp, _fp, c_f]),
 }
-PROTO_CO_PATH = os.path.join(_HERE, "pnr_two_tile_proto.co")
 _blib = None
 
 
@@ -121,31 +117,3 @@ def probe_raw_read(raw, n_rays, n_samples, iters=5):
         _check(load().pnrb_probe_raw_read(_p(raw), ops._chk_raw(raw, raw.shape[0], n_rays * n_samples), int(n_rays), int(n_samples),
                                           int(raw.shape[0]), int(iters), _p(scratch), ctypes.byref(gbs), _stream()), "pnrb_probe_raw_read")
     return float(gbs.value)
-
-
-def proto_two_tile_image(device, seed=0):
-    """Pseudo-random weight image of the timing-only two-tile prototypes: 40 chunks x (32 KiB He-scaled bf16 weights + a 1 KiB
-    fragment whose first 64 floats are small fp32 biases)."""
-    n = int(load().pnrb_proto_two_tile_image_bytes())
-    g = torch.Generator().manual_seed(seed)
-    chunks = n // (33 * 1024)
-    w = ((torch.rand(chunks, 32 * 512, generator=g) * 2 - 1) * 0.153).to(torch.bfloat16).view(torch.uint8).reshape(chunks, 32 * 1024)
-    b = torch.zeros(chunks, 256)
-    b[:, :64] = (torch.rand(chunks, 64, generator=g) - 0.3) * 0.2
-    img = torch.cat([w, b.view(torch.uint8).reshape(chunks, 1024)], 1).contiguous()
-    assert img.numel() == n
-    return img.to(device)
-
-
-def proto_two_tile(image, n_samples, flags=7, iters=5, asm=False):
-    """(ms per launch, shader MHz, cycles per MFMA of one wave) of the timing-only two-tile prototype (include/pnr_bench.h)."""
-    ms, mhz, cyc = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
-    with torch.cuda.device(image.device):
-        scratch = torch.zeros(512, device=image.device, dtype=torch.int64)
-        if asm:
-            _check(load().pnrb_proto_two_tile_asm(PROTO_CO_PATH.encode(), _p(image), int(n_samples), int(flags), int(iters), _p(scratch),
-                                                  ctypes.byref(ms), ctypes.byref(mhz), ctypes.byref(cyc), _stream()), "pnrb_proto_two_tile_asm")
-        else:
-            _check(load().pnrb_proto_two_tile(_p(image), int(n_samples), int(flags), int(iters), _p(scratch), ctypes.byref(ms),
-                                              ctypes.byref(mhz), ctypes.byref(cyc), _stream()), "pnrb_proto_two_tile")
-    return float(ms.value), float(mhz.value), float(cyc.value)

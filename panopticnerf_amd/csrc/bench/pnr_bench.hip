@@ -24,7 +24,7 @@ static void set_error(const char* fmt, ...)
     va_end(ap);
 }
 PNRB_EXPORT const char* pnrb_last_error(void) { return g_err; }
-// for the other translation units of the library (bench/pnr_proto_two_tile.hip)
+// (also for other translation units of the bench library)
 void pnrb_set_error(const char* fmt, ...)
 {
     va_list ap;

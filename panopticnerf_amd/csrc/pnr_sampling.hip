@@ -7,6 +7,7 @@
 // Reference functions these replace (the reference source
 // is not in the mount, include/pnr.h explains the citation form).
 #include "pnr_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 #pragma clang fp contract(off)
@@ -324,6 +325,223 @@ __device__ __forceinline__ void sample_pdf_body(const float* __restrict__ z, con
     }
 }
 
+// ---- the inference frame's instance (round 6): deterministic u, merged z_fine (+ labels) only, Nc <= 64, Nc + Nf <= 256.
+// Same operations on the same values as sample_pdf_body -- bit for bit -- with a different instruction stream: the general body ran
+// 8 waves per SIMD with SGPRs spilled to VGPR lanes (249 v_readlane / 147 v_writelane in its code) and VGPRs to scratch, and the
+// kernel is bound by ISSUE, not latency.  Here: lane = coarse sample, z / w / pdf / bins in registers (neighbours by DPP); the
+// searches are branch-free fixed-depth bisections over LDS (upper / lower bound of a SORTED list = the number of elements <= / <
+// the key: identical to the general body's loops whenever the lists are sorted, and the merge path is only taken when they are);
+// a ray's hit list is loaded once, one entry per lane, its ids looked up once per hit instead of once per sample, and broadcast by
+// v_readlane with the hit loop outermost (the same sequence of comparisons per sample).  Unsorted lists (never with deterministic
+// u and a monotone CDF) fall back to the bitonic sort in a function of its own.
+__device__ __noinline__ void pdf_bitonic_fallback(float* s_sort, const float* s_z, const float* s_zs, int Nc, int Nf, int P, int lane)
+{
+    const int Nt = Nc + Nf;
+    for (int i = lane; i < Nc; i += 64) s_sort[i] = s_z[i];
+    for (int i = lane; i < Nf; i += 64) s_sort[Nc + i] = s_zs[i];
+    for (int i = Nt + lane; i < P; i += 64) s_sort[i] = INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (P >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const float a = s_sort[i], b = s_sort[p];
+                const bool asc = (i & k) == 0;
+                if ((a > b) == asc) {
+                    s_sort[i] = b;
+                    s_sort[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+#ifndef PDF_DET_WPE
+#define PDF_DET_WPE 8           /* waves per SIMD the register allocation is held to.  The kernel is bound by LATENCY (a dozen dependent LDS round trips
+                                   per ray, one ray per wave): at its natural 73 VGPRs (6 waves) it is SLOWER than the general body at 8 waves
+                                   (1.06 against 0.94 ms per frame's 8 launches) although it issues a third of the instructions; held to 64
+                                   registers 0.87 (profiles/r06/r06d, same box) */
+#endif
+#if PDF_DET_WPE
+__attribute__((amdgpu_waves_per_eu(PDF_DET_WPE, PDF_DET_WPE)))
+#endif
+__global__ __launch_bounds__(64) void k_sample_pdf_det(const float* __restrict__ z, const float* __restrict__ weights, int64_t R, int Nc,
+                                                        int Nf, float* __restrict__ zfine_out, const PdfLabelArgs lab)
+{
+    __shared__ float s_z[64], s_w[64], s_pdf[64], s_cdf[64], s_bins[64];
+    __shared__ float s_zs[192], s_out[256];
+    __shared__ float s_total, s_part[32];
+    const int lane = threadIdx.x;
+    const int nb = Nc - 1, nw = Nc - 2, Nt = Nc + Nf;
+    int topc = 1, topf = 1;                      // the largest powers of two <= Nc, <= Nf: first strides of the bisections
+    while (topc * 2 <= Nc) topc *= 2;
+    while (topf * 2 <= Nf) topf *= 2;
+    const int mh = lab.max_hits;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const float* __restrict__ zr = z + r * Nc;
+        const float* __restrict__ wr = weights + r * Nc;
+        const float zl = lane < Nc ? zr[lane] : 0.0f, wl = lane < Nc ? wr[lane] : 0.0f;
+        // the ray's hit list, one kept entry per lane (requested now, used at the end)
+        int cnt = 0, h_ls = -1, h_li = -1;
+        float h_ti = 0.0f, h_to = 0.0f;
+        if (lab.label_sem) {
+            const int c0 = lab.hit_count[r];
+            cnt = c0 < mh ? c0 : mh;
+            if (lane < cnt) {
+                const float2 t2 = *reinterpret_cast<const float2*>(lab.hit_t + (r * mh + lane) * 2);
+                h_ti = t2.x; h_to = t2.y;
+                const int m = lab.hit_box[r * mh + lane];
+                h_ls = lab.box_ids[m * 2];
+                h_li = lab.box_ids[m * 2 + 1];
+            }
+        }
+        s_z[lane] = zl;
+        s_w[lane] = wl;
+        const float zn = __shfl_down(zl, 1, 64), wn = __shfl_down(wl, 1, 64);
+        s_bins[lane] = 0.5f * (zn + zl);             // bins[k] = 0.5 (z[k + 1] + z[k]), k < nb
+        __syncthreads();
+        // total = torch.sum(w[1:-1] + 1e-5) in ATen's order: sample_pdf_body's code
+        if (lane < 32) {
+            const int k = lane >> 3, l = lane & 7, nv = nw / 8, groups = nv / 4;
+            float pacc = 0.0f;
+            for (int g = 0; g < groups; ++g) pacc = pacc + (s_w[(g * 4 + k) * 8 + l + 1] + 1e-5f);
+            if (k == 0)
+                for (int v = groups * 4; v < nv; ++v) pacc = pacc + (s_w[v * 8 + l + 1] + 1e-5f);
+            s_part[lane] = pacc;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const int nv = nw / 8;
+            float total = 0.0f;
+            for (int j = nv * 8; j < nw; ++j) total = total + (s_w[j + 1] + 1e-5f);
+            for (int l = 0; l < 8; ++l) {
+                float p0 = s_part[l];
+                p0 = p0 + s_part[8 + l]; p0 = p0 + s_part[16 + l]; p0 = p0 + s_part[24 + l];
+                total = total + p0;
+            }
+            s_total = total;
+        }
+        __syncthreads();
+        const float total = s_total;
+        const float pl = lane < nw ? (wn + 1e-5f) / total : 0.0f;      // pdf[j] = (w[j + 1] + 1e-5) / total
+        s_pdf[lane] = pl;
+        double c = (double)pl;
+        bool exact = __all(pl == 0.0f || pl >= 0x1p-28f);
+        if (exact) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double o = __shfl_up(c, d, 64);
+                if (lane >= d) c += o;
+            }
+            exact = __shfl(c, 63, 64) < 1.999;
+        }
+        if (exact) {
+            if (lane == 0) s_cdf[0] = 0.0f;
+            if (lane < nw) s_cdf[lane + 1] = (float)c;
+        } else {
+            __syncthreads();
+            if (lane == 0) {
+                double cc = 0.0;
+                s_cdf[0] = 0.0f;
+                for (int j = 0; j < nw; ++j) {
+                    cc += (double)s_pdf[j];
+                    s_cdf[j + 1] = (float)cc;
+                }
+            }
+        }
+        __syncthreads();
+        // inverse CDF at the Nf deterministic u: upper bound over cdf[0 .. nb) by bisection (cdf is non-decreasing)
+        bool asc = lane + 1 >= Nc || zl <= zn;
+        for (int i = lane; i < Nf; i += 64) {
+            const float uu = pnr_linspace01(i, Nf);
+            int pos = 0;
+            for (int st = topc; st >= 1; st >>= 1) {
+                const int p = pos + st, q = p <= nb ? p : nb;
+                pos = (p <= nb && s_cdf[q - 1] <= uu) ? p : pos;
+            }
+            const int inds = pos;
+            const int below = inds - 1 > 0 ? inds - 1 : 0;
+            const int above = inds < nb - 1 ? inds : nb - 1;
+            const float cb = s_cdf[below];
+            float denom = s_cdf[above] - cb;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uu - cb) / denom;
+            const float bb = s_bins[below];
+            const float span = s_bins[above] - bb;
+            const float m = t * span;
+            const float zs = bb + m;
+            s_zs[i] = zs;
+        }
+        __syncthreads();
+        for (int i = lane; i + 1 < Nf; i += 64) asc = asc && (s_zs[i] <= s_zs[i + 1]);
+        if (__all(asc)) {
+            // merge by rank: coarse z[i] goes to i + #{samples < z[i]}, sample zs[j] to j + #{coarse z <= zs[j]}
+            if (lane < Nc) {
+                int pos = 0;
+                for (int st = topf; st >= 1; st >>= 1) {
+                    const int p = pos + st, q = p <= Nf ? p : Nf;
+                    pos = (p <= Nf && s_zs[q - 1] < zl) ? p : pos;
+                }
+                s_out[lane + pos] = zl;
+            }
+            for (int j = lane; j < Nf; j += 64) {
+                const float v = s_zs[j];
+                int pos = 0;
+                for (int st = topc; st >= 1; st >>= 1) {
+                    const int p = pos + st, q = p <= Nc ? p : Nc;
+                    pos = (p <= Nc && s_z[q - 1] <= v) ? p : pos;
+                }
+                s_out[j + pos] = v;
+            }
+            __syncthreads();
+        } else {
+            int P = 1;
+            while (P < Nt) P <<= 1;
+            pdf_bitonic_fallback(s_out, s_z, s_zs, Nc, Nf, P, lane);
+        }
+        // the sorted union, and its labels (k_sample_labels' rule: the containing interval with the smallest t_in, lowest index first)
+        float* __restrict__ zo = zfine_out + r * Nt;
+        for (int i0 = 0; i0 < Nt; i0 += 256) {
+            float zz[4];
+            int best[4], ls[4], li[4];
+            float bt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + lane + 64 * k;
+                zz[k] = i < Nt ? s_out[i < Nt ? i : 0] : 0.0f;
+                best[k] = -1; ls[k] = -1; li[k] = -1; bt[k] = 0.0f;
+                if (i < Nt) zo[i] = zz[k];
+            }
+            if (lab.label_sem) {
+                for (int h = 0; h < cnt; ++h) {
+                    const float ti = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_ti), h));
+                    const float to = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_to), h));
+                    const int hs = __builtin_amdgcn_readlane(h_ls, h), hi2 = __builtin_amdgcn_readlane(h_li, h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool take = ti <= zz[k] && zz[k] <= to && (best[k] < 0 || ti < bt[k]);
+                        best[k] = take ? h : best[k];
+                        bt[k] = take ? ti : bt[k];
+                        ls[k] = take ? hs : ls[k];
+                        li[k] = take ? hi2 : li[k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + lane + 64 * k;
+                    if (i < Nt) {
+                        lab.label_sem[r * Nt + i] = ls[k];
+                        lab.label_inst[r * Nt + i] = li[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // two instances: <64, 256> (64 + 128 samples: every BASELINE config) at 64 registers and 3.4 KiB of LDS holds 8 waves per SIMD; the
 // general one (up to 256 + 256 samples) is bound by its 9.1 KiB of LDS per ray
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -617,7 +835,10 @@ static void launch_sample_pdf(const float* z, const float* weights, const float*
 {
     int P = 1;
     while (P < n_coarse + n_fine) P <<= 1;              // the bitonic path pads the union to a power of two
-    if (n_coarse <= 64 && P <= 256)
+    const bool general_only = getenv("PNR_SAMPLE_PDF_GENERAL") != nullptr;      // A/B switch (tests, tools): the general body everywhere
+    if (!u && !z_samples && !inds && z_fine && n_coarse <= 64 && n_fine <= 192 && P <= 256 && lab.max_hits <= 64 && !general_only)
+        hipLaunchKernelGGL(k_sample_pdf_det, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, st, z, weights, n_rays, n_coarse, n_fine, z_fine, lab);
+    else if (n_coarse <= 64 && P <= 256)
         hipLaunchKernelGGL(k_sample_pdf, dim3(pnr_grid_cap(n_rays, 32)), dim3(64), 0, st, z, weights, u, n_rays, n_coarse, n_fine,
                            z_samples, inds, z_fine, lab);
     else

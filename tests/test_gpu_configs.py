@@ -132,10 +132,12 @@ def test_baseline_config_full_frame_properties(dev, n):
 
 FRAME_TOL = {
     # (max, 99.9th percentile) of |hip - oracle| per map over the non-excluded rays of the 4,136-ray subset; depth in metres (far = 100).
-    # Derived from the printed histogram of the MI355X run committed as profiles/r06a_frame_scale_oracle_errors.txt: >= 2x the
-    # measured figure of the worst case of the four (config 4 / 5 x logits / softmax).
-    "rgb": (1e-2, 5e-3), "acc": (1e-2, 5e-3), "weights": (1e-2, 5e-3), "depth": (1.0, 0.3),
-    "semantic": (3e-2, 1e-2), "instance": (3e-2, 1e-2), "fix_semantic": (1e-2, 5e-3), "fix_instance": (1e-2, 5e-3),
+    # From the error histograms of the MI355X run committed as profiles/r06/r06c_frame_scale_oracle_errors.txt: ~3-5x the worst figure of
+    # the four cases (config 4 / 5 x logits / softmax; measured worst: rgb 1.7e-4 / 1.1e-4, acc 3.2e-4 / 2.1e-4, weights 3.2e-4 / 5.4e-5,
+    # depth 1.8e-2 / 5.8e-3 m, learned fields 5.6e-5 / 1.7e-5, fixed fields 2.1e-4 / 1.0e-5).  north_star's 1e-4 is the fp32 bar; this is
+    # the bf16 kernel that is benched, against the oracle in ITS arithmetic -- what is left is accumulation order and exp / sigmoid ulps.
+    "rgb": (1e-3, 5e-4), "acc": (1.5e-3, 1e-3), "weights": (1.5e-3, 3e-4), "depth": (0.1, 0.03),
+    "semantic": (3e-4, 1e-4), "instance": (3e-4, 1e-4), "fix_semantic": (1e-3, 1e-4), "fix_instance": (1e-3, 1e-4),
 }
 
 
@@ -191,7 +193,7 @@ def test_benched_kernel_against_the_oracle_at_frame_scale(dev, n, act):
                 # rays whose two best classes are within the map tolerance of each other may legitimately swap
                 top2 = want[k][ok].topk(2, -1).values
                 clear = (top2[:, 0] - top2[:, 1]) > 2 * FRAME_TOL[k][1]
-                agree_clear = float((got[k][ok][clear].argmax(-1) == want[k][ok][clear].argmax(-1)).float().mean())
+                agree_clear = float((got[k][ok][clear].argmax(-1) == want[k][ok][clear].argmax(-1)).float().mean()) if bool(clear.any()) else 1.0
                 lines.append("  %-13s lv %d  argmax agreement %.4f (all rays), %.4f (%d rays with a top-2 margin > %.0e)"
                              % (k, lv, agree, agree_clear, int(clear.sum()), 2 * FRAME_TOL[k][1]))
                 if not (agree >= 0.995 and agree_clear == 1.0):

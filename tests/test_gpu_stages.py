@@ -731,6 +731,61 @@ def test_sample_pdf_labels_is_sample_pdf_then_sample_labels_bit_for_bit(dev, Nc,
     assert np.array_equal(ls.cpu().numpy(), lsw) and np.array_equal(li.cpu().numpy(), liw)
 
 
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (64, 192), (64, 64), (48, 100), (33, 7), (3, 1), (5, 130)])
+def test_sample_pdf_inference_instance_equals_the_general_body_and_the_oracle(dev, Nc, Nf, monkeypatch):
+    """k_sample_pdf_det (round 6: deterministic u, merged z_fine + labels only, Nc <= 64 -- what every inference frame launches)
+    against the general body (PNR_SAMPLE_PDF_GENERAL=1 routes the same call to it) and the C oracle, bit for bit: ragged ray
+    counts, weights that leave the exact-scan regime (huge / denormal / zero rows: the sequential CDF), with and without the
+    label block, max_hits 1 / 3 / 8 with overflowing hit lists, and UNSORTED coarse z (the bitonic fallback)."""
+    rng = np.random.default_rng(Nc * 977 + Nf)
+    R = 1031
+    rays = synthetic.camera_rays()[::509][:R].contiguous()
+    box, ids = synthetic.random_boxes(48, 6, 3, seed=7)
+    d = lambda t: None if t is None else t.to(dev)
+    w = rng.uniform(0, 1, (R, Nc)).astype(np.float32) ** 4
+    if Nc > 8:
+        w[0::9, 7] = 3.0e4
+        w[3::9, 3] = 1.0e9
+    w[1::9] = 1.0e-30
+    w[2::9, ::2] = 0.0
+    w[4::9] = 0.0
+    w = torch.from_numpy(w)
+    z = ops.stratified(d(rays), Nc)
+    for mh in (8, 3, 1):
+        hits = ops.bbox_hits(d(rays), d(box), mh)
+        got = {}
+        for mode in ("det", "general"):
+            if mode == "general":
+                monkeypatch.setenv("PNR_SAMPLE_PDF_GENERAL", "1")
+            else:
+                monkeypatch.delenv("PNR_SAMPLE_PDF_GENERAL", raising=False)
+            zf, ls, li = ops.sample_pdf_labels(z, d(w), Nf, hits, d(ids), None)
+            zf2, _, _ = ops.sample_pdf(z, d(w), Nf, None, want_samples=False)
+            got[mode] = (zf.clone(), ls.clone(), li.clone(), zf2.clone())
+        for a, b in zip(got["det"], got["general"]):
+            assert torch.equal(a, b), (Nc, Nf, mh)
+        assert torch.equal(got["det"][0], got["det"][3])
+        if mh == 8:
+            zs, _ = co.sample_pdf(z.cpu().numpy(), w.numpy(), Nf)
+            zw = co.merge_sorted(z.cpu().numpy(), zs)
+            assert np.array_equal(got["det"][0].cpu().numpy(), zw)
+            lsw, liw = co.sample_labels(zw, *(h.cpu().numpy() for h in hits), ids.numpy())
+            assert np.array_equal(got["det"][1].cpu().numpy(), lsw) and np.array_equal(got["det"][2].cpu().numpy(), liw)
+    # unsorted coarse depths: not a merge of two sorted lists -> both bodies sort the union
+    zu = z.clone()
+    zu[::3] = zu[::3].flip(-1)
+    out = {}
+    for mode in ("det", "general"):
+        if mode == "general":
+            monkeypatch.setenv("PNR_SAMPLE_PDF_GENERAL", "1")
+        else:
+            monkeypatch.delenv("PNR_SAMPLE_PDF_GENERAL", raising=False)
+        out[mode] = ops.sample_pdf(zu, d(w), Nf, None, want_samples=False)[0].clone()
+    monkeypatch.delenv("PNR_SAMPLE_PDF_GENERAL", raising=False)
+    assert torch.equal(out["det"], out["general"])
+    assert bool((out["det"][:, 1:] >= out["det"][:, :-1]).all())
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("tap,depth", [("feature", 2), ("trunk", 1), ("feature", 1)])
 @pytest.mark.parametrize("geom", [(8, 256, [4], 45, 32), (4, 128, [1], 6, 0)])
