@@ -57,6 +57,7 @@ V_ZZ, V_ZN, V_DN, V_LW = 240, 242, 244, 246      # [2] each: per-tile compositin
 V_IN = 224                              # next group's inputs [2][8]: ox oy oz dx dy dz zz zn   (v[224:239])
 V_TMP = 208                             # encoder / epilogue temporaries share the g area once g is dead: v[208:223]
 V_PTMP = 248                            # 8 more temporaries v[248:255]
+V_LWA = V_IN + 2                        # address of the local-weight table reads in a group's last unit (the next group's o_z: dead since its point)
 # ---- AGPR map: two activation arrays of [2 tiles][64]
 A0, A1 = 0, 128
 # ---- SGPR map
@@ -68,6 +69,8 @@ S_LO32, S_N0, S_HI0 = 52, 54, 56        # constants: lanes 0..31, lanes {0, 32},
 S_SAVE, S_REC_T = 58, 60                # saved exec; the two tiles' record pointers s[60:61], s[62:63]
 S_MSK = 64                              # store masks of the (up to) three logit blocks: s[64:69] = lanes with hi == 0 and channel < n_out
 S_REC_I = 70                            # the two tiles' record pointers + 4 n_sem (the instance columns): s[70:73]
+S_LWW, S_LWR = 74, 75                   # LDS addresses of this wave's local-weight table: + 4 (lane & 31) to write, + (V_BIAS[0] = slot 0 + 16 hi) to read
+LW_BASE = NSLOT * SLOT                  # [4 waves][2 tiles][32 floats] behind the weight slots (1 KiB)
 S_CLK0 = 96                             # s[96:99] clocks at start
 S_K = 100                               # s100: literal constants that VOP3 cannot carry
 S_Q = 19                                # the tile's Q (v_readlane) between the scan and its store
@@ -146,6 +149,7 @@ class Gen:
         self.m0 = None
         self.logit_units = []
         self.acc_free = list(range(8))
+        self.lwr_acc = self.lwr_tag = None
         self.build_plan()
         self.build_units()
         self.stream = []
@@ -739,7 +743,15 @@ class Gen:
             e("v_mov_b32_dpp v%d, v%d wave_shr:1 row_mask:0xf bank_mask:0xf" % (n, f))
             e("v_cndmask_b32 v%d, v%d, 1.0, s[%d:%d]" % (n, n, S_N0, S_N0 + 1))        # lane n == 0: 1
             e("v_mul_f32 v%d, v%d, v%d" % (V_LW + t, al, n))                          # lw = alpha * exclusive product
-        self.q(26, scan)
+            if self.nbs:
+                # ... and into this wave's LDS table (lanes 0..31: sample n's weight at 4 n): the logit tail reads its per-register weights
+                # lwr[r] = lw[row(r, hi)] back with ds_read_b64 (round 6; 64 v_readlane + 64 v_mov per group before: 864 cycles in the open)
+                with self.atomic():
+                    e("v_add_u32 v%d, s%d, v%d" % (n, S_LWW, V_LB4))
+                    e("s_mov_b64 exec, s[%d:%d]" % (S_HI0, S_HI0 + 1))
+                    self.lds_read("ds_write_b32 v%d, v%d offset:%d" % (n, V_LW + t, 128 * t))
+                    e("s_mov_b64 exec, -1")
+        self.q(26 + (4 if self.nbs else 0), scan)
 
         def stores():
           with self.atomic():
@@ -774,54 +786,6 @@ class Gen:
             self.vm_op("global_store_dword v%d, v%d, s[%d:%d]%s" % (d, x, S_REC_T + 2 * t, S_REC_T + 2 * t + 1, STORE_NT))
             e("s_mov_b64 exec, -1")
         self.q(28, stores)
-
-    # ---- a transposed 32-channel logit block of tile t (fuse_logits_t): rec[rec_base + ch] = sum_r lwr[r] acc[r] (+ other half)
-    def lwr_load(self, t):
-        """the tile's 32 local weights -> s[S_W : S_W + 32) (lane order)"""
-        e = self.e
-        e("s_nop 1")
-        for lane in range(32):
-            e("v_readlane_b32 s%d, v%d, %d" % (S_W + lane, V_LW + t, lane))
-
-    def logits_epilogue(self, t, acc, blk, inst):
-        e = self.e
-        T = list(range(V_TMP, V_TMP + 16))
-        s_, o, adr = V_PTMP, V_PTMP + 1, V_PTMP + 2
-
-        def body():
-            # lwr[r] (lwr_build): v[V_TMP + r] = hi ? lw[row(r, 1)] : lw[row(r, 0)]
-            self.wait_lgkm(self.lwr_tag)
-            e("v_fma_f32 v%d, v%d, v%d, 0" % (s_, T[0], acc))
-            for r in range(1, 16):
-                e("v_fmac_f32 v%d, v%d, v%d" % (s_, T[r], acc + r))
-            # s += s of the other half-wave (lane ^ 32)
-            e("v_xor_b32 v%d, 32, v%d" % (adr, V_TID))
-            e("v_and_b32 v%d, 63, v%d" % (adr, adr))
-            e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
-            tag = self.lds_read("ds_bpermute_b32 v%d, v%d, v%d" % (o, adr, s_))
-            # channel ch = blk * 32 + (lane & 31); store for hi == 0 and ch < n_out
-            e("v_and_b32 v%d, 31, v%d" % (adr, V_TID))
-            e("v_add_u32 v%d, %d, v%d" % (adr, blk * 32, adr))
-            e("v_cmp_gt_i32 vcc, s%d, v%d" % (S_NINST if inst else S_NSEM, adr))
-            e("s_and_b64 s[%d:%d], vcc, s[%d:%d]" % (S_SAVE, S_SAVE + 1, S_HI0, S_HI0 + 1))
-            e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
-            self.wait_lgkm(tag)
-            e("v_add_f32 v%d, v%d, v%d" % (o, s_, o))
-            self._logits_store(t, adr, o, inst)
-        return body
-
-    def _logits_store(self, t, adr, o, inst):
-        e = self.e
-        with self.atomic():
-            e("s_mov_b64 exec, s[%d:%d]" % (S_SAVE, S_SAVE + 1))
-            if inst:                # record column 1 + n_sem + ch
-                e("s_lshl_b32 s%d, s%d, 2" % (S_T0, S_NSEM))
-                e("s_add_u32 s%d, s%d, s%d" % (S_T0, S_REC_T + 2 * t, S_T0))
-                e("s_addc_u32 s%d, s%d, 0" % (S_T1, S_REC_T + 2 * t + 1))
-                self.vm_op("global_store_dword v%d, v%d, s[%d:%d] offset:4" % (adr, o, S_T0, S_T1))
-            else:                   # record column 1 + ch
-                self.vm_op("global_store_dword v%d, v%d, s[%d:%d] offset:4" % (adr, o, S_REC_T + 2 * t, S_REC_T + 2 * t + 1))
-            e("s_mov_b64 exec, -1")
 
     # ------------------------------------------------------------------ accumulators
     def acc_reg(self, i):
@@ -963,9 +927,15 @@ class Gen:
             for op in plans[kk]:
                 musts.append(op)
                 dls.append(None)
+        if nxt is None and (self.logit_units or l["mode"] == "logits"):
+            # the group's last unit: the logit tail's per-register weights lwr[r] = lw[row(r, hi)] of both tiles come back from the LDS
+            # table (rgbs_epilogue: scan) into the two accumulators nobody holds any more -- behind the packs that release them
+            for op in self.lwr_ops():
+                musts.append(op)
+                dls.append(None)
         n = len(musts)
         pos = []
-        late = not packs and n > 0                      # nothing to pack (the previous unit's results go through the side queue and hold
+        late = not packs and n > 0 and nxt is not None  # nothing to pack (the previous unit's results go through the side queue and hold
         for j in range(n):                              # their accumulators until then): arm in the unit's last third
             spread = 1 + (j * max(1, nm - 6)) // max(1, n) if not late else (2 * nm) // 3 + (j * max(1, nm // 3 - 5)) // max(1, n)
             pos.append(spread if dls[j] is None else min(spread, max(0, dls[j] - 2)))
@@ -1065,6 +1035,26 @@ class Gen:
                     e("s_barrier")
                 d += 1
 
+    def lwr_ops(self):
+        """closures (one instruction each) that load lwr of both tiles: 8 ds_read_b64 per tile.  lw[8 q + 4 hi + j], j = 0..3, is
+        register 4 q + ((j + 2) & 3) of the tile's block -- two positions round its quad, so that the tail's FMA (lwr[r] x register r
+        of a 16-aligned accumulator) reads its two operands from different VGPR banks (register number mod 4)"""
+        ops = []
+
+        def first():
+            assert len(self.acc_free) >= 2, ("no free accumulators for the local weights", self.acc_free)
+            self.lwr_acc = self.acc_take(2)
+            self.e("v_add_u32 v%d, s%d, v%d" % (V_LWA, S_LWR, V_BIAS + 0))
+        ops.append(first)
+        for t in range(2):
+            for q in range(4):
+                for h2 in range(2):
+                    def rd(t=t, q=q, h2=h2):
+                        dst = self.acc_reg(self.lwr_acc[t]) + 4 * q + ((2 * h2 + 2) & 3)
+                        self.lwr_tag = self.lds_read("ds_read_b64 %s, v%d offset:%d" % (vr(dst, 2), V_LWA, 128 * t + 32 * q + 8 * h2))
+                    ops.append(rd)
+        return ops
+
     def logit_blocks(self):
         return [(b, False) for b in range(self.nbs)] + [(0, True)] * self.nbi
 
@@ -1082,32 +1072,14 @@ class Gen:
             for bi, blk in enumerate(u["blocks"]):
                 blocks.append((u, bi, blk, inst))
         nb = len(blocks)
-        lwr = (V_TMP, V_RING)
+        lwr = tuple(self.acc_reg(a) for a in self.lwr_acc)
 
         def lwr_reg(t, r):
-            # weight r of tile t lives one register further round its block of 16: the FMA below reads lwr[r] and register r of an
-            # accumulator, and with both at the same offset from a multiple of 16 they sat in the same VGPR bank (register number
-            # mod 4) -- every FMA of the tail paid a bank conflict
-            return lwr[t] + ((r + 1) & 15)
+            return lwr[t] + 4 * (r >> 2) + (((r & 3) + 2) & 3)            # see lwr_ops
         sums = ([V_PTMP + k for k in range(nb)], [V_IN + 1 + k for k in range(nb)])
         oth = ([V_PTMP + 3 + k for k in range(nb)], [V_IN + 4, V_IN + 5, V_IN + 9][:nb])
         adr = V_PTMP + 7
-        S_LW = S_REC_I + 4                              # 16 SGPRs: the local weights of eight sample-row pairs
-        for t in range(2):
-            # lwr[r] = lw[row(r, 0) + 4 hi], row(r, 0) = (r & 3) + 8 (r >> 2): in two halves of eight registers (16 v_readlane each:
-            # VALU only -- 32 ds_bpermute_b32 measured ~35 cycles each here, where nothing overlaps them)
-            for half in range(2):
-                rows = [(r & 3) + 8 * (r >> 2) for r in range(8 * half, 8 * half + 8)]
-                for i, row in enumerate(rows):
-                    e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i, V_LW + t, row))
-                    e("v_readlane_b32 s%d, v%d, %d" % (S_LW + 2 * i + 1, V_LW + t, row + 4))
-                for i in range(8):
-                    e("v_mov_b32 v%d, s%d" % (lwr_reg(t, 8 * half + i), S_LW + 2 * i + 1))
-                e("s_mov_b64 exec, s[%d:%d]" % (S_HI0, S_HI0 + 1))
-                for i in range(8):
-                    e("v_mov_b32 v%d, s%d" % (lwr_reg(t, 8 * half + i), S_LW + 2 * i))
-                e("s_mov_b64 exec, -1")
-        tag_lwr = [None, None]
+        tag_lwr = [self.lwr_tag, self.lwr_tag]          # (in order: the last read covers all sixteen)
         e("v_xor_b32 v%d, 32, v%d" % (adr, V_TID))
         e("v_and_b32 v%d, 63, v%d" % (adr, adr))
         e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
@@ -1145,13 +1117,9 @@ class Gen:
         stores(1)
         for u in self.logit_units:
             self.acc_release(list(u["accs"].values()))
+        self.acc_release(self.lwr_acc)
+        self.lwr_acc = None
         self.logit_units = []
-
-    def lwr_build(self, t):
-        """lwr[r] of tile t -> v[V_TMP + r] = lw[row(r, 0) + 4 hi]: sixteen ds_bpermute_b32 (address = hi * 16 + 4 row(r, 0)); the 32
-        v_readlane + 32 v_mov of the first version were a fifth of the heads' side work"""
-        for r in range(16):
-            self.lwr_tag = self.lds_read("ds_bpermute_b32 v%d, v%d, v%d offset:%d" % (V_TMP + r, V_BIAS, V_LW + t, 4 * ((r & 3) + 8 * (r >> 2))))
 
     def queue_inputs_early(self):
         """side work from the first unit behind the skip layer on (gamma(x) of this group is dead): the next group's inputs, its
@@ -1188,7 +1156,10 @@ class Gen:
         self.park_acc = None
 
     def queue_inputs_late(self):
-        """behind the rgb / sigma unit (gamma(d) of this group is dead): gamma(d) of the next group"""
+        """behind the rgb / sigma unit (gamma(d) of this group is dead): gamma(d) of the next group.  (Round 6 tried the skip layer's
+        one-block units of the SAME group instead -- the emptiest gaps of the loop: bit-identical, and no faster: the skip layer's units
+        grew by what the head units shrank, profiles/r06/r06f.  What the kernel pays for is the NUMBER of non-MFMA instructions, not
+        where they stand.)"""
         for t in range(2):
             for cost, fn in self.encode_tile(t, "d"):
                 self.q(cost, fn, low=True)
@@ -1294,6 +1265,9 @@ class Gen:
         e("s_mov_b32 s%d, 1" % (S_N0 + 1))
         e("s_mov_b32 s%d, -1" % S_HI0)
         e("s_mov_b32 s%d, 0" % (S_HI0 + 1))
+        e("s_lshr_b32 s%d, s%d, 4" % (S_LWW, S_W4K))                      # wave * 256: this wave's [2 tiles][32] local-weight table
+        e("s_add_u32 s%d, s%d, 0x%x" % (S_LWW, S_LWW, LW_BASE))
+        e("s_sub_u32 s%d, s%d, 0x%x" % (S_LWR, S_LWW, slot_base(0)))      # + V_BIAS[0] (= slot 0's base + 16 hi) = table + 16 hi
         e("s_waitcnt lgkmcnt(0)")
         # store masks of the logit blocks (constant): channel = 32 blk + (lane & 31) < n_out, lanes 0..31 only
         for k, (blk, inst) in enumerate(self.logit_blocks()):
@@ -1399,7 +1373,7 @@ class Gen:
         e("s_endpgm")
         self.o += [".Lend_%s:" % name, "\t.size\t%s, .Lend_%s-%s" % (name, name, name), ""]
         self.o += ["\t.rodata", "\t.p2align\t6", "\t.amdhsa_kernel %s" % name,
-                   "\t\t.amdhsa_group_segment_fixed_size %d" % (NSLOT * SLOT),
+                   "\t\t.amdhsa_group_segment_fixed_size %d" % (NSLOT * SLOT + 1024),
                    "\t\t.amdhsa_private_segment_fixed_size 0", "\t\t.amdhsa_kernarg_size %d" % KERNARG_BYTES, "\t\t.amdhsa_user_sgpr_count 2",
                    "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1", "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
                    "\t\t.amdhsa_system_vgpr_workitem_id 0", "\t\t.amdhsa_next_free_vgpr 512", "\t\t.amdhsa_next_free_sgpr 102",
@@ -1416,7 +1390,7 @@ def metadata(names):
     o = ["\t.amdgpu_metadata", "---", "amdhsa.kernels:"]
     for n in names:
         o += ["  - .agpr_count:     256", "    .args:", "      - .offset:         0", "        .size:           %d" % KERNARG_BYTES,
-              "        .value_kind:     by_value", "    .group_segment_fixed_size: %d" % (NSLOT * SLOT),
+              "        .value_kind:     by_value", "    .group_segment_fixed_size: %d" % (NSLOT * SLOT + 1024),
               "    .kernarg_segment_align: 8", "    .kernarg_segment_size: %d" % KERNARG_BYTES, "    .max_flat_workgroup_size: 256",
               "    .name:           %s" % n, "    .private_segment_fixed_size: 0", "    .sgpr_count:     108",
               "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % n, "    .uniform_work_group_size: 1",
