@@ -62,7 +62,7 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
                                        64 x 2: 1.98 ms, 32 x 4: 2.00-2.11, 32 x 5: 2.04-2.11, 16 x 8: 2.75-2.80 */
 #endif
 #define WG_TILE_BYTES (WG_KT * 512) /* one operand tile at the widest region (256 slots) */
-static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && WG_NBUF * 2 * WG_TILE_BYTES <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
+static_assert(WG_KT % 16 == 0 && WG_NBUF >= 2 && WG_NBUF * (2 * WG_TILE_BYTES + WG_KT * 64) <= 163840, "wgrad tile ring does not fit the 160 KiB LDS");
 #ifndef WG_STACK_HEADS
 #define WG_STACK_HEADS 1            /* sem0 + inst0 as one stacked-dY job (A/B knob) */
 #endif
@@ -74,8 +74,16 @@ struct WgJob {
     int64_t a2_off;                 // -1, or a SECOND dY region of the same width stacked under the first (rows ma/2 .. ma-1):
                                     // two layers that read the same X (the semantic and instance heads' first Linear) in one pass
     int64_t p_off;                  // float offset of this job's partials: [n_slabs][ma][nb + WG_BIAS_COLS]
+    int64_t a3_off, p3_off;         // -1, or an EXTRA 32-slot dY region multiplied by the same X in the same pass (round 6: the [rgb, sigma]
+                                    // gradient block beside dY_feature -- alpha_linear reads h like feature_linear does, and its own
+                                    // job read all of h again for ONE useful row): its partials [n_slabs][32][nb + WG_BIAS_COLS] at p3_off
     int ma, nb;                     // widths in slots: 32, 64, 128 or 256 (ma: both stacked regions together)
 };
+#ifndef WG_MERGE_ALPHA
+#define WG_MERGE_ALPHA 1            /* the alpha row rides in the feature job (A/B knob) */
+#endif
+#define WG_EXTRA_TILE_BYTES (WG_KT * 64)    /* one 32-slot bf16 tile */
+#define WG_LDS_BYTES (WG_NBUF * (2 * WG_TILE_BYTES + WG_EXTRA_TILE_BYTES))
 struct WgArgs {
     const uint16_t* acts; const uint16_t* dys;
     float* partial;
@@ -111,6 +119,7 @@ __device__ __forceinline__ void wg_landed(bf16x8 (&fa)[TM], bf16x8 (&fb)[TN])
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[j]));
 }
+__device__ __forceinline__ void wg_touch(bf16x8& f) { asm volatile("" : "+v"(f)); }     // (covered by the same counted wait)
 struct WgGridT { int wm, wn; };
 constexpr WgGridT wg_grid(int MB, int NB)
 {
@@ -126,7 +135,10 @@ constexpr WgGridT wg_grid(int MB, int NB)
 
 // One (job, slab) of shape MB x NB blocks: partial[ma][nb + 32] = sum over the slab's samples of dY^T [X | 1].
 // STACK: the dY tile is two verbatim sub-tiles of MB / 2 row blocks each (WgJob::a2_off), one behind the other in the LDS.
-template <int MB, int NB, bool STACK = false>
+// EXTRA: one more 32-slot dY region (WgJob::a3_off) against the same X tile: its row block x the NB column blocks is spread over the
+// waves -- wave (wm, wn) takes column block wn * TN + wm, whose X fragment it reads anyway (needs WM == TN) -- and accumulated in
+// the same k order as a job of its own would (bit-identical partials).
+template <int MB, int NB, bool STACK = false, bool EXTRA = false>
 __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const int jb, const int slab, const int lane, const int wave)
 {
     constexpr WgGridT G = wg_grid(MB, NB);
@@ -136,7 +148,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     constexpr int subA = WG_KT * cprA * 16;                         // bytes of one dY (sub-)tile
     static_assert(!STACK || (MB % 2 == 0 && TM <= MBS && MBS % TM == 0), "a wave's row blocks lie in one of the stacked regions");
     constexpr int piecesS = WG_KT * cprA / 64;                      // 1 KiB pieces of one dY (sub-)tile
-    constexpr int piecesA = (STACK ? 2 : 1) * piecesS, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB;
+    constexpr int piecesE = EXTRA ? WG_KT * 4 / 64 : 0;             // the extra region's tile: 4 chunks per row
+    static_assert(!EXTRA || (WM == TN && WM * WN == 8 && !STACK), "extra row block: one column block per wave");
+    constexpr int piecesA = (STACK ? 2 : 1) * piecesS, piecesB = WG_KT * cprB / 64, pieces = piecesA + piecesB + piecesE;
     constexpr int NQ = (pieces + 7) / 8;                            // LDS-DMA pieces per wave and tile (at most)
     constexpr int NKS = WG_KT / 16;
 
@@ -151,6 +165,8 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     const char* const srcA = reinterpret_cast<const char*>(Ag);         // wave-uniform bases: pnr_dma_piece adds 16 * lane
     const char* const srcA2 = STACK ? reinterpret_cast<const char*>(a.dys + a.job[jb].a2_off) : srcA;
     const char* const srcB = reinterpret_cast<const char*>(Bg);
+    const char* const srcE = EXTRA ? reinterpret_cast<const char*>(a.dys + a.job[jb].a3_off) : srcA;
+    char* const smemE = smem + WG_NBUF * 2 * WG_TILE_BYTES;         // the extra tiles live behind the ring
     auto issue = [&](int t, int buf, int q0, int q1) {
         const int64_t g0 = (s_begin + t * WG_KT) >> 3;              // first 8-sample group of the tile
         char* const dst = smem + buf * 2 * WG_TILE_BYTES;
@@ -159,6 +175,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             if (q < q0 || q >= q1) continue;
             const int p = wave + 8 * q;
             if (p >= pieces) continue;
+            if (EXTRA && p >= piecesA + piecesB) {
+                const int pe = p - piecesA - piecesB;
+                pnr_dma_piece<WG_DMA_AUX>(srcE + g0 * (4 * 128) + pe * 1024, smemE + buf * WG_EXTRA_TILE_BYTES + pe * 1024, lane * 16);
+                continue;
+            }
             const bool isA = p < piecesA;
             const int pp = isA ? p : p - piecesA;                   // LDS side: the sub-tiles of a stacked dY lie back to back
             const bool second = STACK && isA && p >= piecesS;
@@ -185,10 +206,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
 #pragma unroll
     for (int j = 0; j < TN; ++j) offB[j] = (hi * cprB + (wn * TN + j) * 4 + cin) * 128 + pos;
 
+    const int offE = WG_NBUF * 2 * WG_TILE_BYTES + (hi * 4 + cin) * 128 + pos;      // the extra block: chunks 0..3 of a 4-chunk row
     static_assert(TM <= WN || (TM == 1 && WN == 1), "one bias block per wave at most");
     const int isel = wn;                                            // the row block whose bias (row sum) this wave accumulates
     const bool has_bias = wn < TM;
-    f32x16 acc[TM][TN], bacc;
+    f32x16 acc[TM][TN], bacc, eacc;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -196,7 +218,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bacc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { bacc[r] = 0.0f; eacc[r] = 0.0f; }
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -234,17 +256,19 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
     // every LDS read that follows an LDS-DMA request (it cannot tell the buffers apart) and lgkmcnt(0) in front of every
     // MFMA, which serialises request -> land -> read -> multiply per k-step.  ds_read_b64_tr_b16 hands a lane 4 consecutive
     // samples of its feature; the reads at rows ks*16 and ks*16 + 4 make one k = 16 MFMA operand.
-    bf16x8 fa[2][TM], fb[2][TN];
-    int adA[TM], adB[TN], adA2[TM], adB2[TN];
+    bf16x8 fa[2][TM], fb[2][TN], fe[2][1];
+    int adA[TM], adB[TN], adA2[TM], adB2[TN], adE[1], adE2[1];
     auto load = [&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         wg_load_frags<ks * 2 * cprA * 128, TM>(adA, adA2, fa[ks & 1]);              // k-step ks = sample groups 2ks, 2ks + 1
         wg_load_frags<WG_TILE_BYTES + ks * 2 * cprB * 128, TN>(adB, adB2, fb[ks & 1]);
+        if constexpr (EXTRA) wg_load_frags<ks * 2 * 4 * 128, 1>(adE, adE2, fe[ks & 1]);
     };
     // the fragments of k-step ks have landed once at most PENDING younger reads are outstanding (LDS reads return in order)
     auto landed = [&](auto ks_c, auto pending_c) {
         constexpr int ks = decltype(ks_c)::value;
         wg_landed<decltype(pending_c)::value, TM, TN>(fa[ks & 1], fb[ks & 1]);
+        if constexpr (EXTRA) wg_touch(fe[ks & 1][0]);
     };
     auto mma = [&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
@@ -257,8 +281,14 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
         if (has_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fsel, ones, bacc, 0, 0, 0);
+        if constexpr (EXTRA) {
+            bf16x8 bsel = fb[ks & 1][0];
+#pragma unroll
+            for (int j = 1; j < TN; ++j) bsel = wm == j ? fb[ks & 1][j] : bsel;
+            eacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fe[ks & 1][0], bsel, eacc, 0, 0, 0);
+        }
     };
-    constexpr int RD = 2 * (TM + TN);                               // ds_reads per k-step
+    constexpr int RD = 2 * (TM + TN + (EXTRA ? 1 : 0));             // ds_reads per k-step
     static_assert(RD <= 15, "lgkmcnt is a 4-bit counter");
 
 #pragma unroll
@@ -274,6 +304,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
         for (int i = 0; i < TM; ++i) { adA[i] = offA[i] + buf * 2 * WG_TILE_BYTES; adA2[i] = adA[i] ^ 64; }
 #pragma unroll
         for (int j = 0; j < TN; ++j) { adB[j] = offB[j] + buf * 2 * WG_TILE_BYTES; adB2[j] = adB[j] ^ 64; }
+        if constexpr (EXTRA) { adE[0] = offE + buf * WG_EXTRA_TILE_BYTES; adE2[0] = adE[0] ^ 64; }
         // software pipeline: the fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued; the next
         // tile's LDS-DMA goes out behind the first fragment requests, so only those are exposed per tile
         load(std::integral_constant<int, 0>{});
@@ -310,6 +341,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, char* const smem, const
             if (has_bias && i == isel && n == 0) P[(int64_t)row * ldp + NB * 32] = bacc[r];
         }
     }
+    if constexpr (EXTRA) {      // the extra region's partials: [32][nb + 32] of this slab, column block wn * TN + wm
+        float* const PE = a.partial + a.job[jb].p3_off + (int64_t)slab * 32 * ldp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) PE[(int64_t)pnr_row_of(r, hl) * ldp + (wn * TN + wm) * 32 + n] = eacc[r];
+    }
 }
 
 __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
@@ -327,6 +363,10 @@ __global__ __launch_bounds__(512, 1) void k_wgrad(const WgArgs a)
     const int shape = (31 - __builtin_clz(a.job[jb].ma >> 5)) * 4 + (31 - __builtin_clz(a.job[jb].nb >> 5));
     if (a.job[jb].a2_off >= 0) {       // two stacked 128-slot dY regions against one 256-slot X (wg_plan makes no other stack)
         wg_body<8, 8, true>(a, smem, jb, slab, lane, wave);
+        return;
+    }
+    if (a.job[jb].a3_off >= 0) {       // dY_feature (256 slots) + the [rgb, sigma] gradient block against h (256 slots)
+        wg_body<8, 8, false, true>(a, smem, jb, slab, lane, wave);
         return;
     }
     switch (shape) {
@@ -430,6 +470,7 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     auto add_job = [&](int64_t a_off, int64_t a2_off, int ma, int64_t b_off, int nb) {
         WgJob& j = pl.job[pl.n++];
         j.a_off = a_off; j.a2_off = a2_off; j.b_off = b_off; j.ma = ma; j.nb = nb; j.p_off = po;
+        j.a3_off = -1; j.p3_off = 0;
         po += (int64_t)pl.n_slabs * ma * (nb + WG_BIAS_COLS);
         return j.p_off;
     };
@@ -451,9 +492,22 @@ static void wg_plan(const pnr_mlp_desc& d, int64_t S, const pnr_mlp_params_host*
     }
     const int64_t Xh = ao[1 + D];
     add(dof[1], W, Xh, W, 0, W, PNR_SEG_FEAT, 0, W, have ? F(g->feature_w) : nullptr, W, 0, have ? F(g->feature_b) : nullptr);
+    const bool merge_alpha = WG_MERGE_ALPHA && W == 256;        // (the 8 x 8-block shape: WM == TN == 2)
+    const int feat_job = pl.n - 1;
     add(dof[0], H, ao[2 + D], W, 0, H, PNR_SEG_FEAT, 0, W, have ? F(g->views_w) : nullptr, W + EDn, 0, have ? F(g->views_b) : nullptr);
     add(dof[0], H, ao[1], 32, 0, H, PNR_SEG_GD, d.dir_L, EDn, have ? F(g->views_w) : nullptr, W + EDn, W, nullptr);
     add(dof[4 + D], 32, ao[3 + D], H, 0, 3, PNR_SEG_FEAT, 0, H, have ? F(g->rgb_w) : nullptr, H, 0, have ? F(g->rgb_b) : nullptr);
+    if (merge_alpha) {
+        // alpha_linear reads h as feature_linear does: its dY row (sigma = row 3 of the [rgb, sigma] block) rides in the feature job as
+        // an extra row block -- h is read once less (512 + 64 of the 13.2 KB a sample cost this kernel); its bias gradient is the
+        // row sum the rgb job (previous add) already forms for the same block
+        WgJob& fj = pl.job[feat_job];
+        fj.a3_off = dof[4 + D];
+        fj.p3_off = po;
+        po += (int64_t)pl.n_slabs * 32 * (W + WG_BIAS_COLS);
+        add_red(fj.p3_off, 32, W, 3, 1, PNR_SEG_FEAT, 0, W, have ? F(g->alpha_w) : nullptr, W, 0, nullptr);
+        add_red(pl.job[pl.n - 1].p_off, 32, H, 3, 1, PNR_SEG_FEAT, 0, 0, nullptr, 1, 0, have ? F(g->alpha_b) : nullptr);
+    } else
     add(dof[4 + D], 32, Xh, W, 3, 1, PNR_SEG_FEAT, 0, W, have ? F(g->alpha_w) : nullptr, W, 0, have ? F(g->alpha_b) : nullptr);
     const int64_t Xtap = d.head_tap ? ao[2 + D] : Xh;       // what the heads read: the feature (head_tap 1) or h
     // the first Linear of both heads reads the same X: one pass over it with the two dY regions stacked (X read once instead
@@ -507,7 +561,7 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     wg_plan(*desc, n_samples, grads_dev, pl);
     PNR_REQUIRE(pl.n <= WG_MAX_JOBS && pl.n_red <= WG_MAX_JOBS, "pnr_mlp_wgrad: too many jobs");
     for (int i = 0; i < pl.n_red; ++i)  // out_b is null by design for the second job of a concatenated weight
-        PNR_REQUIRE(pl.red[i].out, "pnr_mlp_wgrad: a weight-gradient pointer of grads_dev is null");
+        PNR_REQUIRE(pl.red[i].out || pl.red[i].n_cols == 0, "pnr_mlp_wgrad: a weight-gradient pointer of grads_dev is null");
     PNR_REQUIRE(grads_dev->alpha_b && grads_dev->rgb_b && grads_dev->feature_b && grads_dev->views_b,
                 "pnr_mlp_wgrad: a bias-gradient pointer of grads_dev is null");
     WgArgs a;
@@ -518,10 +572,10 @@ PNR_EXPORT int pnr_mlp_wgrad(const pnr_mlp_desc* desc, const void* acts, const v
     for (int i = 0; i < pl.n; ++i) a.job[i] = pl.job[i];
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, WG_NBUF * 2 * WG_TILE_BYTES));
+        PNR_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), WG_NBUF * 2 * WG_TILE_BYTES, st, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(pl.n * pl.n_slabs), dim3(512), WG_LDS_BYTES, st, a);
     PNR_CHECK_LAUNCH("pnr_mlp_wgrad");
     WgRedArgs r;
     memset(&r, 0, sizeof(r));

@@ -286,13 +286,17 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
-        with torch.cuda.graph(self.graph):
+        # capture_error_mode "thread_local": the default ("global") makes EVERY thread's stream-unsafe call an error while this
+        # thread captures -- and a process group's watchdog thread polls the events of the warm-up's collectives on its own
+        # schedule: a poll that lands inside the capture kills the process ("operation not permitted when stream is capturing",
+        # seen once in round 6 with a one-rank nccl group).  Everything captured here is issued by this thread.
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = self._fwd_bwd()
             if reduce is None:
                 optimizer.step()
         if reduce is not None:
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 optimizer.step()
 
     def _fwd_bwd(self):

@@ -277,7 +277,7 @@ def test_training_step_is_graph_capturable(dev):
     for a, b in zip(net_e.parameters(), net_g.parameters()):
         assert torch.equal(a, b)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         static_loss = step_g()
     losses_g = []
     for _ in range(3):

@@ -303,6 +303,6 @@ def test_training_trajectory_at_the_benched_geometry(dev):
 # 8.3e-3, worst tensor 6.3e-2 / 4.2e-2 / 2.7e-2 at k = 5 / 10 / 20); measured on the MI355X (r05e): pooled 1.58e-2 / 1.05e-2 / 8.9e-3,
 # worst 8.6e-2 / 5.5e-2 / 4.0e-2 -- the HIP fp32 mode IS a jittered fp32 student.  bf16: 1.5 x the bf16_bwd students' own jitter
 # distance (pooled 1.19e-1 / 9.2e-2 / 7.1e-2, worst 0.42 / 0.31 / 0.21); measured 9.0e-2 / 6.9e-2 / 5.1e-2, worst 0.48 / 0.37 / 0.21.
-TRAJ_SCALE = 0.06      # |pooled projection coefficient - 1| of a HIP student's update on its CPU twin's (measured: see profiles/r06)
+TRAJ_SCALE = 0.03      # |pooled projection coefficient - 1| of a HIP student's update on its CPU twin's: measured 0.9958 / 0.9976 / 0.9989 (bf16) and 0.9999 / 1.0000 / 1.0000 (fp32 mode) at k = 5 / 10 / 20 (profiles/r06/r06g); an off-by-one Adam step gives 0.874
 TRAJ_POOLED = {"fp32": {5: 0.035, 10: 0.025, 20: 0.021}, "bf16": {5: 0.18, 10: 0.14, 20: 0.107}}
 TRAJ_WORST = {"fp32": {5: 0.16, 10: 0.105, 20: 0.07}, "bf16": {5: 0.63, 10: 0.46, 20: 0.31}}

@@ -183,7 +183,7 @@ def test_render_chunk_is_graph_capturable(dev):
         rend.render_rays(static_in, box, ids)            # warm-up (lazy module loading is not capturable either)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             static_out = rend.render_rays(static_in, box, ids)
         static_in.copy_(rays_b)
         g.replay()
