@@ -372,13 +372,14 @@ def self_launch(args):
 def train_bytes_per_sample(c, split=False):
     """HBM bytes per sample of the three training kernels: forward writes the saved activations (bf16) + one gate
     bit per ReLU output + raw; the data-gradient pass reads gate bits + d_raw and writes every dY (bf16); the weight-gradient
-    kernel reads both sets back (the trunk output h by three jobs: feature, the stacked first Linears of the two heads, alpha --
-    four when only one head exists)."""
+    kernel reads both sets back (the trunk output h by two jobs since round 6: feature with the alpha row riding in it, and the stacked
+    first Linears of the two heads -- i.e. ONE re-read of h; the re-reads of dY_skip, dY_views, gamma(x) and the [rgb, sigma] block that
+    the job structure also has, 1.4 KB per sample, are NOT counted as algorithmic)."""
     D, W, H, ch = c["D"], c["W"], c["W"] // 2, 4 + c["num_classes"] + c["num_instances"]
     acts = 2 * (64 + 32 + (D + 1) * W + 3 * H)
     gates = (D * W + 3 * H) // 8
     dys = 2 * ((D + 1) * W + 3 * H + 160)
-    h_rereads = 2 if (c["num_classes"] and c["num_instances"]) else (2 if (c["num_classes"] or c["num_instances"]) else 1)
+    h_rereads = 1 if (c["num_classes"] or c["num_instances"]) else 0
     if split:
         return {"forward_train": acts + gates + 4 * ch, "mlp_bwd": gates + 4 * ch + dys, "wgrad": acts + dys + h_rereads * 2 * W}
     return (acts + gates + 4 * ch) + (gates + 4 * ch + dys) + (acts + dys + h_rereads * 2 * W)
@@ -701,13 +702,13 @@ def main():
                     roofline["traffic_note"] = ("%.2fx the algorithmic %.2f GB: k_mlp_tt requests its weight pieces with the DEFAULT cache policy and the 69 GB "
                                                 "L2 -> LDS weight stream stays in the L2.  With `nt` (what k_mlp_pp uses) 20 %% of that stream missed the L2 -- "
                                                 "13.8 GB of fabric traffic per launch, 37x the algorithmic bytes -- and the power-limited part answered with a lower "
-                                                "clock: same-box A/Bs profiles/r05p, r05q: 10.6-10.7 ms at 1818-1877 MHz without nt, 11.3-11.5 ms at 1773-1798 MHz "
+                                                "clock: same-box A/Bs profiles/r05/r05p, r05q: 10.6-10.7 ms at 1818-1877 MHz without nt, 11.3-11.5 ms at 1773-1798 MHz "
                                                 "with it" % (ratio, alg / 1e9))
                 else:
                     roofline["traffic_note"] = ("%.1fx the algorithmic %.2f GB: k_mlp_pp requests its weight pieces with the `nt` policy, so ~3 %% of the 69 GB "
                                                 "L2 -> LDS weight stream misses the L2 and is re-fetched over the fabric (0.2 TB/s).  Same-box A/Bs: nt "
                                                 "10.97-11.08 ms against 11.17 ms with the default policy in round 4 (profiles/r04/r04j), a wash in round 5 "
-                                                "(profiles/r05q: 1087-1089 against 1083-1094 Msamples/s); with the default policy the launch moves 1.07x its "
+                                                "(profiles/r05/r05q: 1087-1089 against 1083-1094 Msamples/s); with the default policy the launch moves 1.07x its "
                                                 "algorithmic bytes (profiles/r03/r03d)" % (ratio, alg / 1e9))
             if fused or (ops.default_schedule() != 1 and args.precision == "bf16"):
                 # the weight stream of the same launch: every workgroup (256 samples: 8 waves x one 32-sample tile in registers)

@@ -30,7 +30,7 @@ import os
 # Cache policy of the LDS-DMA weight pieces: the DEFAULT one.  With " nt" (what k_mlp_pp uses, -1 % there) this kernel's weight stream
 # missed the L2 for 20 % of its 69 GB per fine-level launch -- 13.8 GB of fabric traffic per launch (rocprofv3 FETCH_SIZE; k_mlp_pp: 2.1 GB,
 # the default policy: 0.09 GB) -- and the part paid for it in clock: 11.5 ms at 1773-1793 MHz with nt, 10.66 ms at 1863-1877 MHz without
-# (same box, profiles/r05p).  tools/build_tt_variant.sh builds A/B variants (PNR_TT_DMA_POLICY=" nt" | " sc0" | " sc1").
+# (same box, profiles/r05/r05p).  tools/build_tt_variant.sh builds A/B variants (PNR_TT_DMA_POLICY=" nt" | " sc0" | " sc1").
 DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void k_bbox_hits(const float* __restrict__ ray
 // same order, so the hit lists are k_bbox_hits' bit for bit.  Phase 2, lane = sample: z and the labels, written in whole rows.
 // 64 rays per 4-wave workgroup: phase 1 occupies one wave (one thread per ray is all the parallelism it has; as one wave per SIMD
 // of a 256-ray workgroup, phase 2 ran at 42 us against the separate kernels' 26), the other three are in the phase 2 of the CU's
-// other workgroups.  65,536 rays x 64 samples, 64 boxes: 50 us against 27 + 11 + 15 for the three kernels (profiles/r05l).  max_hits <= 8 (7 KiB of LDS); the separate kernels remain for larger lists.
+// other workgroups.  65,536 rays x 64 samples, 64 boxes: 50 us against 27 + 11 + 15 for the three kernels (profiles/r05/r05l).  max_hits <= 8 (7 KiB of LDS); the separate kernels remain for larger lists.
 #define SETUP_MAXH 8
 struct RaySetupArgs {
     const float* rays; int64_t R; const float* box; int M; int max_hits; const int32_t* box_ids;
