@@ -39,7 +39,7 @@ run_prof() {
   timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/train_write -o t -- python $R/tools/train_trace.py 3 > $O/train_write.log 2>&1
   cd $R
   python tools/prof_summary.py $(db prof_trace) $(db prof_fetch) $(db prof_write) $(db prof_sq) $(db prof_l2) > $O/rocprof_summary.txt 2> $O/summary.err
-  python tools/update_traffic.py $(db prof_fetch) $(db prof_write) ${T}_rocprof_summary.txt $(db prof_trace) > $O/traffic.log 2>&1; cp profiles/latest_traffic.json $O/latest_traffic.json
+  python tools/update_traffic.py $(db prof_fetch) $(db prof_write) ${T:0:3}/${T}_rocprof_summary.txt $(db prof_trace) > $O/traffic.log 2>&1; cp profiles/latest_traffic.json $O/latest_traffic.json
   python tools/train_summary.py $(db train_trace) 4 $(db train_fetch) $(db train_write) 3 > $O/train_summary.txt 2>> $O/summary.err
   rm -rf $O/prof_l2 $O/prof_trace $O/prof_fetch $O/prof_write $O/prof_sq $O/train_trace $O/train_fetch $O/train_write
   tail -12 $O/train_summary.txt; tail -5 $O/summary.err; grep -n "fused MLP fine-level" $O/rocprof_summary.txt
