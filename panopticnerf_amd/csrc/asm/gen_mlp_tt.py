@@ -12,7 +12,8 @@ order per value: outputs (per-tile records, per-sample quadruples) are BIT-IDENT
 plan-2 image (pnr_mlp_plan.h): plan 1's chunk order, every chunk <= 33 fragments, sem1 / inst1 one chunk each.
 
 Geometry (fixed): D = 8, W = 256, skip = 4, xyz_L = 10, dir_L = 4, head_W = 128, head_tap 0; NBS = 0 | 1 | 2 semantic logit blocks, with
-NBS >= 1 also NBI = 0 | 1 instance logit blocks -> five kernels k_mlp_tt_s<NBS>i<NBI> (s0i0: no heads; s<n>i0: no instance head).
+NBS >= 1 also NBI = 0 | 1 instance logit blocks -> five kernels k_mlp_tt_s<NBS>i<NBI> (s0i0: no heads; s<n>i0: no instance head), and
+four more for head_depth = 1 (one Linear W -> n per head, read from h: k_mlp_tt_d1_s<NBS>i<NBI>).
 
 Time structure per 256-sample group (one workgroup; tile = (wave, t), record index grp * 8 + wave * 2 + t):
   image chunk c lives in LDS slot c % 4 (33 KiB each); during chunk c every wave issues its LDS-DMA pieces of chunk c + 3; at
@@ -132,9 +133,12 @@ class Sim:
 
 
 class Gen:
-    def __init__(self, nbs, nbi, name, trace=False, abl=0):
+    def __init__(self, nbs, nbi, name, trace=False, abl=0, depth=2):
         # abl (trace builds only; results invalid): 1 = no LDS-DMA pieces in the loop, 2 = no chunk hand-over (vmcnt + barrier),
         # 4 = no pack / ReLU of the hidden layers
+        # depth: pnr_mlp_desc.head_depth -- 2: heads W -> W/2 -> n (sem0 | inst0 | sem1 | inst1); 1: one Linear W -> n per head, straight from
+        # the trunk output h (round 6: SURVEY.md 9 item 4 as a kernel variant, k_mlp_tt_d1_s<n>i<m>)
+        self.depth = depth
         self.nbs, self.nbi, self.name, self.trace, self.abl = nbs, nbi, name, trace, abl
         self.nstamp = 0
         self.o = []
@@ -178,14 +182,20 @@ class Gen:
         add("rgbs", 1, [("g", 8), ("hh", 16)], 1, "rgbs")
         # heads: sem0 | inst0 | sem1 | inst1 -- a logit layer never follows its own hidden layer directly (the hidden layer's last
         # blocks would have to be packed inside the logit unit's first MFMA gaps), sem1's reduction runs beside inst1
-        if self.nbs:
-            add("sem0", 4, [("hh", 16)], 2, "relu")
-        if self.nbi:
-            add("inst0", 4, [("hh", 16)], 2, "relu")
-        if self.nbs:
-            add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
-        if self.nbi:
-            add("inst1", 1, [("shi", 8)], 1, "logits")
+        if self.depth == 1:             # one Linear per head: the logit layers read h itself (16 k-steps)
+            if self.nbs:
+                add("sem1", self.nbs, [("hh", 16)], self.nbs, "logits")
+            if self.nbi:
+                add("inst1", 1, [("hh", 16)], 1, "logits")
+        else:
+            if self.nbs:
+                add("sem0", 4, [("hh", 16)], 2, "relu")
+            if self.nbi:
+                add("inst0", 4, [("hh", 16)], 2, "relu")
+            if self.nbs:
+                add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
+            if self.nbi:
+                add("inst1", 1, [("shi", 8)], 1, "logits")
         self.layers = L
         self.chunks = []
         off = 0
@@ -886,7 +896,7 @@ class Gen:
             self.drain_side()                       # (nothing left normally) the early side work uses the g area
         if l["name"] == "views" and u["blocks"] == [1]:
             self.park()
-        if l["name"] == ("sem0" if self.nbs else "inst0") and u["blocks"][0] == 0:
+        if l["name"] == (("sem0" if self.nbs else "inst0") if self.depth == 2 else "sem1") and u["blocks"][0] == 0:
             self.unpark()
         if l["name"] == "views" and u["blocks"] == [2]:
             self.g2_acc = self.acc_take(1)[0]       # home of g block 2 (packed during the next unit) until the rgb / sigma unit is issued
@@ -927,9 +937,11 @@ class Gen:
             for op in plans[kk]:
                 musts.append(op)
                 dls.append(None)
+        lwr_from = None
         if nxt is None and (self.logit_units or l["mode"] == "logits"):
             # the group's last unit: the logit tail's per-register weights lwr[r] = lw[row(r, hi)] of both tiles come back from the LDS
             # table (rgbs_epilogue: scan) into the two accumulators nobody holds any more -- behind the packs that release them
+            lwr_from = len(musts)
             for op in self.lwr_ops():
                 musts.append(op)
                 dls.append(None)
@@ -939,6 +951,10 @@ class Gen:
         for j in range(n):                              # their accumulators until then): arm in the unit's last third
             spread = 1 + (j * max(1, nm - 6)) // max(1, n) if not late else (2 * nm) // 3 + (j * max(1, nm // 3 - 5)) // max(1, n)
             pos.append(spread if dls[j] is None else min(spread, max(0, dls[j] - 2)))
+        if lwr_from is not None:                        # the local-weight reads: in the unit's second half (the side queue drains first)
+            nl = n - lwr_from
+            for j in range(lwr_from, n):
+                pos[j] = max(pos[j], min(nm - 2, nm // 2 + ((j - lwr_from) * max(1, nm // 2 - 3)) // nl))
         for j in range(n - 2, -1, -1):                  # program order: a must never after a later must's position
             pos[j] = min(pos[j], pos[j + 1])
         must_at = {}
@@ -1042,6 +1058,11 @@ class Gen:
         ops = []
 
         def first():
+            # the table is written by the rgb / sigma unit's epilogue (scan), which is side work: everything of it that is still queued
+            # goes out NOW, in front of the reads (head_depth 1 without an instance head: the last unit follows the rgb / sigma unit
+            # directly -- the reads returned the previous group's weights), and with it the accumulators that epilogue holds
+            while self.side or self.outbox or (len(self.acc_free) < 2 and self.side_busy()):
+                self.drain_side(8)
             assert len(self.acc_free) >= 2, ("no free accumulators for the local weights", self.acc_free)
             self.lwr_acc = self.acc_take(2)
             self.e("v_add_u32 v%d, s%d, v%d" % (V_LWA, S_LWR, V_BIAS + 0))
@@ -1407,6 +1428,10 @@ def main():
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())
+    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # head_depth = 1: one Linear per head
+        n = "k_mlp_tt_d1_s%di%d" % (nbs, nbi)
+        names.append(n)
+        parts.append(Gen(nbs, nbi, n, depth=1).kernel())
     # diagnostics builds only (make EXTRA_TT=trace | abl): the production library carries no kernel that writes (64 + n_wg) * 4 bytes
     # to the clock buffer (a 16-byte clk_probe buffer under PNR_MLP_TRACE was an out-of-bounds device write)
     extra = sys.argv[3] if len(sys.argv) > 3 else ""

@@ -147,8 +147,14 @@ def fused_plan(desc, limit=None):
     cap = limit if limit is not None else os.environ.get("PNR_FUSED_PLAN")
     if cap is None or int(cap) >= best:
         return best
-    # below the best plan: plan 1 exists only for networks with a semantic head (the merged logit chunk), else the classic order
-    return 1 if (int(cap) >= 1 and desc.n_sem > 0) else 0
+    # below the best plan: plan 1 where the library takes it (a semantic head of depth 2: the merged logit chunk), else the classic order
+    if int(cap) >= 1:
+        d1 = _lib.MlpDesc()
+        ctypes.memmove(ctypes.byref(d1), ctypes.byref(desc), ctypes.sizeof(d1))
+        d1.plan = 1
+        if int(_lib.load().pnr_mlp_packed_bytes(ctypes.byref(d1))) > 0:
+            return 1
+    return 0
 
 
 def _param_struct(desc, params, device):

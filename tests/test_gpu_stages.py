@@ -574,6 +574,44 @@ def test_two_tile_assembly_kernel_equals_pingpong_bit_for_bit(dev, R, N, heads):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 0), (19, 0)])
+@pytest.mark.parametrize("R,N", [(300, 192), (1001, 64), (7, 32), (2051, 32)])
+def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads):
+    """head_depth = 1 (heads of one Linear W -> n, read from the trunk output) in the two-tile assembly form
+    (round 6: k_mlp_tt_d1_s<n>i<m>, plan 2) against the ping-pong kernel's fused pass on the classic image (plan 0: there is no
+    plan 1 for this depth).  The two reduce a tile's logits differently (transposed FMA chains against 32-lane butterflies), so
+    records and maps agree to fp32 rounding -- 2e-6 of the field's scale per sample of the tile -- while Q and the per-sample
+    quadruples (lw, r, g, b), which do not go through the logit layers, are the same bits; a second launch must not depend on what
+    the first left behind; and both match the two-kernel path (mlp_forward + composite) to the fused pass's usual tolerance."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N + C)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K, head_depth=1)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d0, i0 = net.packed(1, dev, "bf16", fused=0)
+    d2, i2 = net.packed(1, dev, "bf16", fused=2)
+    assert d0.plan == 0 and d2.plan == 2 and d2.head_depth == 1
+    rec0, ps0 = _tiles_workspace(d0, i0, rays, z)
+    for rep in range(2):
+        rec2, ps2 = _tiles_workspace(d2, i2, rays, z)
+        assert torch.equal(ps0.view(torch.int32), ps2.view(torch.int32)), rep
+        assert torch.equal(rec0[:, 0].view(torch.int32), rec2[:, 0].view(torch.int32)), rep          # Q
+        scale = float(rec0[:, 1:1 + C + K].abs().max()) + 1e-6
+        assert float((rec0[:, 1:1 + C + K] - rec2[:, 1:1 + C + K]).abs().max()) <= 64e-6 * scale, rep
+    a = ops.mlp_forward_composite(d0, i0, rays, z, None, None, False, True)
+    b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True)
+    dd, ii = net.packed(1, dev, "bf16")
+    raw = ops.mlp_forward(dd, ii, rays, z, channel_major=True)
+    c = ops.composite(raw, z, rays, C, K, True, None, None, None, 0, False, True)
+    for k in a:
+        sc = max(1.0, float(a[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
+        assert float((c[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
+
+
 def test_two_tile_kernel_is_the_default_where_it_exists_and_can_be_capped(dev, monkeypatch):
     """The renderer's fused inference pass packs the BEST plan the geometry has (pnr_mlp_fused_plan: 2 = k_mlp_tt for the benched
     network); PNR_FUSED_PLAN=1 (A/B runs) caps it at the ping-pong kernel's plan.  Same frame either way, bit for bit."""
