@@ -676,7 +676,7 @@ def main():
             flops = S * mlp_flops_per_sample(c["D"], c["W"], skip, 63, 27, N_SEM, N_INST)
             ach = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-            kname = ("k_mlp_tt<two-tile assembly, fused compositing epilogue, plan 2>" if fused and fdesc.plan == 2 else
+            kname = ("k_mlp_tt<two-tile assembly, fused %scompositing epilogue, plan 2>" % ("softmax " if rend.sem_mode == 1 else "") if fused and fdesc.plan == 2 else
                      "k_mlp_pp<fused %scompositing epilogue, plan %d>" % ("softmax " if rend.sem_mode == 1 else "", fdesc.plan) if fused else
                      "k_mlp_pp" if (ops.default_schedule() != 1 and args.precision == "bf16") else "k_mlp_fused")
             tkey = ("k_mlp_tt_fused" if fdesc.plan == 2 else "k_mlp_pp_fused") if fused else "k_mlp_pp"

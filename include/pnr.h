@@ -93,8 +93,10 @@ typedef struct pnr_mlp_desc {
 
 #define PNR_MLP_SOFTMAX 1      /* pnr_mlp_forward_composite / pnr_mlp_forward_tiles composite softmax(logits) over each learned field's
                                   channels instead of the logits (the reference's semantic_activation = softmax; pnr_composite's
-                                  sem_mode 1).  Needs the plan-1 image (pnr_mlp_fused_plan >= 1 and pnr_mlp_desc.plan = 1): a head's
-                                  logit blocks must be in registers together; PNR_ERR_ARG otherwise */
+                                  sem_mode 1).  Needs an image whose plan has a softmax kernel -- a head's logit blocks must be in
+                                  registers together: plan 2 (k_mlp_tt_sm_*, round 6: heads of depth 2) or plan 1; ask
+                                  pnr_mlp_fused_plan WITH this flag set in desc.flags (0 = none: use pnr_mlp_forward + pnr_composite);
+                                  PNR_EINVAL otherwise */
 #define PNR_MLP_TRACE 0x7A00   /* diagnostics BUILDS of the library only (make EXTRA_TT=trace | abl; the shipped library refuses the
                                   flag), with plan 2: the trace build of k_mlp_tt -- clk_probe must then address (64 + workgroups) * 4
                                   bytes (workgroups <= number of CUs; tools/tt_trace.py allocates 1280): 64 per-unit s_memtime stamps
@@ -163,7 +165,8 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  *      (csrc/asm/gen_mlp_tt.py);
  *   0: the classic order, which every entry point accepts.
  * Set desc.plan to the returned value (or to a smaller supported one: plan 1 needs a semantic head) before pnr_mlp_packed_bytes / pnr_mlp_pack* and keep it
- * for the forward call.  Same arithmetic per layer under every plan: records and maps are bit-identical. */
+ * for the forward call.  Same arithmetic per layer under every plan: records and maps are bit-identical (head_depth 1: plan 2 against
+ * plan 0 to fp32 rounding).  With PNR_MLP_SOFTMAX in desc.flags the answer is the best plan that has a SOFTMAX kernel (2, 1, or 0 = none). */
 int pnr_mlp_fused_plan(const pnr_mlp_desc* desc);
 int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc* desc, int64_t n_rays, int n_samples, int want_weights);
 int pnr_mlp_forward_composite(const pnr_mlp_desc* desc, const void* packed, const float* rays, const float* z,

@@ -70,6 +70,7 @@ S_LO32, S_N0, S_HI0 = 52, 54, 56        # constants: lanes 0..31, lanes {0, 32},
 S_SAVE, S_REC_T = 58, 60                # saved exec; the two tiles' record pointers s[60:61], s[62:63]
 S_MSK = 64                              # store masks of the (up to) three logit blocks: s[64:69] = lanes with hi == 0 and channel < n_out
 S_REC_I = 70                            # the two tiles' record pointers + 4 n_sem (the instance columns): s[70:73]
+S_VMSK = 76                             # softmax kernels: s[76:77] / s[78:79] = ALL lanes whose channel of the semantic / instance head's last block exists
 S_LWW, S_LWR = 74, 75                   # LDS addresses of this wave's local-weight table: + 4 (lane & 31) to write, + (V_BIAS[0] = slot 0 + 16 hi) to read
 LW_BASE = NSLOT * SLOT                  # [4 waves][2 tiles][32 floats] behind the weight slots (1 KiB)
 S_CLK0 = 96                             # s[96:99] clocks at start
@@ -133,12 +134,16 @@ class Sim:
 
 
 class Gen:
-    def __init__(self, nbs, nbi, name, trace=False, abl=0, depth=2):
+    def __init__(self, nbs, nbi, name, trace=False, abl=0, depth=2, softmax=False):
         # abl (trace builds only; results invalid): 1 = no LDS-DMA pieces in the loop, 2 = no chunk hand-over (vmcnt + barrier),
         # 4 = no pack / ReLU of the hidden layers
         # depth: pnr_mlp_desc.head_depth -- 2: heads W -> W/2 -> n (sem0 | inst0 | sem1 | inst1); 1: one Linear W -> n per head, straight from
         # the trunk output h (round 6: SURVEY.md 9 item 4 as a kernel variant, k_mlp_tt_d1_s<n>i<m>)
         self.depth = depth
+        # softmax: semantic_activation = softmax (PNR_MLP_SOFTMAX) -- the learned fields composite softmax(logits) over their channels;
+        # the tail normalises each head's transposed logit blocks per sample before the weighted sums (tail_softmax), operation for
+        # operation fuse_softmax_t of the ping-pong kernel (pnr_mlp_fuse.h): k_mlp_tt_sm_s<n>i<m>
+        self.softmax = softmax
         self.nbs, self.nbi, self.name, self.trace, self.abl = nbs, nbi, name, trace, abl
         self.nstamp = 0
         self.o = []
@@ -1051,6 +1056,107 @@ class Gen:
                     e("s_barrier")
                 d += 1
 
+    def tail_softmax(self, blocks, lwr_reg, tag_lwr):
+        """semantic_activation = softmax: per head and tile, IN PLACE -- the head's logit accumulators become e = exp(x - max) and the
+        tile's lwr registers become lwr / denominator, so that the FMA chains that follow (the logits tail, unchanged) form
+        sum_r (lwr[r] / den[r]) e[r] = the record column of softmax(logits).  Lane = channel, register r = sample row(r, hi): maximum
+        and denominator of a sample are reductions over the 32 lanes of each half-wave -- quad_perm / row_half_mirror / row_mirror
+        DPP steps and v_permlane16_swap for the xor-16 step, all sixteen registers of both tiles per step back to back (independent).
+        Operation for operation fuse_softmax_t (pnr_mlp_fuse.h): max_raw chain, xor_max 1 2 4 8 16, mm = -m log2e, e = exp2(fma(x, log2e,
+        mm)), d = e_0 (+ e_1), xor_add 1 2 4 8, swap-add 16, lwr * rcp(d).  Channels past the head's last are set to -inf first (the
+        ping-pong kernel starts their accumulators there): exp makes them 0.  The lwr registers are consumed head by head: the
+        semantic head's FMA chains are issued before the instance head rescales them."""
+        e = self.e
+        M = (V_TMP, V_RING)                         # m / d of the tile: 16 registers each (g area; the fragment ring is idle at a group's end)
+        TMP = [V_IN + 10, V_IN + 11, V_IN + 12, V_IN + 13]  # temporaries of the xor-16 steps: the next group's o_z and q of tile 1 (dead: its
+                                                            # gamma(d) is encoded) -- NOT the logits tail's sums / oth registers (V_IN + 1..5, 9)
+        ninf = V_PTMP + 6
+        heads = []
+        for inst in (False, True):
+            hb = [(u, bi, blk) for (u, bi, blk, i2) in blocks if i2 == inst]
+            if hb:
+                heads.append((inst, hb))
+        for t in (0, 1):
+            self.wait_lgkm(tag_lwr[t])
+        e("v_mov_b32 v%d, 0xff800000" % ninf)
+
+        def xor16(op):
+            # x op x[lane ^ 16] through v_permlane16_swap on two copies (one ends up with rows {0, 0, 2, 2}, the other {1, 1, 3, 3}); four
+            # registers at a time: a VALU write needs two wait states before v_permlane16_swap reads it, and so does the swap's result
+            regs = [M[t] + r for t in (0, 1) for r in range(16)]
+            for g in range(0, 32, 4):
+                for i in range(4):
+                    e("v_mov_b32 v%d, v%d" % (TMP[i], regs[g + i]))
+                for i in range(4):
+                    e("v_permlane16_swap_b32 v%d, v%d" % (regs[g + i], TMP[i]))
+                for i in range(4):
+                    e("%s v%d, v%d, v%d" % (op, regs[g + i], regs[g + i], TMP[i]))
+        for hi_, (inst, hb) in enumerate(heads):
+            accs = [[self.acc_reg(u["accs"][(bi, t)]) for (u, bi, blk) in hb] for t in (0, 1)]      # [tile][block] -> first register
+            NB = len(hb)
+            vm = S_VMSK + 2 * (1 if inst else 0)
+            for t in (0, 1):                        # the head's LAST block: channels >= n_out -> -inf
+                for r in range(16):
+                    e("v_cndmask_b32 v%d, v%d, v%d, s[%d:%d]" % (accs[t][NB - 1] + r, ninf, accs[t][NB - 1] + r, vm, vm + 1))
+            # m[r] = max over the head's blocks (max_raw chain), then the 32-lane butterfly
+            first_src = None
+            if NB > 1:
+                for t in (0, 1):
+                    for r in range(16):
+                        e("v_max_f32 v%d, v%d, v%d" % (M[t] + r, accs[t][0] + r, accs[t][1] + r))
+                        for b in range(2, NB):
+                            e("v_max_f32 v%d, v%d, v%d" % (M[t] + r, M[t] + r, accs[t][b] + r))
+            else:
+                first_src = [accs[t][0] for t in (0, 1)]
+            for k, ctrl in enumerate(("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror")):
+                for t in (0, 1):
+                    for r in range(16):
+                        src = (first_src[t] + r) if (k == 0 and first_src) else (M[t] + r)
+                        e("v_max_f32_dpp v%d, v%d, v%d %s row_mask:0xf bank_mask:0xf bound_ctrl:1" % (M[t] + r, src, src, ctrl))
+            xor16("v_max_f32")
+            # mm = -m log2(e);  e = exp2(fma(x, log2 e, mm));  d = e_0 + e_1 ...
+            for t in (0, 1):
+                for r in range(16):
+                    e("v_mul_f32 v%d, 0xbfb8aa3b, v%d" % (M[t] + r, M[t] + r))
+            for t in (0, 1):
+                for r in range(16):
+                    for b in range(NB):
+                        e("v_fmamk_f32 v%d, v%d, 0x3fb8aa3b, v%d" % (accs[t][b] + r, accs[t][b] + r, M[t] + r))
+                        e("v_exp_f32 v%d, v%d" % (accs[t][b] + r, accs[t][b] + r))
+            first_src = None
+            if NB > 1:
+                for t in (0, 1):
+                    for r in range(16):
+                        e("v_add_f32 v%d, v%d, v%d" % (M[t] + r, accs[t][0] + r, accs[t][1] + r))
+                        for b in range(2, NB):
+                            e("v_add_f32 v%d, v%d, v%d" % (M[t] + r, M[t] + r, accs[t][b] + r))
+            else:
+                first_src = [accs[t][0] for t in (0, 1)]
+            for k, ctrl in enumerate(("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror")):
+                for t in (0, 1):
+                    for r in range(16):
+                        src = (first_src[t] + r) if (k == 0 and first_src) else (M[t] + r)
+                        e("v_add_f32_dpp v%d, v%d, v%d %s row_mask:0xf bank_mask:0xf bound_ctrl:1" % (M[t] + r, src, src, ctrl))
+            xor16("v_add_f32")
+            # wr[r] = lwr[r] * rcp(d[r]): kept in M (the lwr registers stay what they are for the next head)
+            for t in (0, 1):
+                for r in range(16):
+                    e("v_rcp_f32 v%d, v%d" % (M[t] + r, M[t] + r))
+            for t in (0, 1):
+                for r in range(16):
+                    e("v_mul_f32 v%d, v%d, v%d" % (M[t] + r, lwr_reg(t, r), M[t] + r))
+            # this head's FMA chains against wr (fmas() is told to skip them): s = sum_r wr[r] e[r]
+            for r in range(16):
+                for t in (0, 1):
+                    for (u, bi, blk) in hb:
+                        kk = [i for i, (u2, bi2, blk2, i2) in enumerate(blocks) if u2 is u and bi2 == bi][0]
+                        a = self.acc_reg(u["accs"][(bi, t)])
+                        dst = self.sm_sums[t][kk]
+                        if r == 0:
+                            e("v_fma_f32 v%d, v%d, v%d, 0" % (dst, M[t], a))
+                        else:
+                            e("v_fmac_f32 v%d, v%d, v%d" % (dst, M[t] + r, a + r))
+
     def lwr_ops(self):
         """closures (one instruction each) that load lwr of both tiles: 8 ds_read_b64 per tile.  lw[8 q + 4 hi + j], j = 0..3, is
         register 4 q + ((j + 2) & 3) of the tile's block -- two positions round its quad, so that the tail's FMA (lwr[r] x register r
@@ -1106,12 +1212,14 @@ class Gen:
         e("v_lshlrev_b32 v%d, 2, v%d" % (adr, adr))
         tags = [None, None]
 
+        self.sm_sums = sums
+
         def fmas(ts):
             # the chains of the tiles in `ts` side by side: a chain is 16 DEPENDENT FMAs, and three of them interleaved still ran at
             # ~10 cycles per instruction (one wave per SIMD: nobody else fills the result latency); six run at the issue rate
             for t in ts:
                 self.wait_lgkm(tag_lwr[t])
-            for r in range(16):
+            for r in ([] if self.softmax else range(16)):
                 for t in ts:
                     for k, (u, bi, blk, inst) in enumerate(blocks):
                         a = self.acc_reg(u["accs"][(bi, t)])
@@ -1132,6 +1240,8 @@ class Gen:
                 self.vm_op("global_store_dword v%d, v%d, s[%d:%d] offset:%d%s" % (V_LB4, oth[t][k], base, base + 1, 4 + 128 * blk, STORE_NT))
             e("s_mov_b64 exec, -1")
         self.stamp(len(self.units) + 4)
+        if self.softmax:
+            self.tail_softmax(blocks, lwr_reg, tag_lwr)
         fmas((0, 1))
         self.stamp(len(self.units) + 5)
         stores(0)
@@ -1297,6 +1407,14 @@ class Gen:
                 e("v_add_u32 v%d, %d, v%d" % (V_T0, 32 * blk, V_T0))
             e("v_cmp_gt_i32 vcc, s%d, v%d" % (S_NINST if inst else S_NSEM, V_T0))
             e("s_and_b64 s[%d:%d], vcc, s[%d:%d]" % (S_MSK + 2 * k, S_MSK + 2 * k + 1, S_HI0, S_HI0 + 1))
+        if self.softmax:
+            # ALL lanes (both halves) whose channel of the head's last block exists: 32 (blocks - 1) + (lane & 31) < n_out
+            for k, (nblk, sreg) in enumerate(((self.nbs, S_NSEM), (self.nbi, S_NINST))):
+                if nblk:
+                    e("v_and_b32 v%d, 31, v0" % V_T0)
+                    if nblk > 1:
+                        e("v_add_u32 v%d, %d, v%d" % (V_T0, 32 * (nblk - 1), V_T0))
+                    e("v_cmp_gt_i32 s[%d:%d], s%d, v%d" % (S_VMSK + 2 * k, S_VMSK + 2 * k + 1, sreg, V_T0))
         lend, lloop, lfin = self.label(), self.label(), self.label()
         e("s_mov_b32 s%d, s2" % S_GRP)
         e("s_cmp_ge_i32 s%d, s%d" % (S_GRP, S_NGRP))
@@ -1432,6 +1550,10 @@ def main():
         n = "k_mlp_tt_d1_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n, depth=1).kernel())
+    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # semantic_activation = softmax (head_depth 2)
+        n = "k_mlp_tt_sm_s%di%d" % (nbs, nbi)
+        names.append(n)
+        parts.append(Gen(nbs, nbi, n, softmax=True).kernel())
     # diagnostics builds only (make EXTRA_TT=trace | abl): the production library carries no kernel that writes (64 + n_wg) * 4 bytes
     # to the clock buffer (a 16-byte clk_probe buffer under PNR_MLP_TRACE was an out-of-bounds device write)
     extra = sys.argv[3] if len(sys.argv) > 3 else ""

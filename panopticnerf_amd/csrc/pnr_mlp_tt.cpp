@@ -16,7 +16,7 @@ static const unsigned char k_co[] = {
 namespace {
 struct DevTable {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][3][2] = {};     // [head_depth - 1 ... 0 = depth 2, 1 = depth 1][nbs][nbi]
+    hipFunction_t fn[3][3][2] = {};     // [variant: 0 = head_depth 2, 1 = head_depth 1, 2 = head_depth 2 with softmax compositing][nbs][nbi]
     hipFunction_t fn_trace[8] = {};     // [ablation]: 0 = the trace build; 1, 2, 3, 4, 7 exist only in PNR_TT_ABL=1 builds of the library
     bool tried = false, ok = false;
 };
@@ -44,9 +44,13 @@ static int tt_table(DevTable*& out, int capturing = 0)
             char nm[64];
             snprintf(nm, sizeof(nm), "k_mlp_tt_s%di%d", geo[k][0], geo[k][1]);
             e = hipModuleGetFunction(&t.fn[0][geo[k][0]][geo[k][1]], t.mod, nm);
-            if (e == hipSuccess && geo[k][0]) {        // head_depth = 1 twins (no twin without heads)
+            if (e == hipSuccess && geo[k][0]) {        // head_depth = 1 and softmax twins (no twin without heads)
                 snprintf(nm, sizeof(nm), "k_mlp_tt_d1_s%di%d", geo[k][0], geo[k][1]);
                 e = hipModuleGetFunction(&t.fn[1][geo[k][0]][geo[k][1]], t.mod, nm);
+            }
+            if (e == hipSuccess && geo[k][0]) {
+                snprintf(nm, sizeof(nm), "k_mlp_tt_sm_s%di%d", geo[k][0], geo[k][1]);
+                e = hipModuleGetFunction(&t.fn[2][geo[k][0]][geo[k][1]], t.mod, nm);
             }
         }
         // diagnostics kernels: only in `make EXTRA_TT=trace | abl` builds of the library
@@ -88,7 +92,7 @@ void pnr_mlp_tt_prepare_quiet(void)
     if (tt_table(t) != PNR_OK) pnr_set_error("%s", keep.c_str());
 }
 
-int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, hipStream_t stream, bool trace, int trace_abl)
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, bool softmax, hipStream_t stream, bool trace, int trace_abl)
 {
     PNR_REQUIRE(nbs >= 0 && nbs <= 2 && nbi >= 0 && nbi <= (nbs ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
@@ -98,10 +102,12 @@ int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, hipS
     PNR_HIP(hipStreamIsCapturing(stream, &cs));
     int rc = tt_table(t, cs != hipStreamCaptureStatusNone);
     if (rc != PNR_OK) return rc;
-    hipFunction_t fn = t->fn[(head_depth == 1 && nbs) ? 1 : 0][nbs][nbi];
+    PNR_REQUIRE(!(softmax && nbs && head_depth == 1), "pnr_mlp_forward_composite: softmax compositing has no two-tile kernel at head_depth 1 "
+                "(pnr_mlp_fused_plan with PNR_MLP_SOFTMAX set says which plan has one)");
+    hipFunction_t fn = t->fn[!nbs ? 0 : softmax ? 2 : head_depth == 1 ? 1 : 0][nbs][nbi];
     PNR_REQUIRE(fn, "pnr_mlp_tt: no kernel for %d + %d logit blocks at head_depth %d", nbs, nbi, head_depth);
     if (trace) {
-        PNR_REQUIRE(head_depth != 1, "pnr_mlp_tt: the trace build exists for head_depth 2");
+        PNR_REQUIRE(head_depth != 1 && !softmax, "pnr_mlp_tt: the trace build exists for head_depth 2, logits compositing");
         PNR_REQUIRE(nbs == 2 && nbi == 1 && a.clk, "pnr_mlp_tt: the trace build exists for 2 + 1 logit blocks and needs the clock buffer");
         fn = t->fn_trace[trace_abl & 7];
         PNR_REQUIRE(fn, "pnr_mlp_tt: PNR_MLP_TRACE%s%d is not in this library: the trace kernels are diagnostics builds "

@@ -112,7 +112,10 @@ class Network(nn.Module):
         if fused and not backward:
             # image for pnr_mlp_forward_composite only: the best fused-inference chunk order the geometry has (fused = 1 / 2: at most
             # that plan -- tests compare the kernels)
-            desc.plan = ops.fused_plan(desc, None if fused is True else int(fused))
+            if fused == "softmax":      # the best plan that has a softmax-compositing kernel (ops.fused_image(1))
+                desc.plan = ops.fused_plan(ops.desc_for_mode(desc, 1), None)
+            else:
+                desc.plan = ops.fused_plan(desc, None if fused is True else int(fused))
         key = ("bwd" if backward else "fwd", level if self.nerf_1 is not None else 0, str(device), precision, int(desc.plan))
         ver = self._version(level)
         hit = self._packed.get(key)
@@ -137,7 +140,8 @@ class Network(nn.Module):
 
     def packed(self, level, device, precision=None, fused=False):
         """(desc, packed image).  fused=True: the image only ops.mlp_forward_composite consumes (desc.plan as
-        pnr_mlp_fused_plan says; fused = 1 | 2 caps the plan); every other op takes the classic image (fused=False)."""
+        pnr_mlp_fused_plan says; fused = 1 | 2 caps the plan, "softmax" asks for the best plan with a softmax kernel); every other op
+        takes the classic image (fused=False)."""
         return self._pack(level, device, precision or self.precision, False, fused)
 
     def packed_bwd(self, level, device):

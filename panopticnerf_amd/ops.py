@@ -443,12 +443,12 @@ def _maps(out, R, N, n_sem, n_inst, label_sem, label_inst, want_weights, dev):
 
 def fused_supported(desc, n_samples, sem_mode=0, noise=None):
     """Can pnr_mlp_forward_composite take this level?  bf16, no sigma noise, N a multiple of 32; softmax compositing
-    (sem_mode 1) where the geometry has the plan-1 kernel (a head's logit blocks in registers together), on the plan-1 image:
+    (sem_mode 1) where the geometry has a softmax kernel (a head's logit blocks in registers together: plan 2 or 1), on that image:
     net.packed(level, device, fused=fused_image(sem_mode))."""
     ok = (desc.precision == _lib.PREC_BF16 and int(sem_mode) in (0, 1) and noise is None and n_samples % 32 == 0
           and 32 <= n_samples <= 256 and desc.n_sem + desc.n_inst <= 128)
     if ok and int(sem_mode) == 1 and desc.n_sem + desc.n_inst > 0:
-        ok = int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc))) >= 1
+        ok = int(_lib.load().pnr_mlp_fused_plan(ctypes.byref(desc_for_mode(desc, 1)))) >= 1     # (flag-aware: a plan with a softmax kernel)
     return ok
 
 
@@ -464,9 +464,9 @@ def desc_for_mode(desc, sem_mode):
 
 
 def fused_image(sem_mode=0):
-    """The `fused` argument of PanopticNetwork.packed for a compositing mode: the best plan for logits, at most plan 1 for
-    softmax (the two-tile assembly kernel composites logits only)."""
-    return 1 if int(sem_mode) == 1 else True
+    """The `fused` argument of PanopticNetwork.packed for a compositing mode: the best plan the geometry has for logits (True), the
+    best plan that has a SOFTMAX kernel for softmax ("softmax": plan 2 = k_mlp_tt_sm_* for heads of depth 2, else plan 1)."""
+    return "softmax" if int(sem_mode) == 1 else True
 
 
 @_on_device
@@ -476,7 +476,7 @@ def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None
     epilogue and k_composite_combine finishes the rays -- the raw image (324 B per sample at 45 / 32 heads) is never
     written.  Same dict as composite().  Sums are associated per tile, so results equal mlp_forward + composite to fp32
     rounding (not bit for bit).  sem_mode as in composite(): 1 composites softmax(logits) of each learned field
-    (PNR_MLP_SOFTMAX; plan-1 image only, see fused_supported)."""
+    (PNR_MLP_SOFTMAX; an image of a plan with a softmax kernel, see fused_supported / fused_image)."""
     rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
     label_sem = _chk(label_sem, "label_sem", torch.int32)
     label_inst = _chk(label_inst, "label_inst", torch.int32)

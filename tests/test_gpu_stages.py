@@ -440,8 +440,8 @@ def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, he
     the map's scale; the fixed fields additionally round through 2^-30 fixed point per tile.  Ragged sample counts (R*N not a
     multiple of 256), one ray, several tiles per ray, labels on and off, white background.
     sem_mode 1 (semantic_activation = softmax, PNR_MLP_SOFTMAX): the learned fields composite softmax(logits) -- the fused pass
-    normalises in the logit chunk's epilogue (v_exp_f32 / v_rcp_f32 in place of expf / the division: 4e-6), on the plan-1 image;
-    the plan-0 and plan-2 images refuse the flag."""
+    normalises in the logit chunk's epilogue (v_exp_f32 / v_rcp_f32 in place of expf / the division: 4e-6), on the best image
+    that has a softmax kernel (plan 2 since round 6); the plan-0 image refuses the flag."""
     from types import SimpleNamespace as NS
     from panopticnerf_amd import make_network
     C, K = heads
@@ -463,13 +463,11 @@ def test_fused_mlp_composite_equals_two_kernel_path(dev, R, N, labels, white, he
     raw = ops.mlp_forward(desc, img, rays, z, channel_major=True)
     want = ops.composite(raw, z, rays, C, K, True, None, ls, li, sem_mode, white, True)
     if sem_mode == 1 and (C or K):
-        for fused in (False, 2):
-            d_bad, i_bad = net.packed(1, dev, "bf16", fused=fused)
-            if d_bad.plan != 1:
-                with pytest.raises(RuntimeError, match="softmax compositing"):
-                    ops.mlp_forward_composite(d_bad, i_bad, rays, z, ls, li, white, True, sem_mode=1)
+        d_bad, i_bad = net.packed(1, dev, "bf16", fused=False)         # the classic image has no softmax kernel
+        with pytest.raises(RuntimeError, match="softmax compositing"):
+            ops.mlp_forward_composite(d_bad, i_bad, rays, z, ls, li, white, True, sem_mode=1)
         desc, img = net.packed(1, dev, "bf16", fused=ops.fused_image(sem_mode))
-        assert desc.plan == 1
+        assert desc.plan == 2          # round 6: k_mlp_tt_sm_* (plan 1 = k_mlp_pp's softmax epilogue is compared with it bit for bit below)
         # sum_c sum_i w_i p_ic = sum_i w_i: the mode is really on
         assert float((want["semantic"].sum(-1) - want["acc"]).abs().max()) < 1e-4
     for rep in range(2):
@@ -572,6 +570,46 @@ def test_two_tile_assembly_kernel_equals_pingpong_bit_for_bit(dev, R, N, heads):
     b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 1), (45, 0), (19, 0)])
+@pytest.mark.parametrize("R,N", [(300, 192), (37, 96), (1001, 64), (7, 32), (2051, 32)])
+def test_two_tile_softmax_kernels_equal_pingpong_bit_for_bit(dev, R, N, heads):
+    """semantic_activation = softmax in the two-tile assembly form (round 6: k_mlp_tt_sm_s<n>i<m>, plan 2; tail_softmax of
+    csrc/asm/gen_mlp_tt.py) against the ping-pong kernel's softmax epilogue (fuse_softmax_t, plan 1): operation for operation the same
+    arithmetic -- the max_raw chain, the xor_max / xor_add butterflies with v_permlane16_swap for the xor-16 step, exp2(fma(x, log2 e,
+    -m log2 e)), lwr * rcp(den), the FMA chains -- so records and quadruples are the SAME BITS, one and two semantic blocks, heads
+    with padded channels (their logits must count as -inf), ragged groups; run twice; then every map of the whole fused call."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N + C + 1)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    with torch.no_grad():           # logits of a few units' spread, so that the normalisation is not a near-uniform one
+        for head in (getattr(net.nerf_1, "semantic_linears", None), getattr(net.nerf_1, "instance_linears", None)):
+            if head is not None and len(head):
+                head[-1].weight.mul_(40.0)
+                head[-1].bias.add_(torch.linspace(-3.0, 3.0, head[-1].bias.numel(), device=dev))
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d1, i1 = net.packed(1, dev, "bf16", fused=1)
+    d2, i2 = net.packed(1, dev, "bf16", fused="softmax")
+    assert d1.plan == 1 and d2.plan == 2
+    d1, d2 = ops.desc_for_mode(d1, 1), ops.desc_for_mode(d2, 1)
+    rec1, ps1 = _tiles_workspace(d1, i1, rays, z)
+    assert float(rec1[:, 1:1 + C].abs().max()) > 0
+    for rep in range(2):
+        rec2, ps2 = _tiles_workspace(d2, i2, rays, z)
+        assert torch.equal(ps1.view(torch.int32), ps2.view(torch.int32)), rep
+        bad = rec1.view(torch.int32) != rec2.view(torch.int32)
+        assert not bool(bad.any()), (rep, int(bad.sum()), float((rec1 - rec2).abs().max()))
+    a = ops.mlp_forward_composite(d1, i1, rays, z, None, None, False, True, sem_mode=1)
+    b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True, sem_mode=1)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # probabilities: every sample's channels sum to one, so the composited semantic map sums to the opacity
+    assert float((b["semantic"].sum(-1) - b["acc"]).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 0), (19, 0)])
