@@ -94,7 +94,7 @@ typedef struct pnr_mlp_desc {
 #define PNR_MLP_SOFTMAX 1      /* pnr_mlp_forward_composite / pnr_mlp_forward_tiles composite softmax(logits) over each learned field's
                                   channels instead of the logits (the reference's semantic_activation = softmax; pnr_composite's
                                   sem_mode 1).  Needs an image whose plan has a softmax kernel -- a head's logit blocks must be in
-                                  registers together: plan 2 (k_mlp_tt_sm_*, round 6: heads of depth 2) or plan 1; ask
+                                  registers together: plan 2 (k_mlp_tt_sm_* / k_mlp_tt_d1sm_*, round 6) or plan 1; ask
                                   pnr_mlp_fused_plan WITH this flag set in desc.flags (0 = none: use pnr_mlp_forward + pnr_composite);
                                   PNR_EINVAL otherwise */
 #define PNR_MLP_TRACE 0x7A00   /* diagnostics BUILDS of the library only (make EXTRA_TT=trace | abl; the shipped library refuses the

@@ -1550,10 +1550,13 @@ def main():
         n = "k_mlp_tt_d1_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n, depth=1).kernel())
-    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # semantic_activation = softmax (head_depth 2)
+    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # semantic_activation = softmax (head_depth 2, and head_depth 1)
         n = "k_mlp_tt_sm_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n, softmax=True).kernel())
+        n = "k_mlp_tt_d1sm_s%di%d" % (nbs, nbi)
+        names.append(n)
+        parts.append(Gen(nbs, nbi, n, depth=1, softmax=True).kernel())
     # diagnostics builds only (make EXTRA_TT=trace | abl): the production library carries no kernel that writes (64 + n_wg) * 4 bytes
     # to the clock buffer (a 16-byte clk_probe buffer under PNR_MLP_TRACE was an out-of-bounds device write)
     extra = sys.argv[3] if len(sys.argv) > 3 else ""

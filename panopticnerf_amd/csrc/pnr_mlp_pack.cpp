@@ -54,7 +54,7 @@ PNR_EXPORT int pnr_mlp_fused_plan(const pnr_mlp_desc* desc)
     d.plan = 0;
     if (pnr_mlp_validate(&d) != PNR_OK) return 0;
     if ((d.flags & PNR_MLP_SOFTMAX) && d.n_sem + d.n_inst > 0)      // softmax compositing: the best plan that HAS a softmax kernel
-        return (pnr_plan2_supported(d) && pnr_head_depth(d) == 2) ? 2 : pnr_plan1_supported(d) ? 1 : 0;
+        return pnr_plan2_supported(d) ? 2 : pnr_plan1_supported(d) ? 1 : 0;       // (k_mlp_tt_sm_* / _d1sm_*: both head depths)
     return pnr_plan2_supported(d) ? 2 : pnr_plan1_supported(d) ? 1 : 0;
 }
 

@@ -16,7 +16,7 @@ static const unsigned char k_co[] = {
 namespace {
 struct DevTable {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[3][3][2] = {};     // [variant: 0 = head_depth 2, 1 = head_depth 1, 2 = head_depth 2 with softmax compositing][nbs][nbi]
+    hipFunction_t fn[4][3][2] = {};     // [variant: 0 = head_depth 2, 1 = head_depth 1, 2 / 3 = the same with softmax compositing][nbs][nbi]
     hipFunction_t fn_trace[8] = {};     // [ablation]: 0 = the trace build; 1, 2, 3, 4, 7 exist only in PNR_TT_ABL=1 builds of the library
     bool tried = false, ok = false;
 };
@@ -51,6 +51,10 @@ static int tt_table(DevTable*& out, int capturing = 0)
             if (e == hipSuccess && geo[k][0]) {
                 snprintf(nm, sizeof(nm), "k_mlp_tt_sm_s%di%d", geo[k][0], geo[k][1]);
                 e = hipModuleGetFunction(&t.fn[2][geo[k][0]][geo[k][1]], t.mod, nm);
+            }
+            if (e == hipSuccess && geo[k][0]) {
+                snprintf(nm, sizeof(nm), "k_mlp_tt_d1sm_s%di%d", geo[k][0], geo[k][1]);
+                e = hipModuleGetFunction(&t.fn[3][geo[k][0]][geo[k][1]], t.mod, nm);
             }
         }
         // diagnostics kernels: only in `make EXTRA_TT=trace | abl` builds of the library
@@ -102,9 +106,7 @@ int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, bool
     PNR_HIP(hipStreamIsCapturing(stream, &cs));
     int rc = tt_table(t, cs != hipStreamCaptureStatusNone);
     if (rc != PNR_OK) return rc;
-    PNR_REQUIRE(!(softmax && nbs && head_depth == 1), "pnr_mlp_forward_composite: softmax compositing has no two-tile kernel at head_depth 1 "
-                "(pnr_mlp_fused_plan with PNR_MLP_SOFTMAX set says which plan has one)");
-    hipFunction_t fn = t->fn[!nbs ? 0 : softmax ? 2 : head_depth == 1 ? 1 : 0][nbs][nbi];
+    hipFunction_t fn = t->fn[!nbs ? 0 : (softmax ? 2 : 0) + (head_depth == 1 ? 1 : 0)][nbs][nbi];
     PNR_REQUIRE(fn, "pnr_mlp_tt: no kernel for %d + %d logit blocks at head_depth %d", nbs, nbi, head_depth);
     if (trace) {
         PNR_REQUIRE(head_depth != 1 && !softmax, "pnr_mlp_tt: the trace build exists for head_depth 2, logits compositing");

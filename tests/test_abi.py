@@ -166,12 +166,14 @@ def test_fused_pass_eligibility_and_workspace_arithmetic():
     assert ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 19, 40, 128, "bf16"), 192, sem_mode=0)
     assert ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 0, 0, 128, "bf16"), 192, sem_mode=1)       # no learned field: nothing to normalise
     assert ops.fused_image(0) is True and ops.fused_image(1) == "softmax"
-    # ... and the plan question is flag-aware: softmax has the two-tile kernel for heads of depth 2, plan 1 below it, nothing at depth 1
+    # ... and the plan question is flag-aware: softmax has the two-tile kernels for heads of depth 2 and 1, plan 1 (depth 2) below them
     d2 = ops.desc_for_mode(d, 1)
     assert lib.pnr_mlp_fused_plan(ctypes.byref(d2)) == 2 and lib.pnr_mlp_fused_plan(ctypes.byref(d)) == 2
     dd1 = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16", "trunk", 1)
-    assert lib.pnr_mlp_fused_plan(ctypes.byref(dd1)) == 2 and lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(dd1, 1))) == 0
-    assert ops.fused_supported(dd1, 192) and not ops.fused_supported(dd1, 192, sem_mode=1)
+    assert lib.pnr_mlp_fused_plan(ctypes.byref(dd1)) == 2 and lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(dd1, 1))) == 2
+    assert ops.fused_supported(dd1, 192) and ops.fused_supported(dd1, 192, sem_mode=1)
+    dt1 = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16", "feature", 1)          # head_tap feature + one Linear: no fused softmax at all
+    assert lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(dt1, 1))) == 0 and not ops.fused_supported(dt1, 192, sem_mode=1)
     d4 = ops.make_desc(4, 256, 1, 10, 4, 45, 32, 128, "bf16")            # another depth: no two-tile kernel, plan 1 has softmax
     assert lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(d4, 1))) == 1
     assert not ops.fused_supported(ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "fp32"), 192)

@@ -648,6 +648,16 @@ def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads):
         sc = max(1.0, float(a[k].abs().max()))
         assert float((a[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
         assert float((c[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
+    # ... and with softmax compositing (k_mlp_tt_d1sm_*: there is no ping-pong softmax kernel at this depth) against the two-kernel path
+    ds, is_ = net.packed(1, dev, "bf16", fused="softmax")
+    assert ds.plan == 2 and ops.fused_supported(ds, N, 1)
+    cs = ops.composite(raw, z, rays, C, K, True, None, None, None, 1, False, True)
+    for rep in range(2):
+        bs = ops.mlp_forward_composite(ds, is_, rays, z, None, None, False, True, sem_mode=1)
+        for k in cs:
+            sc = max(1.0, float(cs[k].abs().max()))
+            assert float((cs[k] - bs[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), (k, rep)
+    assert float((bs["semantic"].sum(-1) - bs["acc"]).abs().max()) < 1e-4
 
 
 def test_two_tile_kernel_is_the_default_where_it_exists_and_can_be_capped(dev, monkeypatch):
