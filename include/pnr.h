@@ -94,7 +94,7 @@ typedef struct pnr_mlp_desc {
 #define PNR_MLP_SOFTMAX 1      /* pnr_mlp_forward_composite / pnr_mlp_forward_tiles composite softmax(logits) over each learned field's
                                   channels instead of the logits (the reference's semantic_activation = softmax; pnr_composite's
                                   sem_mode 1).  Needs an image whose plan has a softmax kernel -- a head's logit blocks must be in
-                                  registers together: plan 2 (k_mlp_tt_sm_* / k_mlp_tt_d1sm_*, round 6) or plan 1; ask
+                                  registers together: plan 2 (the k_mlp_tt_*sm_* kernels, round 6) or plan 1; ask
                                   pnr_mlp_fused_plan WITH this flag set in desc.flags (0 = none: use pnr_mlp_forward + pnr_composite);
                                   PNR_EINVAL otherwise */
 #define PNR_MLP_TRACE 0x7A00   /* diagnostics BUILDS of the library only (make EXTRA_TT=trace | abl; the shipped library refuses the
@@ -160,7 +160,7 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  *   1: the fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then
  *      BOTH head hidden layers, then the two logit layers as ONE chunk (k_mlp_pp: 8 waves, one 32-sample tile per wave);
  *   2: the two-tile plan (the 8 x 256 network of the BASELINE configs: D = 8, skip = 4, L = 10 / 4, head_tap 0; no heads, a
- *      semantic head of up to 64 classes, or that plus an instance head of up to 32; head_depth 2 or 1): no chunk above 33 fragments, consumed by
+ *      semantic head of up to 64 classes, or that plus an instance head of up to 32; any head_tap / head_depth): no chunk above 33 fragments, consumed by
  *      k_mlp_tt -- hand-placed gfx950 assembly, one wave per SIMD, two tiles per wave, every LDS weight fragment feeds two MFMAs
  *      (csrc/asm/gen_mlp_tt.py);
  *   0: the classic order, which every entry point accepts.

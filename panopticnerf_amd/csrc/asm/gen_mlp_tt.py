@@ -134,12 +134,16 @@ class Sim:
 
 
 class Gen:
-    def __init__(self, nbs, nbi, name, trace=False, abl=0, depth=2, softmax=False):
+    def __init__(self, nbs, nbi, name, trace=False, abl=0, depth=2, softmax=False, tap=0):
         # abl (trace builds only; results invalid): 1 = no LDS-DMA pieces in the loop, 2 = no chunk hand-over (vmcnt + barrier),
         # 4 = no pack / ReLU of the hidden layers
         # depth: pnr_mlp_desc.head_depth -- 2: heads W -> W/2 -> n (sem0 | inst0 | sem1 | inst1); 1: one Linear W -> n per head, straight from
         # the trunk output h (round 6: SURVEY.md 9 item 4 as a kernel variant, k_mlp_tt_d1_s<n>i<m>)
         self.depth = depth
+        # tap: pnr_mlp_desc.head_tap -- 0: the heads read the trunk output h; 1: the feature_linear output F (round 6: k_mlp_tt_f..).  F must
+        # then outlive the views layer: the last g block goes to the gamma(d) registers instead of F[0:15] (g_block), and the head
+        # hidden layers' outputs to h -- dead once the rgb / sigma unit is issued -- instead of F (shs_block, shi_block)
+        self.tap = tap
         # softmax: semantic_activation = softmax (PNR_MLP_SOFTMAX) -- the learned fields composite softmax(logits) over their channels;
         # the tail normalises each head's transposed logit blocks per sample before the weighted sums (tail_softmax), operation for
         # operation fuse_softmax_t of the ping-pong kernel (pnr_mlp_fuse.h): k_mlp_tt_sm_s<n>i<m>
@@ -189,14 +193,14 @@ class Gen:
         # blocks would have to be packed inside the logit unit's first MFMA gaps), sem1's reduction runs beside inst1
         if self.depth == 1:             # one Linear per head: the logit layers read h itself (16 k-steps)
             if self.nbs:
-                add("sem1", self.nbs, [("hh", 16)], self.nbs, "logits")
+                add("sem1", self.nbs, [("tap", 16)], self.nbs, "logits")
             if self.nbi:
-                add("inst1", 1, [("hh", 16)], 1, "logits")
+                add("inst1", 1, [("tap", 16)], 1, "logits")
         else:
             if self.nbs:
-                add("sem0", 4, [("hh", 16)], 2, "relu")
+                add("sem0", 4, [("tap", 16)], 2, "relu")
             if self.nbi:
-                add("inst0", 4, [("hh", 16)], 2, "relu")
+                add("inst0", 4, [("tap", 16)], 2, "relu")
             if self.nbs:
                 add("sem1", self.nbs, [("shs", 8)], self.nbs, "logits")
             if self.nbi:
@@ -373,6 +377,8 @@ class Gen:
         if seg == "h":                  # the trunk's ping-pong: L1 reads A0 ... (layer i reads what layer i - 1 wrote)
             src = self.trunk_out(layer_index - 1)
             return Loc("a", src + 64 * t + 4 * ks)
+        if seg == "tap":                # what the heads read: h, or the feature (head_tap 1)
+            return Loc("a", (self.F_base() if self.tap else self.trunk_out(D - 1)) + 64 * t + 4 * ks)
         if seg == "hh":                 # the trunk output h = what L7 wrote
             return Loc("a", self.trunk_out(D - 1) + 64 * t + 4 * ks)
         if seg == "F":
@@ -402,12 +408,20 @@ class Gen:
             return Loc("v", V_G + 16 * t + 8 * blk + r)
         if blk == 2:
             return Loc("v", self.acc_reg(self.g2_acc) + 8 * t + r)                  # an idle accumulator (views / rgbs units take two)
+        if self.tap:
+            # head_tap 1: F is read by the heads.  gamma(d) of THIS group is dead once the views layer's MFMAs are issued (the pack runs
+            # during the rgb / sigma unit) and the next group's is encoded behind that unit: exactly [2 tiles][8] registers
+            return Loc("v", V_ED + 8 * t + r)
         return Loc("a", self.F_base() + 8 * t + r)                                  # F[0:15] (packed during the rgb / sigma unit)
 
     def shs_block(self, blk, t, r=0):
+        if self.tap:
+            return Loc("a", self.trunk_out(D - 1) + 32 * t + 8 * blk + r)           # h[0:63]: dead since the rgb / sigma unit
         return Loc("a", self.F_base() + 32 + 32 * t + 8 * blk + r)                  # F[32:95]
 
     def shi_block(self, blk, t, r=0):
+        if self.tap:
+            return Loc("a", self.trunk_out(D - 1) + 64 + 32 * t + 8 * blk + r)      # h[64:127]
         # the last inst0 unit is packed while sem1's MFMAs still read shs: its blocks go to h (dead once inst0's MFMAs are issued)
         if blk < 2:
             return Loc("a", self.F_base() + 96 + 16 * t + 8 * blk + r)              # F[96:127]
@@ -1538,6 +1552,11 @@ def metadata(names):
     return "\n".join(o)
 
 
+def variant_name(tap, depth, sm, nbs, nbi):
+    tag = ("f" if tap else "") + ("d1" if depth == 1 else "") + ("sm" if sm else "")
+    return "k_mlp_tt_%ss%di%d" % (tag + "_" if tag else "", nbs, nbi)
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
     parts = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 5", ""]
@@ -1546,17 +1565,17 @@ def main():
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())
-    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # head_depth = 1: one Linear per head
-        n = "k_mlp_tt_d1_s%di%d" % (nbs, nbi)
-        names.append(n)
-        parts.append(Gen(nbs, nbi, n, depth=1).kernel())
-    for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):       # semantic_activation = softmax (head_depth 2, and head_depth 1)
-        n = "k_mlp_tt_sm_s%di%d" % (nbs, nbi)
-        names.append(n)
-        parts.append(Gen(nbs, nbi, n, softmax=True).kernel())
-        n = "k_mlp_tt_d1sm_s%di%d" % (nbs, nbi)
-        names.append(n)
-        parts.append(Gen(nbs, nbi, n, depth=1, softmax=True).kernel())
+    # the variants of the networks WITH heads: head_tap (f) x head_depth 1 (d1) x softmax compositing (sm): k_mlp_tt[_f][_d1][sm]... as
+    # variant_name() spells them (pnr_mlp_tt.cpp builds the same names)
+    for tap in (0, 1):
+        for depth in (2, 1):
+            for sm in (False, True):
+                if (tap, depth, sm) == (0, 2, False):
+                    continue
+                for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):
+                    n = variant_name(tap, depth, sm, nbs, nbi)
+                    names.append(n)
+                    parts.append(Gen(nbs, nbi, n, depth=depth, softmax=sm, tap=tap).kernel())
     # diagnostics builds only (make EXTRA_TT=trace | abl): the production library carries no kernel that writes (64 + n_wg) * 4 bytes
     # to the clock buffer (a 16-byte clk_probe buffer under PNR_MLP_TRACE was an out-of-bounds device write)
     extra = sys.argv[3] if len(sys.argv) > 3 else ""

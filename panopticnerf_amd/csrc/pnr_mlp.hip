@@ -1008,7 +1008,8 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
         t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
         t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
         const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + (a << 4), a in 1..7: the timing-only ablation a
-        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, a.head_depth, softmax, st, trace, trace ? ((desc->flags >> 4) & 7) : 0);
+        return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, a.head_depth, a.head_tap, softmax, st, trace,
+                                 trace ? ((desc->flags >> 4) & 7) : 0);
     }
     if (desc->plan == 1) {
         const int nbs = (desc->n_sem + 31) / 32, nbi = (desc->n_inst + 31) / 32;

@@ -31,7 +31,7 @@ static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
 static inline int pnr_plan2_supported(const pnr_mlp_desc& d)
 {
     const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
-    return d.precision == PNR_PREC_BF16 && d.W == 256 && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 && d.head_tap == 0 &&
+    return d.precision == PNR_PREC_BF16 && d.W == 256 && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 &&      // head_tap 0 and (round 6) 1
            nbs <= 2 && nbi <= (nbs ? 1 : 0) && (nbs == 0 || d.head_W == 128);      // head_depth 2 and (round 6) 1
 }
 

@@ -16,7 +16,7 @@ static const unsigned char k_co[] = {
 namespace {
 struct DevTable {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[4][3][2] = {};     // [variant: 0 = head_depth 2, 1 = head_depth 1, 2 / 3 = the same with softmax compositing][nbs][nbi]
+    hipFunction_t fn[8][3][2] = {};     // [variant = 4 head_tap + 2 softmax + (head_depth == 1)][nbs][nbi]; without heads: variant 0
     hipFunction_t fn_trace[8] = {};     // [ablation]: 0 = the trace build; 1, 2, 3, 4, 7 exist only in PNR_TT_ABL=1 builds of the library
     bool tried = false, ok = false;
 };
@@ -41,20 +41,12 @@ static int tt_table(DevTable*& out, int capturing = 0)
         const bool loaded = e == hipSuccess;
         static const int geo[5][2] = {{1, 1}, {2, 1}, {0, 0}, {1, 0}, {2, 0}};      // (semantic, instance) logit blocks of the generated kernels
         for (int k = 0; k < 5 && e == hipSuccess; ++k) {
-            char nm[64];
-            snprintf(nm, sizeof(nm), "k_mlp_tt_s%di%d", geo[k][0], geo[k][1]);
-            e = hipModuleGetFunction(&t.fn[0][geo[k][0]][geo[k][1]], t.mod, nm);
-            if (e == hipSuccess && geo[k][0]) {        // head_depth = 1 and softmax twins (no twin without heads)
-                snprintf(nm, sizeof(nm), "k_mlp_tt_d1_s%di%d", geo[k][0], geo[k][1]);
-                e = hipModuleGetFunction(&t.fn[1][geo[k][0]][geo[k][1]], t.mod, nm);
-            }
-            if (e == hipSuccess && geo[k][0]) {
-                snprintf(nm, sizeof(nm), "k_mlp_tt_sm_s%di%d", geo[k][0], geo[k][1]);
-                e = hipModuleGetFunction(&t.fn[2][geo[k][0]][geo[k][1]], t.mod, nm);
-            }
-            if (e == hipSuccess && geo[k][0]) {
-                snprintf(nm, sizeof(nm), "k_mlp_tt_d1sm_s%di%d", geo[k][0], geo[k][1]);
-                e = hipModuleGetFunction(&t.fn[3][geo[k][0]][geo[k][1]], t.mod, nm);
+            // names as csrc/asm/gen_mlp_tt.py::variant_name spells them: k_mlp_tt_[f][d1][sm]_s<n>i<m>
+            for (int v = 0; v < (geo[k][0] ? 8 : 1) && e == hipSuccess; ++v) {
+                char tag[16], nm[64];
+                snprintf(tag, sizeof(tag), "%s%s%s", (v & 4) ? "f" : "", (v & 1) ? "d1" : "", (v & 2) ? "sm" : "");
+                snprintf(nm, sizeof(nm), "k_mlp_tt_%s%ss%di%d", tag, tag[0] ? "_" : "", geo[k][0], geo[k][1]);
+                e = hipModuleGetFunction(&t.fn[v][geo[k][0]][geo[k][1]], t.mod, nm);
             }
         }
         // diagnostics kernels: only in `make EXTRA_TT=trace | abl` builds of the library
@@ -96,7 +88,7 @@ void pnr_mlp_tt_prepare_quiet(void)
     if (tt_table(t) != PNR_OK) pnr_set_error("%s", keep.c_str());
 }
 
-int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, bool softmax, hipStream_t stream, bool trace, int trace_abl)
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, int head_tap, bool softmax, hipStream_t stream, bool trace, int trace_abl)
 {
     PNR_REQUIRE(nbs >= 0 && nbs <= 2 && nbi >= 0 && nbi <= (nbs ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
@@ -106,10 +98,10 @@ int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, bool
     PNR_HIP(hipStreamIsCapturing(stream, &cs));
     int rc = tt_table(t, cs != hipStreamCaptureStatusNone);
     if (rc != PNR_OK) return rc;
-    hipFunction_t fn = t->fn[!nbs ? 0 : (softmax ? 2 : 0) + (head_depth == 1 ? 1 : 0)][nbs][nbi];
+    hipFunction_t fn = t->fn[!nbs ? 0 : (head_tap ? 4 : 0) + (softmax ? 2 : 0) + (head_depth == 1 ? 1 : 0)][nbs][nbi];
     PNR_REQUIRE(fn, "pnr_mlp_tt: no kernel for %d + %d logit blocks at head_depth %d", nbs, nbi, head_depth);
     if (trace) {
-        PNR_REQUIRE(head_depth != 1 && !softmax, "pnr_mlp_tt: the trace build exists for head_depth 2, logits compositing");
+        PNR_REQUIRE(head_depth != 1 && !softmax && !head_tap, "pnr_mlp_tt: the trace build exists for head_depth 2, head_tap 0, logits compositing");
         PNR_REQUIRE(nbs == 2 && nbi == 1 && a.clk, "pnr_mlp_tt: the trace build exists for 2 + 1 logit blocks and needs the clock buffer");
         fn = t->fn_trace[trace_abl & 7];
         PNR_REQUIRE(fn, "pnr_mlp_tt: PNR_MLP_TRACE%s%d is not in this library: the trace kernels are diagnostics builds "

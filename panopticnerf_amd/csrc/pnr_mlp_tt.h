@@ -26,4 +26,5 @@ static_assert(sizeof(PnrTTArgs) == 88, "k_mlp_tt reads its arguments at fixed of
 int pnr_mlp_tt_prepare(void);
 // the same, best effort and silent, from the CPU-side packing entry points (no device / a capturing thread: nothing happens)
 void pnr_mlp_tt_prepare_quiet(void);
-int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, bool softmax, hipStream_t stream, bool trace = false, int trace_abl = 0);
+int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, int head_tap, bool softmax, hipStream_t stream, bool trace = false,
+                      int trace_abl = 0);

@@ -612,9 +612,48 @@ def test_two_tile_softmax_kernels_equal_pingpong_bit_for_bit(dev, R, N, heads):
     assert float((b["semantic"].sum(-1) - b["acc"]).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("sem_mode", [0, 1])
 @pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 0), (19, 0)])
 @pytest.mark.parametrize("R,N", [(300, 192), (1001, 64), (7, 32), (2051, 32)])
-def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads):
+def test_two_tile_kernels_for_heads_that_read_the_feature(dev, R, N, heads, sem_mode):
+    """head_tap = feature (the heads read the feature_linear output instead of the trunk output) in the two-tile
+    assembly form (round 6: k_mlp_tt_f[sm]_s<n>i<m>: the last g block lives in the gamma(d) registers and the head hidden layers'
+    outputs in h, so that F survives the views layer) against the ping-pong kernel on the plan-1 image: the same arithmetic --
+    records, quadruples and every map bit for bit, logits and softmax compositing -- and the network really taps the feature (its
+    maps differ from the same weights tapped at the trunk)."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    torch.manual_seed(R + N + C + 2)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K, head_tap="feature")).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d1, i1 = net.packed(1, dev, "bf16", fused=1)
+    d2, i2 = net.packed(1, dev, "bf16", fused="softmax" if sem_mode else 2)
+    assert d1.plan == 1 and d2.plan == 2 and d2.head_tap == 1
+    d1, d2 = ops.desc_for_mode(d1, sem_mode), ops.desc_for_mode(d2, sem_mode)
+    rec1, ps1 = _tiles_workspace(d1, i1, rays, z)
+    for rep in range(2):
+        rec2, ps2 = _tiles_workspace(d2, i2, rays, z)
+        assert torch.equal(ps1.view(torch.int32), ps2.view(torch.int32)), rep
+        assert torch.equal(rec1.view(torch.int32), rec2.view(torch.int32)), (rep, float((rec1 - rec2).abs().max()))
+    a = ops.mlp_forward_composite(d1, i1, rays, z, None, None, False, True, sem_mode=sem_mode)
+    b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True, sem_mode=sem_mode)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    net.nerf_1.head_tap = "trunk"           # same weights, the other tap: another function
+    net.invalidate_packed()
+    dt, it = net.packed(1, dev, "bf16", fused=True)
+    assert dt.head_tap == 0
+    c = ops.mlp_forward_composite(dt, it, rays, z, None, None, False, True)
+    assert float((c["semantic"] - ops.mlp_forward_composite(ops.desc_for_mode(d2, 0), i2, rays, z, None, None, False, True)["semantic"]).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("tap", ["trunk", "feature"])
+@pytest.mark.parametrize("heads", [(45, 32), (19, 8), (64, 0), (19, 0)])
+@pytest.mark.parametrize("R,N", [(300, 192), (1001, 64), (7, 32), (2051, 32)])
+def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads, tap):
     """head_depth = 1 (heads of one Linear W -> n, read from the trunk output) in the two-tile assembly form
     (round 6: k_mlp_tt_d1_s<n>i<m>, plan 2) against the ping-pong kernel's fused pass on the classic image (plan 0: there is no
     plan 1 for this depth).  The two reduce a tile's logits differently (transposed FMA chains against 32-lane butterflies), so
@@ -625,13 +664,13 @@ def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads):
     from panopticnerf_amd import make_network
     C, K = heads
     torch.manual_seed(R + N + C)
-    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K, head_depth=1)).to(dev).eval()
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=K, head_depth=1, head_tap=tap)).to(dev).eval()
     synthetic.trained_like_(net, 0.05)
     rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
     z = ops.stratified(rays, N)
     d0, i0 = net.packed(1, dev, "bf16", fused=0)
     d2, i2 = net.packed(1, dev, "bf16", fused=2)
-    assert d0.plan == 0 and d2.plan == 2 and d2.head_depth == 1
+    assert d0.plan == 0 and d2.plan == 2 and d2.head_depth == 1 and d2.head_tap == int(tap == "feature")
     rec0, ps0 = _tiles_workspace(d0, i0, rays, z)
     for rep in range(2):
         rec2, ps2 = _tiles_workspace(d2, i2, rays, z)

@@ -68,8 +68,10 @@ def test_two_tile_plan_image_matches_the_assembly_generator():
     spec = importlib.util.spec_from_file_location("gen_mlp_tt", os.path.join(root, "panopticnerf_amd", "csrc", "asm", "gen_mlp_tt.py"))
     G = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(G)
-    for C, K, depth in ((45, 32, 2), (19, 8, 2), (45, 0, 2), (19, 0, 2), (0, 0, 2), (45, 32, 1), (19, 8, 1), (64, 0, 1), (19, 0, 1)):
-        net = make_network(NS(num_classes=C, num_instances=K, head_depth=depth))
+    for C, K, depth, tap in ((45, 32, 2, "trunk"), (19, 8, 2, "trunk"), (45, 0, 2, "trunk"), (19, 0, 2, "trunk"), (0, 0, 2, "trunk"),
+                             (45, 32, 1, "trunk"), (19, 8, 1, "trunk"), (64, 0, 1, "trunk"), (19, 0, 1, "trunk"),
+                             (45, 32, 2, "feature"), (19, 0, 2, "feature"), (45, 32, 1, "feature"), (64, 0, 1, "feature")):
+        net = make_network(NS(num_classes=C, num_instances=K, head_depth=depth, head_tap=tap))
         desc = net.nerf_0.desc("bf16")
         assert (desc.head_depth == 1) == (depth == 1)
         # head_depth 1 (round 6): the two-tile kernels k_mlp_tt_d1_*; it has no plan 1 (the ping-pong kernel's merged logit chunk)
@@ -77,7 +79,7 @@ def test_two_tile_plan_image_matches_the_assembly_generator():
         desc.plan = 2
         img = ops.pack_mlp(desc, net.nerf_0.state_dict())
         im = PackedImage(img)
-        g = G.Gen((C + 31) // 32, (K + 31) // 32, "x", depth=depth)
+        g = G.Gen((C + 31) // 32, (K + 31) // 32, "x", depth=depth, tap=int(tap == "feature"))
         # the kernel pads its group to a multiple of four chunks with DUMMY chunks (a piece of fragment 0, no unit): not in the image
         real = [c for c in g.chunks if not c.get("dummy")]
         assert all(c.get("dummy") for c in g.chunks[len(real):]) and all((c["off"], c["nfrag"]) == (0, 1) for c in g.chunks[len(real):])
