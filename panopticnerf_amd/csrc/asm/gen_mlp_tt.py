@@ -1105,7 +1105,7 @@ class Gen:
                     e("v_permlane16_swap_b32 v%d, v%d" % (regs[g + i], TMP[i]))
                 for i in range(4):
                     e("%s v%d, v%d, v%d" % (op, regs[g + i], regs[g + i], TMP[i]))
-        for hi_, (inst, hb) in enumerate(heads):
+        for inst, hb in heads:
             accs = [[self.acc_reg(u["accs"][(bi, t)]) for (u, bi, blk) in hb] for t in (0, 1)]      # [tile][block] -> first register
             NB = len(hb)
             vm = S_VMSK + 2 * (1 if inst else 0)
