@@ -35,6 +35,8 @@ import os
 DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)
+WAIT2 = os.environ.get("PNR_TT_WAIT2", "0") != "0"             # (A/B builds) one s_waitcnt lgkmcnt per two fragments instead of one per fragment
+SHARE_BIAS = os.environ.get("PNR_TT_SHARE_BIAS", "1") != "0"     # one armed accumulator per block: tile 1's first MFMA reads tile 0's (A/B builds)
 NSLOT, SLOT = 4, int(os.environ.get("PNR_TT_SLOT_KIB", "33")) * 1024      # (A/B builds: the slot stride, tools/build_tt_variant.sh)
 ACC_PERM = [int(x) for x in os.environ.get("PNR_TT_ACC_PERM", "0,1,2,3,4,5,6,7").split(",")]     # register block of accumulator i (A/B builds)
 SLOT_POS = [int(x) for x in os.environ.get("PNR_TT_SLOT_ORDER", "0,1,2,3").split(",")]      # physical position of logical slot c % 4
@@ -848,6 +850,12 @@ class Gen:
                     while not self.acc_free and self.side_busy():       # a queued epilogue still holds accumulators: run it now
                         self.drain_side(8)
                     u["accs"][key] = self.acc_take(1)[0]
+                if t == 1 and SHARE_BIAS:
+                    # the two tiles of a block start from the SAME bias: tile 1's first MFMA takes tile 0's armed accumulator as its
+                    # C operand (emit_unit issues it in front of tile 0's) -- its own accumulator is only taken, never armed: half the
+                    # arming reads (408 of the 816 LDS reads per group), same values
+                    plans.append([take])
+                    continue
                 if l["mode"] == "logits":       # transposed product: every register = bias of channel lane & 31
                     def first(key=key, slot=slot, take=take):           # the address lives in the accumulator's first register, read last
                         take()
@@ -892,6 +900,11 @@ class Gen:
         return out
 
     # ------------------------------------------------------------------ one unit of MFMAs with its fillers
+    @staticmethod
+    def tile_at(ks, t):
+        """the tile of the t-th MFMA of a fragment: (0, 1), except at a block's first k-step with SHARE_BIAS: (1, 0)"""
+        return 1 - t if (SHARE_BIAS and ks == 0) else t
+
     def b_operand(self, u, ks, t):
         l = self.layers[u["layer"]]
         seg, k = self.seg_of_ks(l, ks)
@@ -927,7 +940,7 @@ class Gen:
         reads = {}
         for i in range(nm):
             f, t = i // 2, i % 2
-            loc = self.b_operand(u, frags[f][2], t)
+            loc = self.b_operand(u, frags[f][2], self.tile_at(frags[f][2], t))
             for r in range(4):
                 reads.setdefault((loc.kind, loc.base + r), i)
         # ... and, pipelined with it, the NEXT unit's bias: as soon as an accumulator is packed it is released and re-armed.  One list
@@ -1006,14 +1019,21 @@ class Gen:
                     for tg in u["arm_tags"][-1:]:
                         self.wait_lgkm(tg)                          # the unit's bias has landed (in-order: the last read covers all)
                     first_wait_done = True
-                self.wait_lgkm(self.ring_tags[gi % P])
-            a = self.acc_reg(u["accs"][(bi, t)])
-            bloc = self.b_operand(u, ks, t)
+                if WAIT2 and f + 1 < len(frags):
+                    if f % 2 == 0:                                  # one counted wait per TWO fragments: the younger of the pair covers both
+                        self.wait_lgkm(self.ring_tags[(gi + 1) % P])
+                else:
+                    self.wait_lgkm(self.ring_tags[gi % P])
+            tile = self.tile_at(ks, t)
+            a = self.acc_reg(u["accs"][(bi, tile)])
+            # a block's first k-step (SHARE_BIAS): tile 1 first, reading the bias out of tile 0's accumulator, then tile 0 in place
+            c_in = self.acc_reg(u["accs"][(bi, 0)]) if (SHARE_BIAS and ks == 0) else a
+            bloc = self.b_operand(u, ks, tile)
             ring = vr(V_RING + 4 * (gi % P), 4)
             if swap:
-                e("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(a, 16), bloc.reg(0, 4), ring, vr(a, 16)))
+                e("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(a, 16), bloc.reg(0, 4), ring, vr(c_in, 16)))
             else:
-                e("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(a, 16), ring, bloc.reg(0, 4), vr(a, 16)))
+                e("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(a, 16), ring, bloc.reg(0, 4), vr(c_in, 16)))
             # ---- fillers of gap i
             if t == 1:
                 gn = gi + P - 1
