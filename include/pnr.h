@@ -155,7 +155,9 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  * points to the branch that holds them) under: bf16, logits compositing (sem_mode 0), no sigma noise, n_samples a
  * multiple of 32 in [32, 256], n_sem + n_inst <= 128.  Results equal the two-kernel path to fp32 rounding (the sums are
  * associated per tile).  Outputs as pnr_composite's (any may be null; fix_* need their labels); weights (R,N) optional.
- * workspace: pnr_mlp_forward_composite_workspace_bytes(desc, n_rays, n_samples, weights != null) device bytes. */
+ * workspace: pnr_mlp_forward_composite_workspace_bytes(desc, n_rays, n_samples, weights != null) device bytes (tile records,
+ * per-sample quadruples and 128 B per ray: |d| and gamma(d / |d|) once per ray, written by a pre-kernel for the plan-2 kernel --
+ * which takes at most 2^24 rays per call). */
 /* Chunk order for images that only pnr_mlp_forward_composite will consume: the BEST plan `desc`'s geometry has.
  *   1: the fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then
  *      BOTH head hidden layers, then the two logit layers as ONE chunk (k_mlp_pp: 8 waves, one 32-sample tile per wave);

@@ -21,8 +21,8 @@ Time structure per 256-sample group (one workgroup; tile = (wave, t), record ind
   c + 1.  MFMAs are grouped in UNITS (<= 2 output blocks x all k-steps x 2 tiles, one accumulator per (block, tile)); a unit's
   accumulators are packed / reduced while the NEXT unit's MFMAs run, the unit after that finds its bias already in its
   accumulators.  Weight fragments pass through a ring of 4 register quads, 3 fragments ahead, counted lgkmcnt.
-  Side work (input fetch, gamma(x) / gamma(d) of the NEXT group, the compositing epilogue) is a queue of instructions drained a few
-  per MFMA gap."""
+  Side work (input fetch and gamma(x) of the NEXT group, the compositing epilogue) is a queue of instructions drained a few
+  per MFMA gap; what depends on the RAY alone (|d|, gamma(d / |d|)) is loaded from the table k_ray_aux (pnr_mlp.hip) wrote."""
 import struct
 import sys
 from contextlib import contextmanager
@@ -60,6 +60,7 @@ V_ZZ, V_ZN, V_DN, V_LW = 240, 242, 244, 246      # [2] each: per-tile compositin
 V_IN = 224                              # next group's inputs [2][8]: ox oy oz dx dy dz zz zn   (v[224:239])
 V_TMP = 208                             # encoder / epilogue temporaries share the g area once g is dead: v[208:223]
 V_PTMP = 248                            # 8 more temporaries v[248:255]
+V_AUXA = V_PTMP + 6                     # [2 tiles]: the lane's address in the per-ray table between the fetch of a tile and its point (v[254:255])
 V_LWA = V_IN + 2                        # address of the local-weight table reads in a group's last unit (the next group's o_z: dead since its point)
 # ---- AGPR map: two activation arrays of [2 tiles][64]
 A0, A1 = 0, 128
@@ -72,6 +73,7 @@ S_LO32, S_N0, S_HI0 = 52, 54, 56        # constants: lanes 0..31, lanes {0, 32},
 S_SAVE, S_REC_T = 58, 60                # saved exec; the two tiles' record pointers s[60:61], s[62:63]
 S_MSK = 64                              # store masks of the (up to) three logit blocks: s[64:69] = lanes with hi == 0 and channel < n_out
 S_REC_I = 70                            # the two tiles' record pointers + 4 n_sem (the instance columns): s[70:73]
+S_AUX = 82                              # s[82:83]: the per-ray table k_ray_aux wrote (gamma(d) of both half-waves and |d|: 128 B per ray)
 S_VMSK = 76                             # softmax kernels: s[76:77] / s[78:79] = ALL lanes whose channel of the semantic / instance head's last block exists
 S_LWW, S_LWR = 74, 75                   # LDS addresses of this wave's local-weight table: + 4 (lane & 31) to write, + (V_BIAS[0] = slot 0 + 16 hi) to read
 LW_BASE = NSLOT * SLOT                  # [4 waves][2 tiles][32 floats] behind the weight slots (1 KiB)
@@ -165,6 +167,7 @@ class Gen:
         self.logit_units = []
         self.acc_free = list(range(8))
         self.lwr_acc = self.lwr_tag = None
+        self.aux_tags = {}
         self.build_plan()
         self.build_units()
         self.stream = []
@@ -607,6 +610,10 @@ class Gen:
         e("v_sub_u32 v%d, v%d, v%d" % (a64, sl, a64))
         e("v_add_u32 v%d, 1, v%d" % (a64, a64))
         e("v_cmp_eq_u32 s[%d:%d], s%d, v%d" % (S_NLAST + 2 * t, S_NLAST + 2 * t + 1, S_N, a64))
+        # this lane's line of the per-ray table: ray * 128 + hi * 64 (kept until the point is formed: aux_x)
+        e("v_lshlrev_b32 v%d, 7, v%d" % (V_AUXA + t, ray))
+        e("v_and_b32 v%d, 32, v%d" % (a64, V_TID))
+        e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (V_AUXA + t, a64, V_AUXA + t))
         # loads
         e("v_lshlrev_b32 v%d, 5, v%d" % (a64, ray))                                     # ray * 32 bytes (R * 32 < 2^32: R * N < 2^31, N >= 32)
         self.vm_op("global_load_dwordx4 %s, v%d, s[%d:%d]" % (vr(vi, 4), a64, S_RAYS, S_RAYS + 1))
@@ -638,24 +645,22 @@ class Gen:
             e("v_cndmask_b32 v%d, v%d, v%d, s[%d:%d]" % (dst, v_hi1, v_hi0, S_HI0, S_HI0 + 1))
 
         def points():
-            # p = o + d * z (separate multiply and add), |d| = sqrt((dx dx + dy dy) + dz dz)
+            # p = o + d * z (separate multiply and add)
             for a in range(3):
                 e("v_mul_f32 v%d, v%d, v%d" % (q[a], vi + 3 + a, vi + 6))
                 e("v_add_f32 v%d, v%d, v%d" % (q[a], vi + a, q[a]))
-            e("v_mul_f32 v%d, v%d, v%d" % (w[0], vi + 3, vi + 3))
-            e("v_mul_f32 v%d, v%d, v%d" % (w[1], vi + 4, vi + 4))
-            e("v_add_f32 v%d, v%d, v%d" % (w[0], w[0], w[1]))
-            e("v_mul_f32 v%d, v%d, v%d" % (w[1], vi + 5, vi + 5))
-            e("v_add_f32 v%d, v%d, v%d" % (w[0], w[0], w[1]))
         if part == "x":
-            out.append((11, points))
+            out.append((6, points))
 
-        def norm():
-            self.sqrt(w[5], w[0], [w[1], w[2], w[3]])
-            # park |d| in the ray record's unused `ox` slot?  no: ox is still needed for nothing after points() -- q holds the point
-            e("v_mov_b32 v%d, v%d" % (vi + 0, w[5]))        # V_IN + 0 := |d| of the next group
+        def aux_x():
+            # |d| = sqrt((dx dx + dy dy) + dz dz) and gamma(d / |d|) are PER-RAY values: k_ray_aux (pnr_mlp.hip) computed them once per
+            # ray, with the operations this kernel used to spend on them per sample (sqrt, three divisions, three sincos, a band step:
+            # 188 instructions per tile).  Here: |d| into the ray record's `ox` slot, the table address into the `dx` slot -- both are
+            # parked across the views layer (PARK) --, gamma(d) is loaded behind the rgb / sigma unit (part "d")
+            self.aux_tags[t] = self.vm_op("global_load_dword v%d, v%d, s[%d:%d] offset:32" % (vi + 0, V_AUXA + t, S_AUX, S_AUX + 1))
+            e("v_mov_b32 v%d, v%d" % (vi + 3, V_AUXA + t))
         if part == "x":
-            out.append((22, norm))
+            out.append((2, aux_x))
 
         def xyz_reg():
             # reg 0 of gamma(x): pack(hi ? pz : px, hi ? 0 : py)
@@ -678,39 +683,16 @@ class Gen:
                 if fp < 4:
                     out.append((15, (lambda: self.band_next(s, c, tt))))
 
-        # q = d / |d|, kept in the d slots of V_IN
-        def dirs():
-            for a in range(3):
-                self.div(q[a], vi + 3 + a, vi + 0, [w[0], w[1], w[2], w[3], w[4]])
-                e("s_nop 0")
-            for a in range(3):
-                e("v_mov_b32 v%d, v%d" % (vi + 3 + a, q[a]))
         if part == "x":
-            out.append((39, dirs))
+            out.append((1, (lambda: self.wait_vm(self.aux_tags[t]))))       # |d| has landed before anything (park) copies it
             return out
 
-        def load_q():
-            for a in range(3):
-                e("v_mov_b32 v%d, v%d" % (q[a], vi + 3 + a))
-        out.append((3, load_q))
-
-        def d_reg():
-            hi_select(w[0], q[2], q[0])
-            e("v_mov_b32 v%d, 0" % w[1])
-            hi_select(w[1], w[1], q[1])
-            e("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (ed, w[0], w[1]))
-            e("v_mov_b32 v%d, 4.0" % tt)
-            e("v_mov_b32 v%d, 1.0" % w[1])
-            hi_select(tt, tt, w[1])
-            for a in range(3):
-                e("v_mul_f32 v%d, v%d, v%d" % (q[a], q[a], tt))
-        out.append((12, d_reg))
-        for a in range(3):
-            out.append((30, (lambda a=a: self.sincos(s[a], c[a], q[a], w))))
-        out.append((3, (lambda: self.band_pack(ed + 1, s, c))))
-        out.append((15, (lambda: self.band_next(s, c, tt))))
-        out.append((3, (lambda: self.band_pack(ed + 4, s, c))))
-        out.append((1, (lambda: e("v_mov_b32 v%d, 0" % (ed + 7)))))
+        def d_load():
+            # this lane's eight packed registers of gamma(d): [x|y or z|0] [band 0 triple] [band 1 triple] [0], as embed_lane writes them
+            self.vm_op("global_load_dwordx4 %s, v%d, s[%d:%d]" % (vr(ed, 4), vi + 3, S_AUX, S_AUX + 1))
+            self.aux_tags[2 + t] = self.vm_op("global_load_dwordx4 %s, v%d, s[%d:%d] offset:16" % (vr(ed + 4, 4), vi + 3, S_AUX, S_AUX + 1))
+        out.append((2, d_load))
+        out.append((1, (lambda: self.wait_vm(self.aux_tags[2 + t]))))
         return out
 
     # ---- the compositing epilogue of the rgb / sigma block (fuse_rgbs) of tile t; acc = VGPR base of its accumulator
@@ -1288,7 +1270,7 @@ class Gen:
 
     def queue_inputs_early(self):
         """side work from the first unit behind the skip layer on (gamma(x) of this group is dead): the next group's inputs, its
-        point, |d|, gamma(x) and q = d / |d|.  Temporaries and inputs live in the g area (free until views' first pack)."""
+        point, gamma(x), and |d| from the per-ray table.  Temporaries and inputs live in the g area (free until views' first pack)."""
         def which():
             # g2 = grp + n_wg < n_groups ? grp + n_wg : grp
             with self.atomic():
@@ -1304,24 +1286,25 @@ class Gen:
             for cost, fn in self.encode_tile(t, "x"):
                 self.q(cost, fn)
 
-    PARK = (3, 4, 5, 6, 7, 0)       # what of V_IN outlives gamma(x): q (3), z, z_next, |d|
+    PARK = (3, 6, 7, 0)             # what of V_IN outlives gamma(x): the per-ray table address, z, z_next, |d|
 
     def park(self):
         """views' packs of tile 1 land on V_IN: its six live values per tile wait in an idle accumulator until the rgb / sigma unit"""
         self.park_acc = self.acc_take(1)[0]
         for t in range(2):
             for i, k in enumerate(Gen.PARK):
-                self.e("v_mov_b32 v%d, v%d" % (self.acc_reg(self.park_acc) + 6 * t + i, V_IN + 8 * t + k))
+                self.e("v_mov_b32 v%d, v%d" % (self.acc_reg(self.park_acc) + len(Gen.PARK) * t + i, V_IN + 8 * t + k))
 
     def unpark(self):
         for t in range(2):
             for i, k in enumerate(Gen.PARK):
-                self.e("v_mov_b32 v%d, v%d" % (V_IN + 8 * t + k, self.acc_reg(self.park_acc) + 6 * t + i))
+                self.e("v_mov_b32 v%d, v%d" % (V_IN + 8 * t + k, self.acc_reg(self.park_acc) + len(Gen.PARK) * t + i))
         self.acc_release([self.park_acc])
         self.park_acc = None
 
     def queue_inputs_late(self):
-        """behind the rgb / sigma unit (gamma(d) of this group is dead): gamma(d) of the next group.  (Round 6 tried the skip layer's
+        """behind the rgb / sigma unit (gamma(d) of this group is dead): gamma(d) of the next group -- since the per-ray table two
+        16-byte loads per tile; before it ~250 instructions of division, sincos and packing per tile.  (Round 6 tried the skip layer's
         one-block units of the SAME group instead -- the emptiest gaps of the loop: bit-identical, and no faster: the skip layer's units
         grew by what the head units shrank, profiles/r06/r06f.  What the kernel pays for is the NUMBER of non-MFMA instructions, not
         where they stand.)"""
@@ -1401,7 +1384,7 @@ class Gen:
         e, name = self.e, self.name
         self.o += ["\t.text", "\t.globl\t%s" % name, "\t.p2align\t8", "\t.type\t%s,@function" % name, "%s:" % name]
         for dst, off, n in ((S_IMG, 0x0, 2), (S_RAYS, 0x8, 2), (S_Z, 0x10, 2), (S_S, 0x18, 2), (S_MAGIC, 0x20, 2), (S_NGRP, 0x28, 2),
-                            (S_REC, 0x30, 2), (S_RECF, 0x38, 1), (S_PS, 0x40, 2), (S_NSEM, 0x48, 2), (S_CLK, 0x50, 2)):
+                            (S_REC, 0x30, 2), (S_RECF, 0x38, 1), (S_PS, 0x40, 2), (S_NSEM, 0x48, 2), (S_CLK, 0x50, 2), (S_AUX, 0x58, 2)):
             e("s_load_dword%s %s, s[0:1], 0x%x" % ("x2" if n == 2 else "", sr(dst, n), off))
         # wave id from v0 itself (never written): a v_readfirstlane of a register that is re-used a few instructions later was
         # observed to return the LATER value while scalar-load data was returning (tools/probe/gen_two_tile_asm.py)
@@ -1556,7 +1539,7 @@ class Gen:
         return "\n".join(self.o)
 
 
-KERNARG_BYTES = 88
+KERNARG_BYTES = 96
 
 
 def metadata(names):

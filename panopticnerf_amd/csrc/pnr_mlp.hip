@@ -953,6 +953,7 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
     return mlp_forward_impl(desc, packed, rays, z, n_rays, n_samples, raw, raw_stride_s, raw_stride_c, nullptr, stream);
 }
 
+#define PNR_RAY_AUX_BYTES 128
 int pnr_composite_combine_launch(const float* rec, int rec_floats, const float4* ps, const float* z, const int32_t* label_sem,
                                  const int32_t* label_inst, int64_t R, int N, int C, int K, int white_bkgd, float* rgb, float* depth,
                                  float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, hipStream_t st);
@@ -964,7 +965,28 @@ PNR_EXPORT int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc*
     (void)want_weights;
     if (pnr_mlp_validate(desc) != PNR_OK || n_rays < 0 || n_samples < 32 || (n_samples & 31)) return -1;
     const int64_t S = n_rays * n_samples, tiles = (S + 255) / 256 * 8;
-    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + S * 16 + 256;
+    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + S * 16 + 256 + PNR_RAY_AUX_BYTES + n_rays * PNR_RAY_AUX_BYTES;
+}
+
+// What the two-tile kernel needs of a RAY rather than of a sample: |d| and gamma(d / |d|), in the registers embed_lane hands a lane
+// of either half-wave.  k_mlp_tt used to compute them per sample (188 of a tile's ~530 encoder instructions; N samples of a ray
+// share them); this kernel computes them once per ray with the SAME calls (bit-identical by construction), 128 bytes per ray:
+// [half-wave]{8 packed registers, |d|, 7 unused}.  ~1 us per 100k rays in front of a launch of milliseconds.
+__global__ void __launch_bounds__(256) k_ray_aux(const float* __restrict__ rays, int64_t R, uint32_t* __restrict__ aux)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * R) return;
+    const int64_t ray = i >> 1;
+    const int hi = (int)(i & 1);
+    const float dx = rays[ray * 8 + 3], dy = rays[ray * 8 + 4], dz = rays[ray * 8 + 5];
+    // k_composite's |d|: sqrtf((dx*dx + dy*dy) + dz*dz), contraction off
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    uint32_t ed[8];
+    embed_lane<PNR_PREC_BF16, 2, 16, 8>(dx / nrm, dy / nrm, dz / nrm, hi, ed);
+    uint4* o = reinterpret_cast<uint4*>(aux + i * 16);
+    o[0] = make_uint4(ed[0], ed[1], ed[2], ed[3]);
+    o[1] = make_uint4(ed[4], ed[5], ed[6], ed[7]);
+    o[2] = make_uint4(__float_as_uint(nrm), 0u, 0u, 0u);
 }
 
 // the fused MLP launch alone (records + optional local weights into `workspace`); `a` is returned for the combine step
@@ -1007,6 +1029,12 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
         memset(&t, 0, sizeof(t));
         t.image = a.data; t.rays = rays; t.z = z; t.S = a.S; t.N = a.N; t.n_magic = a.n_magic; t.n_shift = a.n_shift;
         t.rec = a.rec; t.rec_floats = a.rec_floats; t.ps = a.ps; t.n_sem = a.n_sem; t.n_inst = a.n_inst; t.clk = a.clk;
+        // the per-ray table behind the quadruples (and their 256 bytes of slack), on a 128-byte line of its own per ray
+        PNR_REQUIRE(n_rays < ((int64_t)1 << 24), "pnr_mlp_forward_composite: the two-tile kernel addresses 2^24 rays per launch");
+        uint32_t* aux = (uint32_t*)(((uintptr_t)((uint8_t*)a.ps + (int64_t)a.S * 16 + 256) + PNR_RAY_AUX_BYTES - 1)
+                                    & ~(uintptr_t)(PNR_RAY_AUX_BYTES - 1));
+        k_ray_aux<<<dim3((unsigned)((2 * n_rays + 255) / 256)), dim3(256), 0, st>>>(rays, n_rays, aux);
+        t.aux = aux;
         const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + (a << 4), a in 1..7: the timing-only ablation a
         return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, a.head_depth, a.head_tap, softmax, st, trace,
                                  trace ? ((desc->flags >> 4) & 7) : 0);

@@ -186,8 +186,8 @@ def test_fused_pass_eligibility_and_workspace_arithmetic():
     for R, N in ((1, 32), (37, 192), (65536, 192), (510, 64)):
         S = R * N
         tiles = (S + 255) // 256 * 8
-        assert ws(ctypes.byref(d), R, N, 0) == tiles * rec * 4 + S * 16 + 256
+        assert ws(ctypes.byref(d), R, N, 0) == tiles * rec * 4 + S * 16 + 256 + 128 * (R + 1)       # + the per-ray table of k_ray_aux
         assert ws(ctypes.byref(d), R, N, 1) == ws(ctypes.byref(d), R, N, 0)
     assert ws(ctypes.byref(d), 10, 100, 0) == -1 and ws(ctypes.byref(d), 10, 16, 0) == -1
     d0 = ops.make_desc(4, 128, -1, 10, 4, 0, 0, 64, "bf16")
-    assert ws(ctypes.byref(d0), 8, 32, 0) == 8 * 4 * 4 + 8 * 32 * 16 + 256          # no heads: Q alone, padded to 4 floats
+    assert ws(ctypes.byref(d0), 8, 32, 0) == 8 * 4 * 4 + 8 * 32 * 16 + 256 + 128 * 9          # no heads: Q alone, padded to 4 floats
