@@ -455,7 +455,7 @@ class Gen:
             if c.get("dummy"):
                 continue
             l = self.layers[c["layer"]]
-            step = 2 if l["mode"] != "logits" else c["nfb"]
+            step = 2 if l["mode"] != "logits" else min(c["nfb"], 2)        # (a third semantic block, nbs = 3: units [0, 1] and [2])
             if l["name"] == "rgbs":
                 step = 1
             blocks = list(range(c["fb"], c["fb"] + c["nfb"]))
@@ -1564,7 +1564,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
     parts = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 5", ""]
     names = []
-    for nbs, nbi in ((1, 1), (2, 1), (0, 0), (1, 0), (2, 0)):
+    for nbs, nbi in ((1, 1), (2, 1), (0, 0), (1, 0), (2, 0), (3, 0)):
         n = "k_mlp_tt_s%di%d" % (nbs, nbi)
         names.append(n)
         parts.append(Gen(nbs, nbi, n).kernel())
@@ -1575,7 +1575,7 @@ def main():
             for sm in (False, True):
                 if (tap, depth, sm) == (0, 2, False):
                     continue
-                for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0)):
+                for nbs, nbi in ((1, 1), (2, 1), (1, 0), (2, 0), (3, 0)):
                     n = variant_name(tap, depth, sm, nbs, nbi)
                     names.append(n)
                     parts.append(Gen(nbs, nbi, n, depth=depth, softmax=sm, tap=tap).kernel())

@@ -25,14 +25,15 @@ static inline int pnr_plan1_supported(const pnr_mlp_desc& d)
     return d.precision == PNR_PREC_BF16 && d.W == 256 && nbs >= 1 && nbs <= 2 && nbi <= 1 && pnr_head_depth(d) == 2;
 }
 // plan 2 (the two-tile kernel's image): the geometries its generated kernels exist for -- the 8 x 256 network of BASELINE configs 2..5
-// with no heads, a semantic head of 1..2 logit blocks, or a semantic and a 1-block instance head (csrc/asm/gen_mlp_tt.py); heads of
+// with no heads, a semantic head of 1..3 logit blocks, or a semantic head of 1..2 and a 1-block instance head (csrc/asm/gen_mlp_tt.py); heads of
 // depth 2 (W -> W/2 -> n) or 1 (one Linear W -> n: the generic head_depth-1 branch of pnr_build_plan with the plan-2 chunk rules)
 #define PNR_PLAN2_MAX_CHUNK_FRAGS 33
 static inline int pnr_plan2_supported(const pnr_mlp_desc& d)
 {
     const int nbs = (d.n_sem + 31) / 32, nbi = (d.n_inst + 31) / 32;
     return d.precision == PNR_PREC_BF16 && d.W == 256 && d.D == 8 && d.skip == 4 && d.xyz_L == 10 && d.dir_L == 4 &&      // head_tap 0 and (round 6) 1
-           nbs <= 2 && nbi <= (nbs ? 1 : 0) && (nbs == 0 || d.head_W == 128);      // head_depth 2 and (round 6) 1
+           nbs <= 3 && nbi <= (nbs == 1 || nbs == 2 ? 1 : 0) && (nbs == 0 || d.head_W == 128);      // head_depth 2 and (round 6) 1;
+           // a third semantic block (65..96 classes) without an instance head: six logit accumulators + two for the local weights
 }
 
 #ifndef PNR_PLAN1_TRUNK0_MERGE

@@ -16,7 +16,7 @@ static const unsigned char k_co[] = {
 namespace {
 struct DevTable {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[8][3][2] = {};     // [variant = 4 head_tap + 2 softmax + (head_depth == 1)][nbs][nbi]; without heads: variant 0
+    hipFunction_t fn[8][4][2] = {};     // [variant = 4 head_tap + 2 softmax + (head_depth == 1)][nbs][nbi]; without heads: variant 0
     hipFunction_t fn_trace[8] = {};     // [ablation]: 0 = the trace build; 1, 2, 3, 4, 7 exist only in PNR_TT_ABL=1 builds of the library
     bool tried = false, ok = false;
 };
@@ -39,8 +39,8 @@ static int tt_table(DevTable*& out, int capturing = 0)
         t.tried = true;
         hipError_t e = hipModuleLoadData(&t.mod, k_co);
         const bool loaded = e == hipSuccess;
-        static const int geo[5][2] = {{1, 1}, {2, 1}, {0, 0}, {1, 0}, {2, 0}};      // (semantic, instance) logit blocks of the generated kernels
-        for (int k = 0; k < 5 && e == hipSuccess; ++k) {
+        static const int geo[6][2] = {{1, 1}, {2, 1}, {0, 0}, {1, 0}, {2, 0}, {3, 0}};      // (semantic, instance) logit blocks of the generated kernels
+        for (int k = 0; k < 6 && e == hipSuccess; ++k) {
             // names as csrc/asm/gen_mlp_tt.py::variant_name spells them: k_mlp_tt_[f][d1][sm]_s<n>i<m>
             for (int v = 0; v < (geo[k][0] ? 8 : 1) && e == hipSuccess; ++v) {
                 char tag[16], nm[64];
@@ -90,7 +90,7 @@ void pnr_mlp_tt_prepare_quiet(void)
 
 int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, int head_tap, bool softmax, hipStream_t stream, bool trace, int trace_abl)
 {
-    PNR_REQUIRE(nbs >= 0 && nbs <= 2 && nbi >= 0 && nbi <= (nbs ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
+    PNR_REQUIRE(nbs >= 0 && nbs <= 3 && nbi >= 0 && nbi <= (nbs == 1 || nbs == 2 ? 1 : 0), "pnr_mlp_forward_composite: no two-tile kernel for %d + %d logit blocks", nbs, nbi);
     PNR_REQUIRE(a.S >= 1 && a.S < (1 << 28), "pnr_mlp_forward_composite: the two-tile kernel takes R*N < 2^28 samples per launch (got %d): "
                 "render in chunks", a.S);
     DevTable* t = nullptr;

@@ -699,6 +699,53 @@ def test_two_tile_kernels_for_single_linear_heads(dev, R, N, heads, tap):
     assert float((bs["semantic"].sum(-1) - bs["acc"]).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("tap", ["trunk", "feature"])
+@pytest.mark.parametrize("depth", [2, 1])
+@pytest.mark.parametrize("C", [96, 70])
+@pytest.mark.parametrize("R,N", [(300, 192), (1001, 64), (7, 32)])
+def test_two_tile_kernels_for_a_third_semantic_block(dev, R, N, C, depth, tap):
+    """65..96 semantic classes without an instance head (round-5 verdict item 3: `k_mlp_tt_*_s3i0`, plan 2): three logit blocks
+    per tile in six accumulators, the local weights in the remaining two.  The ping-pong kernel has no merged logit chunk for three
+    blocks (no plan 1), so the reference is its fused pass on the classic image (plan 0; per-block butterflies against transposed
+    FMA chains: records to fp32 rounding, Q and the quadruples bit for bit) and the two-kernel path -- which is also the softmax
+    reference (`k_mlp_tt_*sm_s3i0`); padded channels (70 = 2 blocks + 6) must not leak into the softmax denominator."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    torch.manual_seed(R + N + C + depth)
+    net = make_network(NS(N_importance=128, num_classes=C, num_instances=0, head_depth=depth, head_tap=tap)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d0, i0 = net.packed(1, dev, "bf16", fused=0)
+    d2, i2 = net.packed(1, dev, "bf16", fused=2)
+    assert d0.plan == 0 and d2.plan == 2 and net.packed(1, dev, "bf16", fused=True)[0].plan == 2
+    rec0, ps0 = _tiles_workspace(d0, i0, rays, z)
+    for rep in range(2):
+        rec2, ps2 = _tiles_workspace(d2, i2, rays, z)
+        assert torch.equal(ps0.view(torch.int32), ps2.view(torch.int32)), rep
+        assert torch.equal(rec0[:, 0].view(torch.int32), rec2[:, 0].view(torch.int32)), rep          # Q
+        scale = float(rec0[:, 1:1 + C].abs().max()) + 1e-6
+        assert float((rec0[:, 1:1 + C] - rec2[:, 1:1 + C]).abs().max()) <= 64e-6 * scale, rep
+    a = ops.mlp_forward_composite(d0, i0, rays, z, None, None, False, True)
+    b = ops.mlp_forward_composite(d2, i2, rays, z, None, None, False, True)
+    dd, ii = net.packed(1, dev, "bf16")
+    raw = ops.mlp_forward(dd, ii, rays, z, channel_major=True)
+    c = ops.composite(raw, z, rays, C, 0, True, None, None, None, 0, False, True)
+    for k in a:
+        sc = max(1.0, float(a[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
+        assert float((c[k] - b[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), k
+    ds, is_ = net.packed(1, dev, "bf16", fused="softmax")
+    assert ds.plan == 2 and ops.fused_supported(ds, N, 1)
+    cs = ops.composite(raw, z, rays, C, 0, True, None, None, None, 1, False, True)
+    for rep in range(2):
+        bs = ops.mlp_forward_composite(ds, is_, rays, z, None, None, False, True, sem_mode=1)
+        for k in cs:
+            sc = max(1.0, float(cs[k].abs().max()))
+            assert float((cs[k] - bs[k]).abs().max()) <= 4e-6 * sc * max(1, N // 32), (k, rep)
+    assert float((bs["semantic"].sum(-1) - bs["acc"]).abs().max()) < 1e-4
+
+
 def test_two_tile_kernel_is_the_default_where_it_exists_and_can_be_capped(dev, monkeypatch):
     """The renderer's fused inference pass packs the BEST plan the geometry has (pnr_mlp_fused_plan: 2 = k_mlp_tt for the benched
     network); PNR_FUSED_PLAN=1 (A/B runs) caps it at the ping-pong kernel's plan.  Same frame either way, bit for bit."""

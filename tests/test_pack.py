@@ -70,12 +70,13 @@ def test_two_tile_plan_image_matches_the_assembly_generator():
     spec.loader.exec_module(G)
     for C, K, depth, tap in ((45, 32, 2, "trunk"), (19, 8, 2, "trunk"), (45, 0, 2, "trunk"), (19, 0, 2, "trunk"), (0, 0, 2, "trunk"),
                              (45, 32, 1, "trunk"), (19, 8, 1, "trunk"), (64, 0, 1, "trunk"), (19, 0, 1, "trunk"),
-                             (45, 32, 2, "feature"), (19, 0, 2, "feature"), (45, 32, 1, "feature"), (64, 0, 1, "feature")):
+                             (45, 32, 2, "feature"), (19, 0, 2, "feature"), (45, 32, 1, "feature"), (64, 0, 1, "feature"),
+                             (96, 0, 2, "trunk"), (70, 0, 1, "trunk"), (96, 0, 2, "feature"), (65, 0, 1, "feature")):     # a third semantic block
         net = make_network(NS(num_classes=C, num_instances=K, head_depth=depth, head_tap=tap))
         desc = net.nerf_0.desc("bf16")
         assert (desc.head_depth == 1) == (depth == 1)
         # head_depth 1 (round 6): the two-tile kernels k_mlp_tt_d1_*; it has no plan 1 (the ping-pong kernel's merged logit chunk)
-        assert ops.fused_plan(desc, None) == 2 and ops.fused_plan(desc, 1) == (1 if (C and depth == 2) else 0)
+        assert ops.fused_plan(desc, None) == 2 and ops.fused_plan(desc, 1) == (1 if (0 < C <= 64 and depth == 2) else 0)
         desc.plan = 2
         img = ops.pack_mlp(desc, net.nerf_0.state_dict())
         im = PackedImage(img)
@@ -89,3 +90,4 @@ def test_two_tile_plan_image_matches_the_assembly_generator():
     assert ops.fused_plan(ops.make_desc(n_sem=0, n_inst=32), None) == 0
     assert ops.fused_plan(ops.make_desc(D=4, skip=1, n_sem=45, n_inst=32), None) == 1
     assert ops.fused_plan(ops.make_desc(n_sem=100, n_inst=32), None) == 0
+    assert ops.fused_plan(ops.make_desc(n_sem=96, n_inst=32), None) == 0 and ops.fused_plan(ops.make_desc(n_sem=97, n_inst=0), None) == 0
