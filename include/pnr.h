@@ -162,7 +162,7 @@ int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, const float* r
  *   1: the fused-inference plan (bf16, W = 256, 1..2 semantic and 0..1 instance logit blocks of 32): the appearance branch, then
  *      BOTH head hidden layers, then the two logit layers as ONE chunk (k_mlp_pp: 8 waves, one 32-sample tile per wave);
  *   2: the two-tile plan (the 8 x 256 network of the BASELINE configs: D = 8, skip = 4, L = 10 / 4, head_tap 0; no heads, a
- *      semantic head of up to 64 classes, or that plus an instance head of up to 32; any head_tap / head_depth): no chunk above 33 fragments, consumed by
+ *      semantic head of up to 64 classes, that plus an instance head of up to 32, or a semantic head of 65..96 classes alone; any head_tap / head_depth): no chunk above 33 fragments, consumed by
  *      k_mlp_tt -- hand-placed gfx950 assembly, one wave per SIMD, two tiles per wave, every LDS weight fragment feeds two MFMAs
  *      (csrc/asm/gen_mlp_tt.py);
  *   0: the classic order, which every entry point accepts.

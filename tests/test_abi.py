@@ -174,6 +174,10 @@ def test_fused_pass_eligibility_and_workspace_arithmetic():
     assert ops.fused_supported(dd1, 192) and ops.fused_supported(dd1, 192, sem_mode=1)
     dt1 = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16", "feature", 1)          # head_tap feature + one Linear: k_mlp_tt_fd1[sm]_*
     assert lib.pnr_mlp_fused_plan(ctypes.byref(dt1)) == 2 and lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(dt1, 1))) == 2
+    d96 = ops.make_desc(8, 256, 4, 10, 4, 96, 0, 128, "bf16", "trunk", 2)              # a third semantic block, no instance head: k_mlp_tt_*_s3i0
+    assert lib.pnr_mlp_fused_plan(ctypes.byref(d96)) == 2 and lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(d96, 1))) == 2
+    d96i = ops.make_desc(8, 256, 4, 10, 4, 96, 32, 128, "bf16", "trunk", 2)            # ... beside an instance head: 8 + 2 accumulators
+    assert lib.pnr_mlp_fused_plan(ctypes.byref(d96i)) == 0 and lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(d96i, 1))) == 0
     dbig = ops.make_desc(8, 256, 4, 10, 4, 100, 0, 128, "bf16", "trunk", 1)            # four semantic blocks: no fused softmax at all
     assert lib.pnr_mlp_fused_plan(ctypes.byref(ops.desc_for_mode(dbig, 1))) == 0 and not ops.fused_supported(dbig, 192, sem_mode=1)
     d4 = ops.make_desc(4, 256, 1, 10, 4, 45, 32, 128, "bf16")            # another depth: no two-tile kernel, plan 1 has softmax

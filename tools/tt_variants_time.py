@@ -1,20 +1,23 @@
 """The fused fine-level launch (65,536 rays x 192 samples, 45 + 32 heads) under every position of SURVEY.md 9 items 4 and 5 -- head_tap x
 head_depth x semantic_activation -- as the two-tile assembly kernel (plan 2) and as the ping-pong kernel on the best image it has
-(plan 1, or the classic image where plan 1 does not exist), same box, one process.  usage: python tools/tt_variants_time.py"""
+(plan 1, or the classic image where plan 1 does not exist), same box, one process.
+usage: python tools/tt_variants_time.py [n_sem n_inst]      (default 45 32; 96 0 = the three-block semantic head)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from types import SimpleNamespace as NS
 from panopticnerf_amd import benchlib, make_network, ops, synthetic
 
+C, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (45, 32)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 rays = synthetic.camera_rays()[:65536].to(dev)
 z = ops.stratified(rays, 192)
+print("heads: %d semantic + %d instance logits" % (C, K))
 print("%-8s %-6s %-8s  %-22s %-22s" % ("head_tap", "depth", "compos.", "k_mlp_tt (plan 2)", "k_mlp_pp (its best plan)"))
 for tap in ("trunk", "feature"):
     for depth in (2, 1):
-        net = make_network(NS(N_importance=128, num_classes=45, num_instances=32, head_depth=depth, head_tap=tap)).eval()
+        net = make_network(NS(N_importance=128, num_classes=C, num_instances=K, head_depth=depth, head_tap=tap)).eval()
         synthetic.trained_like_(net)
         net = net.to(dev)
         for sem_mode in (0, 1):
