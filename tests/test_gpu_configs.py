@@ -216,6 +216,31 @@ ODD = {
 }
 
 
+def test_full_frame_in_one_launch_equals_the_chunked_frame(dev):
+    """BASELINE config 5's frame in 8 chunks (the default), in 2, and in ONE (529,408 rays x 192 samples = 101.6 M samples in a single
+    fused launch -- the largest launch a frame can ask for: 32-bit sample indices, 397 K groups over 256 workgroups, the two-tile
+    kernel's 67 MB per-ray table): rays are independent, so every output map must be the same bits whatever the chunking."""
+    ref = None
+    for chunk in (65536, 300000, 600000):
+        cfg = synthetic.baseline_cfg(5, precision="bf16", chunk_size=chunk)
+        torch.manual_seed(0)
+        net = make_network(cfg).eval()
+        synthetic.trained_like_(net)
+        net = net.to(dev)
+        rays = synthetic.camera_rays().to(dev)
+        box, ids = (t.to(dev) for t in synthetic.random_boxes(64, cfg.num_classes, cfg.num_instances))
+        with torch.no_grad():
+            out = make_renderer(cfg, net).render({"rays": rays[None], "bbox": box, "bbox_ids": ids})
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = {k: v.cpu() for k, v in out.items()}
+            continue
+        for k in ref:
+            assert torch.equal(ref[k], out[k].cpu()), (chunk, k)
+        del out
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", list(ODD))
 def test_render_odd_geometries_against_the_oracle(dev, name, prec):
