@@ -36,6 +36,13 @@ DMA_POLICY = os.environ.get("PNR_TT_DMA_POLICY", "")
 STORE_NT = ""           # cache policy of the record / quadruple stores (" nt": measured +-0, round 5)
 PIECE_FRAC = 1.0        # the pieces of a chunk go out in this first fraction of its gaps (0.5: measured slower)
 WAIT2 = os.environ.get("PNR_TT_WAIT2", "0") != "0"             # (A/B builds) one s_waitcnt lgkmcnt per two fragments instead of one per fragment
+# (A/B builds, tools/build_tt_variant.sh) the TRAINING-FORWARD PROTOTYPE: every packed activation block (trunk, feature, views, head hidden layers:
+# 5.4 KB per sample, what k_mlp_fused<TRAIN> saves for the backward pass) is also stored to a scratch region -- 1 KiB per store, fully
+# coalesced, layout arbitrary: the kernel's results stay valid, the stores are what is being timed (profiles/r06/r06p).  The library must be
+# told too: PNR_TT_SAVE_PROTO=1 in the environment makes the launcher allocate and pass the region.
+SAVE_PROTO = os.environ.get("PNR_TT_SAVE", "0") != "0"
+ABL_ALL = int(os.environ.get("PNR_TT_ABL", "0"))        # (A/B builds; results INVALID) the timing-only ablations in every kernel: 1 = no weight pieces
+SAVE_REGION = 352 * 1024                # bytes per wave and group: 2 tiles x 32 samples x 5.5 KiB
 SHARE_BIAS = os.environ.get("PNR_TT_SHARE_BIAS", "1") != "0"     # one armed accumulator per block: tile 1's first MFMA reads tile 0's (A/B builds)
 NSLOT, SLOT = 4, int(os.environ.get("PNR_TT_SLOT_KIB", "33")) * 1024      # (A/B builds: the slot stride, tools/build_tt_variant.sh)
 ACC_PERM = [int(x) for x in os.environ.get("PNR_TT_ACC_PERM", "0,1,2,3,4,5,6,7").split(",")]     # register block of accumulator i (A/B builds)
@@ -74,6 +81,8 @@ S_SAVE, S_REC_T = 58, 60                # saved exec; the two tiles' record poin
 S_MSK = 64                              # store masks of the (up to) three logit blocks: s[64:69] = lanes with hi == 0 and channel < n_out
 S_REC_I = 70                            # the two tiles' record pointers + 4 n_sem (the instance columns): s[70:73]
 S_AUX = 82                              # s[82:83]: the per-ray table k_ray_aux wrote (gamma(d) of both half-waves and |d|: 128 B per ray)
+S_SV, S_SVBASE, S_SVT = 84, 88, 86      # save prototype: running store address s[84:85], the region's base s[88:89], a temporary
+V_SV = 15                               # save prototype: lane * 16 (V_TRACE's register: the trace builds have no save prototype)
 S_VMSK = 76                             # softmax kernels: s[76:77] / s[78:79] = ALL lanes whose channel of the semantic / instance head's last block exists
 S_LWW, S_LWR = 74, 75                   # LDS addresses of this wave's local-weight table: + 4 (lane & 31) to write, + (V_BIAS[0] = slot 0 + 16 hi) to read
 LW_BASE = NSLOT * SLOT                  # [4 waves][2 tiles][32 floats] behind the weight slots (1 KiB)
@@ -152,7 +161,7 @@ class Gen:
         # the tail normalises each head's transposed logit blocks per sample before the weighted sums (tail_softmax), operation for
         # operation fuse_softmax_t of the ping-pong kernel (pnr_mlp_fuse.h): k_mlp_tt_sm_s<n>i<m>
         self.softmax = softmax
-        self.nbs, self.nbi, self.name, self.trace, self.abl = nbs, nbi, name, trace, abl
+        self.nbs, self.nbi, self.name, self.trace, self.abl = nbs, nbi, name, trace, abl or ABL_ALL
         self.nstamp = 0
         self.o = []
         self.nlabel = 0
@@ -1032,6 +1041,8 @@ class Gen:
             self.drain_side(1 if l["name"].startswith("L") or l["name"] in ("feature", "views") else 3 if late else 2)
         for g in sorted(must_at):                       # (positions beyond the last gap: none by construction)
             assert g < nm, (g, nm)
+        if SAVE_PROTO and packs:
+            self.queue_saves([dst for dst, _, _ in packs])
         # ---- this unit's own results: packed during the next unit, or reduced by the side queue
         if l["mode"] in ("relu", "linear"):
             self.pending_pack = dict(ops=self.pack_ops(u), accs=list(u["accs"].values()))
@@ -1360,8 +1371,40 @@ class Gen:
             e("s_mov_b64 s[%d:%d], s[%d:%d]" % (S_VALID + 2 * t, S_VALID + 2 * t + 1, S_NVALID + 2 * t, S_NVALID + 2 * t + 1))
             e("s_mov_b64 s[%d:%d], s[%d:%d]" % (S_LAST + 2 * t, S_LAST + 2 * t + 1, S_NLAST + 2 * t, S_NLAST + 2 * t + 1))
 
+    def save_base(self):
+        """s[S_SV : S_SV + 1] = region base + (4 group + wave) * SAVE_REGION"""
+        e = self.e
+        e("s_lshl_b32 s%d, s%d, 2" % (S_SVT, S_GRP))
+        e("s_add_u32 s%d, s%d, s%d" % (S_SVT, S_SVT, S_WAVE))
+        self.lit(S_K, SAVE_REGION)
+        e("s_mul_hi_u32 s%d, s%d, s%d" % (S_SV + 1, S_SVT, S_K))
+        e("s_mul_i32 s%d, s%d, s%d" % (S_SV, S_SVT, S_K))
+        e("s_add_u32 s%d, s%d, s%d" % (S_SV, S_SV, S_SVBASE))
+        e("s_addc_u32 s%d, s%d, s%d" % (S_SV + 1, S_SV + 1, S_SVBASE + 1))
+        self.save_n = 0
+
+    def queue_saves(self, regs):
+        """side work: 16-byte-per-lane stores of the packed registers `regs` [(kind, index)] -- quads of consecutive registers"""
+        regs = sorted(regs)
+        assert len(regs) % 4 == 0
+        for i in range(0, len(regs), 4):
+            k, r = regs[i]
+            assert [x for x in regs[i:i + 4]] == [(k, r + j) for j in range(4)], regs[i:i + 4]
+
+            def fn(k=k, r=r):
+                self.vm_op("global_store_dwordx4 v%d, %s, s[%d:%d] offset:%d" % (V_SV, (ar if k == "a" else vr)(r, 4), S_SV, S_SV + 1,
+                                                                                   1024 * (self.save_n % 4)))
+                self.save_n += 1
+                if self.save_n % 4 == 0:
+                    with self.atomic():         # (the carry: no other scalar instruction between the two)
+                        self.e("s_add_u32 s%d, s%d, 0x1000" % (S_SV, S_SV))
+                        self.e("s_addc_u32 s%d, s%d, 0" % (S_SV + 1, S_SV + 1))
+            self.q(1, fn)
+
     def group_body(self):
         self.m0 = None
+        if SAVE_PROTO:
+            self.save_base()
         assert self.acc_free == [i for i in range(8) if i not in self.units[0]["accs"].values()], self.acc_free
         self.last_stamp = None
         for ui in range(len(self.units)):
@@ -1384,7 +1427,7 @@ class Gen:
         e, name = self.e, self.name
         self.o += ["\t.text", "\t.globl\t%s" % name, "\t.p2align\t8", "\t.type\t%s,@function" % name, "%s:" % name]
         for dst, off, n in ((S_IMG, 0x0, 2), (S_RAYS, 0x8, 2), (S_Z, 0x10, 2), (S_S, 0x18, 2), (S_MAGIC, 0x20, 2), (S_NGRP, 0x28, 2),
-                            (S_REC, 0x30, 2), (S_RECF, 0x38, 1), (S_PS, 0x40, 2), (S_NSEM, 0x48, 2), (S_CLK, 0x50, 2), (S_AUX, 0x58, 2)):
+                            (S_REC, 0x30, 2), (S_RECF, 0x38, 1), (S_PS, 0x40, 2), (S_NSEM, 0x48, 2), (S_CLK, 0x50, 2), (S_AUX, 0x58, 2)) + (((S_SVBASE, 0x60, 2),) if SAVE_PROTO else ()):
             e("s_load_dword%s %s, s[0:1], 0x%x" % ("x2" if n == 2 else "", sr(dst, n), off))
         # wave id from v0 itself (never written): a v_readfirstlane of a register that is re-used a few instructions later was
         # observed to return the LATER value while scalar-load data was returning (tools/probe/gen_two_tile_asm.py)
@@ -1407,6 +1450,10 @@ class Gen:
                 e("v_add_u32 v%d, 0x%x, v%d" % (V_DMA + k, 16384 * k, V_DMA + k))
         e("v_and_b32 v%d, 31, v0" % V_LB4)
         e("v_lshlrev_b32 v%d, 2, v%d" % (V_LB4, V_LB4))
+        if SAVE_PROTO:
+            assert not self.trace
+            e("v_and_b32 v%d, 63, v0" % V_SV)
+            e("v_lshlrev_b32 v%d, 4, v%d" % (V_SV, V_SV))
         e("s_mov_b32 s%d, -1" % S_LO32)
         e("s_mov_b32 s%d, 0" % (S_LO32 + 1))
         e("s_mov_b32 s%d, 1" % S_N0)
@@ -1539,7 +1586,7 @@ class Gen:
         return "\n".join(self.o)
 
 
-KERNARG_BYTES = 96
+KERNARG_BYTES = 104
 
 
 def metadata(names):

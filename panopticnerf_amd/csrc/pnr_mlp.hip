@@ -954,6 +954,10 @@ PNR_EXPORT int pnr_mlp_forward(const pnr_mlp_desc* desc, const void* packed, con
 }
 
 #define PNR_RAY_AUX_BYTES 128
+// A/B builds only (tools/build_tt_variant.sh save PNR_TT_SAVE=1, run with PNR_TT_SAVE_PROTO=1): the training-forward prototype of the
+// two-tile kernel stores every packed activation block to a scratch region behind the per-ray table (profiles/r06/r06p)
+#define PNR_TT_SAVE_REGION (352 * 1024)
+static bool pnr_tt_save_proto() { static const bool on = getenv("PNR_TT_SAVE_PROTO") != nullptr; return on; }
 int pnr_composite_combine_launch(const float* rec, int rec_floats, const float4* ps, const float* z, const int32_t* label_sem,
                                  const int32_t* label_inst, int64_t R, int N, int C, int K, int white_bkgd, float* rgb, float* depth,
                                  float* acc, float* weights, float* sem, float* inst, float* fix_sem, float* fix_inst, hipStream_t st);
@@ -965,7 +969,8 @@ PNR_EXPORT int64_t pnr_mlp_forward_composite_workspace_bytes(const pnr_mlp_desc*
     (void)want_weights;
     if (pnr_mlp_validate(desc) != PNR_OK || n_rays < 0 || n_samples < 32 || (n_samples & 31)) return -1;
     const int64_t S = n_rays * n_samples, tiles = (S + 255) / 256 * 8;
-    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + S * 16 + 256 + PNR_RAY_AUX_BYTES + n_rays * PNR_RAY_AUX_BYTES;
+    return tiles * pnr_fuse_record_floats(desc->n_sem, desc->n_inst) * 4 + S * 16 + 256 + PNR_RAY_AUX_BYTES + n_rays * PNR_RAY_AUX_BYTES +
+           (pnr_tt_save_proto() ? tiles / 8 * 4 * PNR_TT_SAVE_REGION + 4096 : 0);
 }
 
 // What the two-tile kernel needs of a RAY rather than of a sample: |d| and gamma(d / |d|), in the registers embed_lane hands a lane
@@ -1035,6 +1040,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
                                     & ~(uintptr_t)(PNR_RAY_AUX_BYTES - 1));
         k_ray_aux<<<dim3((unsigned)((2 * n_rays + 255) / 256)), dim3(256), 0, st>>>(rays, n_rays, aux);
         t.aux = aux;
+        if (pnr_tt_save_proto()) t.save = (void*)(((uintptr_t)((uint8_t*)aux + n_rays * PNR_RAY_AUX_BYTES) + 4095) & ~(uintptr_t)4095);
         const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + (a << 4), a in 1..7: the timing-only ablation a
         return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, a.head_depth, a.head_tap, softmax, st, trace,
                                  trace ? ((desc->flags >> 4) & 7) : 0);

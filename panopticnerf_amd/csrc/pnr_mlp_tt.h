@@ -17,8 +17,9 @@ struct PnrTTArgs {
     int32_t n_sem, n_inst;      // 72
     unsigned long long* clk;    // 80  optional {shader cycles, 100 MHz ticks} of workgroup 0's first wave
     const void* aux;            // 88  per-ray table of k_ray_aux (pnr_mlp.hip): [ray][half-wave]{8 packed gamma(d) registers, |d|, 7 pad}
+    void* save;                 // 96  null; A/B builds of the training-forward prototype (PNR_TT_SAVE=1 kernels): 352 KiB per (group, wave)
 };
-static_assert(sizeof(PnrTTArgs) == 96, "k_mlp_tt reads its arguments at fixed offsets");
+static_assert(sizeof(PnrTTArgs) == 104, "k_mlp_tt reads its arguments at fixed offsets");
 
 // trace: the debug build of the kernel (EXTRA_TT=trace | abl builds only): 64 per-unit s_memtime stamps of workgroup 0's first wave
 // to clk[0..63] and every workgroup's cycles to clk[64 + workgroup], 4 bytes each -- `clk` must hold (64 + n_wg) * 4 bytes
