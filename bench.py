@@ -38,6 +38,10 @@ import os
 import sys
 import time
 
+# the host driver of the GPU boxes only supports dmabuf IPC: without this, RCCL's (and torch's) cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument`.  Exported on the boxes already; set here too so that a bare `torchrun bench.py` works
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
