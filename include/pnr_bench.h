@@ -43,6 +43,12 @@ int pnrb_probe_mfma_order(int pattern, int iters, void* scratch, float* tflops_o
 int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int iters,
                         void* scratch, float* gbs_out_host, void* stream);
 
+/* The same for any candidate mapping of a ray onto lanes: lanes_per_ray (8 | 16 | 32 | 64) x n_samples / lanes_per_ray consecutive
+ * samples per lane, 64 / lanes_per_ray rays per wave, rows_in_flight (4 | 8 | 16) channel rows requested at once, a grid of
+ * waves_per_simd x 4 waves per CU at most (tools/composite_patterns.py: the table of profiles/r06/r06q). */
+int pnrb_probe_raw_read_pattern(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels, int lanes_per_ray,
+                                int rows_in_flight, int waves_per_simd, int iters, void* scratch, float* gbs_out_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

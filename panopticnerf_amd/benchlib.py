@@ -20,6 +20,7 @@ SIGNATURES = {
     "pnrb_probe_mfma_peak": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_mfma_order": (c_int, [c_int, c_int, c_f, _fp, _fp, c_f]),
     "pnrb_probe_raw_read": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_f, _fp, c_f]),
+    "pnrb_probe_raw_read_pattern": (c_int, [c_f, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_f, _fp, c_f]),
 }
 _blib = None
 
@@ -107,6 +108,17 @@ def probe_mfma_peak(random_operands, iters=20000, device=None):
         _check(load().pnrb_probe_mfma_peak(int(bool(random_operands)), int(iters), _p(scratch), ctypes.byref(tf), ctypes.byref(mhz),
                                            _stream()), "pnrb_probe_mfma_peak")
     return float(tf.value), float(mhz.value)
+
+
+def probe_raw_read_pattern(raw, n_rays, n_samples, lanes_per_ray, rows_in_flight=8, waves_per_simd=8, iters=5):
+    """GB/s of a pure read of the channel-major raw image with `lanes_per_ray` lanes x n_samples / lanes_per_ray samples per ray."""
+    gbs = ctypes.c_float(0.0)
+    with torch.cuda.device(raw.device):
+        scratch = torch.zeros(256, device=raw.device, dtype=torch.float32)
+        _check(load().pnrb_probe_raw_read_pattern(_p(raw), ops._chk_raw(raw, raw.shape[0], n_rays * n_samples), int(n_rays), int(n_samples),
+                                                  int(raw.shape[0]), int(lanes_per_ray), int(rows_in_flight), int(waves_per_simd), int(iters),
+                                                  _p(scratch), ctypes.byref(gbs), _stream()), "pnrb_probe_raw_read_pattern")
+    return float(gbs.value)
 
 
 def probe_raw_read(raw, n_rays, n_samples, iters=5):

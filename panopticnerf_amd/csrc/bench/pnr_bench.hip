@@ -337,6 +337,70 @@ __global__ __launch_bounds__(256) void k_raw_read2(const float* raw, int64_t sc,
     if (acc == 12345.678f) sink[threadIdx.x] = acc;
 }
 
+// The candidate mappings of a ray's samples onto lanes (round-5 verdict item 6: "change the layout, not the kernel" for the N = 64
+// level): L lanes per ray x N / L consecutive samples per lane (N / L / 4 float4 loads per lane and channel row), 64 / L rays per wave,
+// J channel rows in flight.  Rays are consecutive in a channel row, so a wave-load covers 64 / L rays x N x 4 B contiguous bytes.
+// L = 8: k_composite2's mapping at N = 64; L = 16: four samples per lane (k_composite's mapping) with four rays per wave.
+template <int L, int J>
+__global__ __launch_bounds__(256) void k_raw_read_pattern(const float* raw, int64_t sc, int64_t R, int N, int CH, float* sink)
+{
+    constexpr int RPW = 64 / L;
+    const int lane = threadIdx.x & 63, q = lane % L, g = lane / L;
+    const int per = N / L;                  // samples per lane: a multiple of 4
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float acc = 0.0f;
+    for (int64_t grp = wave; grp < (R + RPW - 1) / RPW; grp += n_waves) {
+        const int64_t ray = grp * RPW + g;
+        const bool in_ray = ray < R;
+        const float* p = raw + (in_ray ? ray : R - 1) * N + q * per;
+        for (int c0 = 0; c0 < CH; c0 += J) {
+            for (int k = 0; k < per; k += 4) {
+                float4 v[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    v[j] = (in_ray && c0 + j < CH) ? *reinterpret_cast<const float4*>(p + (int64_t)(c0 + j) * sc + k) : make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[threadIdx.x] = acc;
+}
+
+PNR_EXPORT int pnrb_probe_raw_read_pattern(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels,
+                                          int lanes_per_ray, int rows_in_flight, int waves_per_simd, int iters, void* scratch,
+                                          float* gbs_out_host, void* stream)
+{
+    PNR_REQUIRE(raw && scratch && gbs_out_host && iters >= 1 && n_rays >= 1, "pnrb_probe_raw_read_pattern: bad arguments");
+    PNR_REQUIRE((lanes_per_ray == 8 || lanes_per_ray == 16 || lanes_per_ray == 32 || lanes_per_ray == 64) &&
+                (rows_in_flight == 4 || rows_in_flight == 8 || rows_in_flight == 16) && n_samples % (4 * lanes_per_ray) == 0 &&
+                (raw_stride_c % 4) == 0 && waves_per_simd >= 1 && waves_per_simd <= 8, "pnrb_probe_raw_read_pattern: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    PNR_HIP(hipEventCreate(&e0));
+    PNR_HIP(hipEventCreate(&e1));
+    const int rpw = 64 / lanes_per_ray;
+    const int grid = pnr_grid_cap((n_rays + 4 * rpw - 1) / (4 * rpw), waves_per_simd);
+    void (*kern)(const float*, int64_t, int64_t, int, int, float*) = nullptr;
+#define PNRB_PAT(LL, JJ) if (lanes_per_ray == LL && rows_in_flight == JJ) kern = k_raw_read_pattern<LL, JJ>;
+    PNRB_PAT(8, 4) PNRB_PAT(8, 8) PNRB_PAT(8, 16) PNRB_PAT(16, 4) PNRB_PAT(16, 8) PNRB_PAT(16, 16)
+    PNRB_PAT(32, 4) PNRB_PAT(32, 8) PNRB_PAT(32, 16) PNRB_PAT(64, 4) PNRB_PAT(64, 8) PNRB_PAT(64, 16)
+#undef PNRB_PAT
+    for (int i = 0; i <= iters; ++i) {
+        if (i == 1) PNR_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, raw, raw_stride_c, n_rays, n_samples, n_channels, (float*)scratch);
+    }
+    PNR_CHECK_LAUNCH("pnrb_probe_raw_read_pattern");
+    PNR_HIP(hipEventRecord(e1, st));
+    PNR_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PNR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gbs_out_host = (float)((double)n_rays * n_samples * 4.0 * n_channels * iters / (ms * 1e-3) / 1e9);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PNR_OK;
+}
+
 PNR_EXPORT int pnrb_probe_raw_read(const float* raw, int64_t raw_stride_c, int64_t n_rays, int n_samples, int n_channels,
                                   int iters, void* scratch, float* gbs_out_host, void* stream)
 {
