@@ -763,10 +763,18 @@ def main():
                 extra["roofline_composite_coarse"] = comp_roofline(N_C, True, "coarse level, weights written")
 
     if rank == 0 and not fake and not args.no_roofline:
+        # on the SERIAL frame (every launch on one stream, cfg.overlap_levels = False): per-launch event differences only add up there;
+        # the timed frames run the fine level of a chunk beside the coarse level of the next (Renderer._render_overlapped)
+        overlapped = bool(getattr(rend, "overlap_levels", False))
         try:
+            rend.overlap_levels = False
             extra["frame_accounting"] = frame_accounting(frame_weak, N_C if N_F else -1)
+            extra["frame_accounting"]["serial_frame"] = ("cfg.overlap_levels = False for this one frame; the timed frames overlap the levels of "
+                                                         "neighbouring chunks" if overlapped else "the timed frames are serial too")
         except Exception as e:      # noqa: BLE001
             extra["frame_accounting"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            rend.overlap_levels = overlapped
 
     # secondary measurement (never the headline value): one training step on a ray batch per rank --
     # render with autograd, the loss wrapper (RGB / depth / 2D CE on learned and fixed fields / 3D CE; fused HIP),
@@ -915,7 +923,9 @@ def main():
                            "small_print": "timed frames: rays are pre-generated and resident (pnr_gen_rays, SURVEY 8f-2, is outside the frame); the "
                                           "fine level's per-sample weights are not written (keep_weights false: nothing downstream reads them, ~0.4 GB "
                                           "per frame); inference is deterministic (perturb = 0, no sigma noise) -- in TRAINING the renderer draws "
-                                          "perturb / raw_noise_std uniforms with torch.rand / torch.randn (renderer.py), there is no in-kernel RNG",
+                                          "perturb / raw_noise_std uniforms with torch.rand / torch.randn (renderer.py), there is no in-kernel RNG; a frame's chunks "
+                                          "alternate between two streams so that the fine level of chunk c (3/4 of the compute units) runs beside the coarse "
+                                          "level of chunk c + 1 (1/4) -- same kernels, same bits (cfg.overlap_levels, PNR_OVERLAP=0 switches it off)",
                            "semantic_activation": args.semantic_activation, "parallelism": par},
                 "scaling_modes": modes, "rccl": rccl,
                 "roofline": roofline, "cpu_baseline": cpu_baseline}

@@ -97,6 +97,9 @@ typedef struct pnr_mlp_desc {
                                   registers together: plan 2 (the k_mlp_tt_*sm_* kernels, round 6) or plan 1; ask
                                   pnr_mlp_fused_plan WITH this flag set in desc.flags (0 = none: use pnr_mlp_forward + pnr_composite);
                                   PNR_EINVAL otherwise */
+#define PNR_MLP_WG_CAP(n) (((n) & 0x1FF) << 16)  /* plan 2 (pnr_mlp_forward_composite / _tiles): launch on at most n workgroups (= compute units;
+                                  0 = all of them).  Two launches with caps that add up to the device can run SIDE BY SIDE on two streams --
+                                  one level of a chunk beside the other level of the next: Renderer's cfg.overlap_levels.  Same results. */
 #define PNR_MLP_TRACE 0x7A00   /* diagnostics BUILDS of the library only (make EXTRA_TT=trace | abl; the shipped library refuses the
                                   flag), with plan 2: the trace build of k_mlp_tt -- clk_probe must then address (64 + workgroups) * 4
                                   bytes (workgroups <= number of CUs; tools/tt_trace.py allocates 1280): 64 per-unit s_memtime stamps

@@ -1040,6 +1040,7 @@ static int fused_mlp_launch(const pnr_mlp_desc* desc, const void* packed, const 
                                     & ~(uintptr_t)(PNR_RAY_AUX_BYTES - 1));
         k_ray_aux<<<dim3((unsigned)((2 * n_rays + 255) / 256)), dim3(256), 0, st>>>(rays, n_rays, aux);
         t.aux = aux;
+        t.n_wg = (desc->flags >> 16) & 0x1FF;
         if (pnr_tt_save_proto()) t.save = (void*)(((uintptr_t)((uint8_t*)aux + n_rays * PNR_RAY_AUX_BYTES) + 4095) & ~(uintptr_t)4095);
         const bool trace = (desc->flags & 0xFF00) == PNR_MLP_TRACE;     // + (a << 4), a in 1..7: the timing-only ablation a
         return pnr_mlp_tt_launch(t, (desc->n_sem + 31) / 32, (desc->n_inst + 31) / 32, a.head_depth, a.head_tap, softmax, st, trace,

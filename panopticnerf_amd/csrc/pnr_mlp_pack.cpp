@@ -38,7 +38,7 @@ int pnr_mlp_validate(const pnr_mlp_desc* d)
     // the descriptor must be zero-initialised (include/pnr.h): the diagnostic words are READ -- clk_probe is a device address the
     // forward kernels store 16 bytes to, flags select kernels -- so garbage there is rejected where it can be recognised
     const uint32_t trace = (uint32_t)d->flags & 0xFF00u;
-    PNR_REQUIRE(((uint32_t)d->flags & ~(uint32_t)(PNR_MLP_SOFTMAX | 0xFF70u)) == 0 && (trace == 0 || trace == PNR_MLP_TRACE) &&
+    PNR_REQUIRE(((uint32_t)d->flags & ~(uint32_t)(PNR_MLP_SOFTMAX | 0xFF70u | PNR_MLP_WG_CAP(0x1FF))) == 0 && (trace == 0 || trace == PNR_MLP_TRACE) &&
                 (trace != 0 || ((uint32_t)d->flags & 0x70u) == 0),
                 "pnr_mlp: unknown bits in flags=0x%x (zero-initialise pnr_mlp_desc; PNR_MLP_* are the defined bits)", (unsigned)d->flags);
     PNR_REQUIRE(((uint32_t)d->clk_probe[0] & 15u) == 0, "pnr_mlp: clk_probe=0x%08x%08x is not a 16-byte aligned device address "

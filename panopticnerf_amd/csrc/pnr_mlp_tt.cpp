@@ -110,7 +110,8 @@ int pnr_mlp_tt_launch(const PnrTTArgs& a, int nbs, int nbi, int head_depth, int 
     PnrTTArgs ka = a;
     const int cus = pnr_cu_count();
     ka.n_groups = (a.S + 255) / 256;
-    ka.n_wg = ka.n_groups < cus ? ka.n_groups : cus;
+    const int cap = (a.n_wg > 0 && a.n_wg < cus) ? a.n_wg : cus;       // PNR_MLP_WG_CAP: a share of the device for a launch that runs beside another
+    ka.n_wg = ka.n_groups < cap ? ka.n_groups : cap;
     size_t size = sizeof(ka);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     PNR_HIP(hipModuleLaunchKernel(fn, (unsigned)ka.n_wg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));

@@ -10,7 +10,7 @@ struct PnrTTArgs {
     int32_t S, N;               // 24  samples, samples per ray
     uint32_t n_magic;           // 32  x / N = (x * n_magic) >> n_shift (pnr_set_div_magic)
     int32_t n_shift;            // 36
-    int32_t n_groups, n_wg;     // 40  256-sample groups, workgroups (filled by the launcher)
+    int32_t n_groups, n_wg;     // 40  256-sample groups (filled by the launcher), workgroups (in: a cap, 0 = every compute unit; out: the grid)
     float* rec;                 // 48  per-tile records
     int32_t rec_floats, pad0;   // 56
     void* ps;                   // 64  per-sample (lw, r, g, b)

@@ -471,12 +471,13 @@ def fused_image(sem_mode=0):
 
 @_on_device
 def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None, white_bkgd=False, want_weights=True, out=None,
-                          sem_mode=0):
+                          sem_mode=0, wg_cap=0):
     """Rows a5 + a6 in one pass (inference): the fused MLP reduces every 32-sample tile to one compositing record in its
     epilogue and k_composite_combine finishes the rays -- the raw image (324 B per sample at 45 / 32 heads) is never
     written.  Same dict as composite().  Sums are associated per tile, so results equal mlp_forward + composite to fp32
     rounding (not bit for bit).  sem_mode as in composite(): 1 composites softmax(logits) of each learned field
-    (PNR_MLP_SOFTMAX; an image of a plan with a softmax kernel, see fused_supported / fused_image)."""
+    (PNR_MLP_SOFTMAX; an image of a plan with a softmax kernel, see fused_supported / fused_image).  wg_cap: plan 2 only, the MLP launch
+    on at most that many workgroups (PNR_MLP_WG_CAP) -- a share of the device, for a launch that runs beside another one."""
     rays, z, packed = _chk(rays, "rays"), _chk(z, "z"), _chk(packed, "packed", torch.uint8)
     label_sem = _chk(label_sem, "label_sem", torch.int32)
     label_inst = _chk(label_inst, "label_inst", torch.int32)
@@ -485,6 +486,11 @@ def mlp_forward_composite(desc, packed, rays, z, label_sem=None, label_inst=None
     dev = z.device
     lib = _lib.load()
     desc = desc_for_mode(desc, sem_mode)
+    if wg_cap:          # PNR_MLP_WG_CAP: the plan-2 launch on a share of the compute units (Renderer's overlapped levels)
+        d2 = _lib.MlpDesc()
+        ctypes.memmove(ctypes.byref(d2), ctypes.byref(desc), ctypes.sizeof(d2))
+        d2.flags = (desc.flags & 0xFFFF) | ((int(wg_cap) & 0x1FF) << 16)
+        desc = d2
     nbytes = lib.pnr_mlp_forward_composite_workspace_bytes(ctypes.byref(desc), R, N, int(bool(want_weights)))
     if nbytes < 0:
         raise RuntimeError("pnr_mlp_forward_composite: unsupported geometry (n_samples=%d must be a multiple of 32)" % N)

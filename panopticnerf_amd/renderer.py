@@ -86,15 +86,23 @@ class Renderer:
         # inference frames of several chunks are written into frame-sized maps chunk by chunk (no concatenation at the end);
         # cfg.frame_outputs = False (or PNR_FRAME_OUT=0) restores per-chunk maps + torch.cat
         self.frame_outputs = bool(_get(cfg, "frame_outputs", os.environ.get("PNR_FRAME_OUT", "1") != "0"))
+        # inference frames of several chunks: the fine level of chunk c runs BESIDE the coarse level of chunk c + 1 (two streams, the
+        # two-tile MLP launches capped to 3/4 and 1/4 of the compute units = the levels' 192 : 64 samples), so the small per-ray
+        # kernels of one chunk overlap with those of the other instead of standing between the MLP launches (_render_overlapped);
+        # cfg.overlap_levels = False (or PNR_OVERLAP=0) keeps every launch of a frame on the caller's stream
+        self.overlap_levels = bool(_get(cfg, "overlap_levels", os.environ.get("PNR_OVERLAP", "1") != "0"))
+        self._side_streams = {}
         if self.N_importance > 0 and getattr(net, "nerf_1", None) is None and not getattr(net, "share_coarse_fine", False):
             raise ValueError("make_renderer: cfg asks for a fine pass (N_importance / cascade_samples = %d) but the network "
                              "was built without a fine NeRF -- build it with make_network(cfg) from the SAME cfg, or set "
                              "cfg.share_coarse_fine = True to evaluate one NeRF at both levels on purpose" % self.N_importance)
 
     # --- one chunk of rays: the reference's render_rays (row a2)
-    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False, out=None):
+    def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False, out=None, sched=None):
         """out: optional {output key: caller-owned tensor of this chunk's shape} (inference only) -- render() passes row slices
-        of the frame-sized maps, so the chunks of a frame are never concatenated."""
+        of the frame-sized maps, so the chunks of a frame are never concatenated.  sched: _render_overlapped's hooks for this
+        chunk -- {"wait": event the coarse MLP launch waits for, "caps": (coarse, fine) workgroup caps, "pdf_done": filled with the
+        event recorded behind sample_pdf}."""
         net, Nc, Nf = self.net, self.N_samples, self.N_importance
         n0 = net.nerf(0)
         C, K = n0.n_sem, n0.n_inst
@@ -138,7 +146,10 @@ class Renderer:
                 if self.fuse and ops.fused_supported(net.nerf(lv).desc(net.precision), zz.shape[1], self.sem_mode, noise):
                     # rows a5 + a6 in one pass: no raw image round trip (pnr_mlp_forward_composite, its own chunk order)
                     desc, img = net.packed(lv, dev, fused=ops.fused_image(self.sem_mode))
-                    res = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w, out=mine, sem_mode=self.sem_mode)
+                    if sched is not None and lv == 0 and sched.get("wait") is not None:
+                        torch.cuda.current_stream(dev).wait_event(sched["wait"])      # start beside the other chunk's fine level
+                    res = ops.mlp_forward_composite(desc, img, rays, zz, ls, li, self.white_bkgd, need_w, out=mine, sem_mode=self.sem_mode,
+                                                    wg_cap=0 if sched is None else sched["caps"][lv])
                 else:
                     desc, img = net.packed(lv, dev)
                     raw = ops.mlp_forward(desc, img, rays, zz, channel_major=True)
@@ -155,10 +166,14 @@ class Renderer:
             w0 = o0["weights"].detach().contiguous()
             if hits is not None:        # rows a7 + a8 in one launch: the wave that merged a ray's samples labels them
                 z_fine, ls1, li1 = ops.sample_pdf_labels(z, w0, Nf, hits, box_ids, u, out=own("z_vals_1"))
-                level(1, z_fine, (ls1, li1))
+                lab1 = (ls1, li1)
             else:
                 z_fine, _, _ = ops.sample_pdf(z, w0, Nf, u, want_samples=False, out=own("z_vals_1"))
-                level(1, z_fine)
+                lab1 = None
+            if sched is not None:
+                sched["pdf_done"] = torch.cuda.Event()
+                sched["pdf_done"].record(torch.cuda.current_stream(dev))
+            level(1, z_fine, lab1)
         return ret
 
     def _empty_outputs(self, lead, has_box, dev):
@@ -174,6 +189,75 @@ class Renderer:
             for k, v in m.items():
                 ret[f"{k}_{lv}"] = v.reshape(*lead, *v.shape[1:])
         return ret
+
+    # --- inference frames of several chunks: the levels of neighbouring chunks side by side
+    def _overlap_caps(self, dev, plan, grad, train, has_box, t_rand, u):
+        """(coarse, fine) workgroup caps of the overlapped frame, or None where it does not apply: inference, >= 2 chunks, both levels
+        on the two-tile kernel (the only launch that takes PNR_MLP_WG_CAP), frame-sized outputs, and a device whose compute units
+        split into two multiples of 8 (one per XCD: the dispatcher deals workgroups round-robin over the 8 XCDs, and a ninth
+        workgroup on a 32-CU XCD waits for a whole launch -- 196 + 60 took 25 ms where 192 + 64 takes 14.2, tools/overlap_probe.py) in
+        the ratio of the levels' samples within 5 %."""
+        if (not self.overlap_levels or grad or train or len(plan) < 2 or not self.fuse or not self.frame_outputs or self.N_importance <= 0
+                or self.strict_hits or t_rand is not None or u is not None or self.raw_noise_std > 0 and train
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        net, Nc, Nt = self.net, self.N_samples, self.N_samples + self.N_importance
+        for lv, N in ((0, Nc), (1, Nt)):
+            d = net.nerf(lv).desc(net.precision)
+            if not ops.fused_supported(d, N, self.sem_mode, None) or net.packed(lv, dev, fused=ops.fused_image(self.sem_mode))[0].plan != 2:
+                return None
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        cap_c = int(round(cus * Nc / float(Nc + Nt) / 8.0)) * 8
+        cap_f = cus - cap_c
+        if cus % 8 or cap_c < 8 or cap_f < 8 or abs((Nc / float(cap_c)) / (Nt / float(cap_f)) - 1.0) > 0.05:
+            return None
+        return cap_c, cap_f
+
+    def _frame_maps(self, R, has_box, dev):
+        """frame-sized output maps, keys and shapes as render_rays returns them"""
+        n0 = self.net.nerf(0)
+        C, K = n0.n_sem, n0.n_inst
+        frame = {}
+        for lv, N in ((0, self.N_samples), (1, self.N_samples + self.N_importance)):
+            need_w = self.keep_weights or lv == 0
+            m = ops._maps(None, R, N, C, K, True if has_box else None, True if has_box else None, need_w, dev)
+            m["z_vals"] = torch.empty((R, N), device=dev, dtype=torch.float32)
+            for k, v in m.items():
+                frame[f"{k}_{lv}"] = v
+        return frame
+
+    def _render_overlapped(self, rays, box, box_ids, plan, caps, lead):
+        """Chunks alternate between two side streams; a chunk's whole chain (ray_setup, coarse MLP, combine, sample_pdf + labels, fine
+        MLP, combine) stays on its stream, and ONE cross-stream rule aligns the pipeline: the coarse MLP of chunk c + 1 (on cap_c
+        workgroups) waits for chunk c's sample_pdf, i.e. starts together with chunk c's fine MLP (on cap_f workgroups).  The first
+        coarse and the last fine launch have the device to themselves.  Same kernels on the same inputs as the serial frame: every
+        map is the same bits (tests/test_gpu_configs.py::test_full_frame_in_one_launch_equals_the_chunked_frame)."""
+        dev = rays.device
+        R = rays.shape[0]
+        cap_c, cap_f = caps
+        frame = self._frame_maps(R, box is not None, dev)
+        main = torch.cuda.current_stream(dev)
+        if dev not in self._side_streams:
+            self._side_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        side = self._side_streams[dev]
+        start = torch.cuda.Event()
+        start.record(main)
+        for st in side:
+            st.wait_event(start)           # rays, boxes, the frame maps: everything the side streams read or write exists
+        prev_pdf = None
+        for ci, (s, e) in enumerate(plan):
+            sched = {"wait": prev_pdf, "caps": (0 if ci == 0 else cap_c, 0 if ci == len(plan) - 1 else cap_f), "pdf_done": None}
+            with torch.cuda.stream(side[ci & 1]):
+                o = self.render_rays(rays[s:e], box, box_ids, None, None, False, False, out={k: v[s:e] for k, v in frame.items()}, sched=sched)
+                for k, v in o.items():          # anything a chunk did not write in place (an output without an out= route)
+                    if v.data_ptr() != frame[k][s:e].data_ptr():
+                        frame[k][s:e].copy_(v)
+            prev_pdf = sched["pdf_done"]
+        for st in side:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        return {k: v.reshape(*lead, *v.shape[1:]) for k, v in frame.items()}
 
     # --- the plugin entry point (row a1)
     def render(self, batch):
@@ -200,9 +284,13 @@ class Renderer:
         self._overflow = None
         if R == 0:
             return self._empty_outputs(lead, box is not None, rays.device)
+        plan = chunk_plan(R, self.chunk_size)
+        caps = self._overlap_caps(rays.device, plan, grad, train, box is not None, t_rand, u)
+        if caps is not None:
+            return self._render_overlapped(rays, box, box_ids, plan, caps, lead)
         outs = []
         frame = None        # inference frames of several chunks: frame-sized maps, every later chunk writes its own rows
-        for s, e in chunk_plan(R, self.chunk_size):
+        for s, e in plan:
             o = self.render_rays(rays[s:e], box, box_ids,
                                  None if t_rand is None else t_rand[s:e],
                                  None if u is None else u[s:e], train, grad,

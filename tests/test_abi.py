@@ -99,11 +99,15 @@ def test_descriptor_diagnostic_words_are_validated():
     lib = _lib.load()
     ok = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(ok)) > 0
-    for flags in (2, 0x80, 0x10000, 0x10, 0x7B00, -1):
+    for flags in (2, 0x80, 0x2000000, 0x10, 0x7B00, -1):
         d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
         d.flags = flags
         assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1, hex(flags)
         assert b"flags" in lib.pnr_last_error()
+    for cap in (8, 64, 192, 511):          # PNR_MLP_WG_CAP(n): bits 16..24, a share of the compute units for a plan-2 launch
+        d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
+        d.flags = cap << 16
+        assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) > 0, cap
     d = ops.make_desc(8, 256, 4, 10, 4, 45, 32, 128, "bf16")
     d.clk_probe[0] = 0x1008
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(d)) == -1 and b"clk_probe" in lib.pnr_last_error()

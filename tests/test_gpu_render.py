@@ -269,6 +269,43 @@ def test_chunked_frame_is_written_in_place_and_equals_one_chunk(dev):
 
 
 
+@pytest.mark.parametrize("act", ["none", "softmax"])
+@pytest.mark.parametrize("heads,with_box", [((45, 32), True), ((45, 0), True), ((0, 0), False)])
+def test_overlapped_levels_equal_the_serial_frame(dev, heads, with_box, act):
+    """Inference frames of several chunks run the fine level of chunk c beside the coarse level of chunk c + 1 (two streams, the
+    two-tile MLP launches on 3/4 and 1/4 of the compute units: Renderer._render_overlapped, PNR_MLP_WG_CAP).  Same kernels on the
+    same inputs: every map is the serial frame's (cfg.overlap_levels = False), bit for bit -- five chunks with a ragged last one,
+    with and without heads / boxes, logits and softmax compositing, and twice in a row (the side streams are reused)."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    C, K = heads
+    if act == "softmax" and not C:
+        pytest.skip("no learned field to activate")
+    cfg = NS(N_samples=64, N_importance=128, num_classes=C, num_instances=K, precision="bf16", chunk_size=4096, keep_weights=True,
+             semantic_activation=act)
+    torch.manual_seed(5)
+    net = make_network(cfg).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[::29][:18000].contiguous().to(dev)
+    b = {"rays": rays[None]}
+    if with_box:
+        box, ids = synthetic.random_boxes(16, max(C, 1), max(K, 1))
+        b.update(bbox=box.to(dev), bbox_ids=ids.to(dev))
+    with torch.no_grad():
+        r_over = make_renderer(cfg, net)
+        assert r_over._overlap_caps(dev, [(0, 1), (1, 2)], False, False, with_box, None, None) == (64, 192)
+        over = r_over.render(b)
+        over2 = r_over.render(b)
+        cfg.overlap_levels = False
+        r_ser = make_renderer(cfg, net)
+        assert r_ser._overlap_caps(dev, [(0, 1), (1, 2)], False, False, with_box, None, None) is None
+        ser = r_ser.render(b)
+    torch.cuda.synchronize()
+    assert set(over) == set(ser)
+    for k in ser:
+        assert over[k].shape == ser[k].shape and torch.equal(over[k], ser[k]) and torch.equal(over2[k], ser[k]), k
+
+
 def test_a_ranks_share_of_the_frame_is_one_chunk(dev):
     # strong scaling over 8 ranks hands every rank 66,176 rays: with the balanced plan (renderer.chunk_plan) that is ONE chunk per
     # level -- not a 65,536-ray chunk plus a 640-ray chunk with its own launches -- and it equals the two-chunk render bit for bit
