@@ -31,6 +31,7 @@ CHUNK_QUANTUM = 1024     # rays: at 64 and at 192 samples per ray a multiple of 
                          # MLP kernels' persistent grid (256 workgroups x 256 samples)
 
 
+PREAMBLE_EARLY = os.environ.get("PNR_OVERLAP_PRE", "1") != "0"     # (A/B) overlapped frames: a chunk's ray_setup in front of the fine MLP two chunks before
 CHUNK_TAIL = 8           # a tail of at most chunk_size / CHUNK_TAIL rays joins the other chunks instead of becoming a chunk
 
 
@@ -97,6 +98,21 @@ class Renderer:
                              "was built without a fine NeRF -- build it with make_network(cfg) from the SAME cfg, or set "
                              "cfg.share_coarse_fine = True to evaluate one NeRF at both levels on purpose" % self.N_importance)
 
+    def _preamble(self, rays, box, box_ids, t_rand, z_out):
+        """a chunk's per-ray preamble: (hits or None, z of the coarse level, its labels or None)"""
+        hits = lab0 = None
+        hull = self.bbox_sampling == "hull"
+        if box is not None and self.max_hits <= ops.RAY_SETUP_MAX_HITS:
+            # rows a8 + a3 in one launch: hit lists, z and the coarse labels (pnr_ray_setup; bit for bit the separate kernels)
+            hits, z, ls0, li0 = ops.ray_setup(rays, box, box_ids, self.N_samples, self.max_hits, self.lindisp, t_rand, hull, out=z_out)
+            lab0 = (ls0, li0)
+        else:
+            if box is not None:
+                hits = ops.bbox_hits(rays, box, self.max_hits)
+            rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and hull) else rays
+            z = ops.stratified(rays_s, self.N_samples, self.lindisp, t_rand, out=z_out)
+        return hits, z, lab0
+
     # --- one chunk of rays: the reference's render_rays (row a2)
     def render_rays(self, rays, box=None, box_ids=None, t_rand=None, u=None, train=False, grad=False, out=None, sched=None):
         """out: optional {output key: caller-owned tensor of this chunk's shape} (inference only) -- render() passes row slices
@@ -112,16 +128,10 @@ class Renderer:
         if t_rand is None and self.perturb > 0 and train:
             t_rand = torch.rand((rays.shape[0], Nc), device=dev)
         own = (lambda key: out.get(key)) if (out and not grad) else (lambda key: None)
-        hull = self.bbox_sampling == "hull"
-        if box is not None and self.max_hits <= ops.RAY_SETUP_MAX_HITS:
-            # rows a8 + a3 in one launch: hit lists, z and the coarse labels (pnr_ray_setup; bit for bit the separate kernels)
-            hits, z, ls0, li0 = ops.ray_setup(rays, box, box_ids, Nc, self.max_hits, self.lindisp, t_rand, hull, out=own("z_vals_0"))
-            lab0 = (ls0, li0)
+        if sched is not None and sched.get("pre") is not None:
+            hits, z, lab0 = sched["pre"]                    # this chunk's preamble was issued earlier on this stream (_render_overlapped)
         else:
-            if box is not None:
-                hits = ops.bbox_hits(rays, box, self.max_hits)
-            rays_s = ops.restrict_rays(rays, hits[0], hits[2]) if (hits is not None and hull) else rays
-            z = ops.stratified(rays_s, Nc, self.lindisp, t_rand, out=own("z_vals_0"))
+            hits, z, lab0 = self._preamble(rays, box, box_ids, t_rand, own("z_vals_0"))
         if hits is not None and self.strict_hits:          # accumulated on the device; checked ONCE at the end of render() (a single sync)
             over = torch.stack([(hits[2] > self.max_hits).sum(), hits[2].max()])
             self._overflow = over if self._overflow is None else torch.stack([self._overflow[0] + over[0],
@@ -173,6 +183,8 @@ class Renderer:
             if sched is not None:
                 sched["pdf_done"] = torch.cuda.Event()
                 sched["pdf_done"].record(torch.cuda.current_stream(dev))
+                if sched.get("before_fine") is not None:
+                    sched["before_fine"]()                  # the preamble of the chunk after next, in front of this chunk's fine MLP
             level(1, z_fine, lab1)
         return ret
 
@@ -245,8 +257,15 @@ class Renderer:
         for st in side:
             st.wait_event(start)           # rays, boxes, the frame maps: everything the side streams read or write exists
         prev_pdf = None
+        pre = {}
+
+        def preamble(cj):               # issued on chunk cj's stream two chunks early: in front of chunk cj - 2's fine MLP
+            sj, ej = plan[cj]
+            pre[cj] = self._preamble(rays[sj:ej], box, box_ids, None, frame["z_vals_0"][sj:ej])
         for ci, (s, e) in enumerate(plan):
-            sched = {"wait": prev_pdf, "caps": (0 if ci == 0 else cap_c, 0 if ci == len(plan) - 1 else cap_f), "pdf_done": None}
+            sched = {"wait": prev_pdf, "caps": (0 if ci == 0 else cap_c, 0 if ci == len(plan) - 1 else cap_f), "pdf_done": None,
+                     "pre": pre.pop(ci, None),
+                     "before_fine": (lambda cj=ci + 2: preamble(cj)) if (PREAMBLE_EARLY and ci + 2 < len(plan)) else None}
             with torch.cuda.stream(side[ci & 1]):
                 o = self.render_rays(rays[s:e], box, box_ids, None, None, False, False, out={k: v[s:e] for k, v in frame.items()}, sched=sched)
                 for k, v in o.items():          # anything a chunk did not write in place (an output without an out= route)
