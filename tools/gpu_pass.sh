@@ -29,6 +29,10 @@ run_bench() {
 db() { find $O/$1 -name "*.db" | head -1; }
 run_prof() {
   cd /tmp
+  # the rocprofv3 passes trace the SERIAL frame (PNR_OVERLAP=0): every k_mlp_tt dispatch is then a whole-device launch, which is what
+  # bench.py's roofline launch (hipEvents around standalone launches) is compared with; the timed frames of bench.py itself run the
+  # fine level of a chunk beside the coarse level of the next on 192 + 64 workgroups (profiles/r06/r06r)
+  export PNR_OVERLAP=0
   timeout 240 rocprofv3 --kernel-trace --stats -d $O/prof_trace -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --train-steps 0 > $O/prof_trace.log 2>&1
   timeout 240 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-roofline --train-steps 0 > $O/prof_fetch.log 2>&1
   timeout 240 rocprofv3 --pmc WRITE_SIZE -d $O/prof_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-roofline --train-steps 0 > $O/prof_write.log 2>&1
@@ -37,6 +41,7 @@ run_prof() {
   timeout 200 rocprofv3 --kernel-trace --stats -d $O/train_trace -o t -- python $R/tools/train_trace.py 4 > $O/train_trace.log 2>&1
   timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/train_fetch -o t -- python $R/tools/train_trace.py 3 > $O/train_fetch.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/train_write -o t -- python $R/tools/train_trace.py 3 > $O/train_write.log 2>&1
+  unset PNR_OVERLAP
   cd $R
   python tools/prof_summary.py $(db prof_trace) $(db prof_fetch) $(db prof_write) $(db prof_sq) $(db prof_l2) > $O/rocprof_summary.txt 2> $O/summary.err
   python tools/update_traffic.py $(db prof_fetch) $(db prof_write) ${T:0:3}/${T}_rocprof_summary.txt $(db prof_trace) > $O/traffic.log 2>&1; cp profiles/latest_traffic.json $O/latest_traffic.json

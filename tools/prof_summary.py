@@ -9,7 +9,7 @@ def kernel_stats(path):
     rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                        "from kernels group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
-    print(f"== kernel trace: {path}")
+    print(f"== kernel trace: {path}   (tools/gpu_pass.sh traces the SERIAL frame, PNR_OVERLAP=0: every MLP dispatch a whole-device launch)")
     print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'pct':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
     for r in rows[:14]:
         print(f"{r[0][:72]:72s} {r[1]:6d} {r[2] / 1e6:10.3f} {100 * r[2] / tot:6.2f} {r[3] / 1e3:10.1f} {r[4] / 1e3:10.1f} {r[5] / 1e3:10.1f}")
