@@ -746,6 +746,27 @@ def test_two_tile_kernels_for_a_third_semantic_block(dev, R, N, C, depth, tap):
     assert float((bs["semantic"].sum(-1) - bs["acc"]).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("R,N", [(3000, 192), (1001, 64), (7, 32)])
+def test_two_tile_launch_on_a_share_of_the_device_is_the_same_launch(dev, R, N):
+    """PNR_MLP_WG_CAP(n) in pnr_mlp_desc.flags: the plan-2 launch on at most n workgroups (the persistent grid walks the 256-sample groups
+    with a stride of its size, every group is independent) -- records, quadruples and maps are the whole-device launch's bit for bit,
+    for caps below, at and above the number of groups; the cap does not change the image (same packed bytes)."""
+    from types import SimpleNamespace as NS
+    from panopticnerf_amd import make_network
+    torch.manual_seed(R + N)
+    net = make_network(NS(N_importance=128, num_classes=45, num_instances=32)).to(dev).eval()
+    synthetic.trained_like_(net, 0.05)
+    rays = synthetic.camera_rays()[:: max(1, (1408 * 376) // R)][:R].contiguous().to(dev)
+    z = ops.stratified(rays, N)
+    d, img = net.packed(1, dev, "bf16", fused=True)
+    assert d.plan == 2
+    ref = ops.mlp_forward_composite(d, img, rays, z, None, None, False, True)
+    for cap in (8, 64, 192, 248, 511):
+        out = ops.mlp_forward_composite(d, img, rays, z, None, None, False, True, wg_cap=cap)
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), (cap, k)
+
+
 def test_two_tile_kernel_is_the_default_where_it_exists_and_can_be_capped(dev, monkeypatch):
     """The renderer's fused inference pass packs the BEST plan the geometry has (pnr_mlp_fused_plan: 2 = k_mlp_tt for the benched
     network); PNR_FUSED_PLAN=1 (A/B runs) caps it at the ping-pong kernel's plan.  Same frame either way, bit for bit."""
