@@ -43,6 +43,11 @@ WAIT2 = os.environ.get("PNR_TT_WAIT2", "0") != "0"             # (A/B builds) on
 SAVE_PROTO = os.environ.get("PNR_TT_SAVE", "0") != "0"
 ABL_ALL = int(os.environ.get("PNR_TT_ABL", "0"))        # (A/B builds; results INVALID) the timing-only ablations in every kernel: 1 = no weight pieces
 SAVE_REGION = 352 * 1024                # bytes per wave and group: 2 tiles x 32 samples x 5.5 KiB
+# The pack / ReLU / v_accvgpr_write triples as a three-stage software pipeline over the packed registers of a unit (closure j: write of pair
+# j - 2, ReLU of pair j - 1, convert of pair j; three rotating temporaries): no instruction of a closure depends on another one of the same
+# closure, where the plain form is three DEPENDENT instructions back to back (A/B builds: PNR_TT_PACK_PIPE=0)
+PACK_PIPE = os.environ.get("PNR_TT_PACK_PIPE", "1") != "0"
+V_T2 = 15                               # third pack temporary (V_TRACE's register: trace / save-prototype builds keep the plain form)
 SHARE_BIAS = os.environ.get("PNR_TT_SHARE_BIAS", "1") != "0"     # one armed accumulator per block: tile 1's first MFMA reads tile 0's (A/B builds)
 NSLOT, SLOT = 4, int(os.environ.get("PNR_TT_SLOT_KIB", "33")) * 1024      # (A/B builds: the slot stride, tools/build_tt_variant.sh)
 ACC_PERM = [int(x) for x in os.environ.get("PNR_TT_ACC_PERM", "0,1,2,3,4,5,6,7").split(",")]     # register block of accumulator i (A/B builds)
@@ -869,6 +874,8 @@ class Gen:
     # ------------------------------------------------------------------ pack / ReLU of a unit's accumulators -> list of (dst, closure)
     def pack_ops(self, u):
         l = self.layers[u["layer"]]
+        if PACK_PIPE and not self.trace and not SAVE_PROTO:
+            return self.pack_ops_pipelined(u)
         out = []
         for bi, blk in enumerate(u["blocks"]):
             for t in range(2):
@@ -888,6 +895,50 @@ class Gen:
                                 self.e("v_pk_max_i16 v%d, v%d, 0" % (tmp, tmp))
                             self.e("v_accvgpr_write_b32 a%d, v%d" % (dst.base + p, tmp))
                     out.append(((dst.kind, dst.base + p), fn, u["accs"][(bi, t)]))
+        return out
+
+    def pack_ops_pipelined(self, u):
+        """-> [([destinations final after this closure], closure, accumulator)]: see PACK_PIPE"""
+        l = self.layers[u["layer"]]
+        relu = l["mode"] == "relu"
+        pairs = []
+        for bi, blk in enumerate(u["blocks"]):
+            for t in range(2):
+                a = self.acc_reg(u["accs"][(bi, t)])
+                dst = self.out_block(l, blk, t)
+                for p in range(8):
+                    pairs.append((a + 2 * p, dst.kind, dst.base + p, u["accs"][(bi, t)]))
+        T = (V_T0, V_T1, V_T2)
+        n = len(pairs)
+
+        def convert(k):
+            src, kind, d, _ = pairs[k]
+            self.e("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (d if (kind == "v" and not relu) else T[k % 3], src, src + 1))
+
+        def activate(k):
+            _, kind, d, _ = pairs[k]
+            if relu:
+                self.e("v_pk_max_i16 v%d, v%d, 0" % (d if kind == "v" else T[k % 3], T[k % 3]))
+
+        def store(k):
+            _, kind, d, _ = pairs[k]
+            if kind == "a":
+                self.e("v_accvgpr_write_b32 a%d, v%d" % (d, T[k % 3]))
+
+        def final_at(k):
+            kind = pairs[k][1]
+            return k + 2 if kind == "a" else (k + 1 if relu else k)
+        out = []
+        for j in range(n + 2):
+            def fn(j=j):
+                if 0 <= j - 2 < n:
+                    store(j - 2)
+                if 0 <= j - 1 < n:
+                    activate(j - 1)
+                if j < n:
+                    convert(j)
+            done = [(pairs[k][1], pairs[k][2]) for k in range(max(0, j - 2), min(n, j + 1)) if final_at(k) == j]
+            out.append((done, fn, pairs[min(j, n - 1)][3]))
         return out
 
     # ------------------------------------------------------------------ one unit of MFMAs with its fillers
@@ -948,7 +999,11 @@ class Gen:
             for dst, fn in lst:
                 musts.append(fn if not self.abl & 4 else (lambda: None))
                 pack_fns.add(musts[-1])
-                dls.append(reads.get(dst))
+                if isinstance(dst, list):           # pipelined packs: every destination that becomes final in this closure
+                    dd = [reads[d] for d in dst if d in reads]
+                    dls.append(min(dd) if dd else None)
+                else:
+                    dls.append(reads.get(dst))
             musts.append(lambda a=a: self.acc_release([a]))
             dls.append(None)
             if k < len(plans):
