@@ -282,7 +282,7 @@ def test_overlapped_levels_equal_the_serial_frame(dev, heads, with_box, act):
     if act == "softmax" and not C:
         pytest.skip("no learned field to activate")
     cfg = NS(N_samples=64, N_importance=128, num_classes=C, num_instances=K, precision="bf16", chunk_size=4096, keep_weights=True,
-             semantic_activation=act)
+             semantic_activation=act, overlap_levels=True)          # (explicit: PNR_OVERLAP=0 in the environment must not switch the test off)
     torch.manual_seed(5)
     net = make_network(cfg).to(dev).eval()
     synthetic.trained_like_(net, 0.05)
